@@ -1,0 +1,188 @@
+/* wis_hip.h — C-ABI of libwis_hip.so: the MI355X-native Whisper ASR hot path for
+ * Willow Inference Server (WIS).
+ *
+ * The reference has no FFI of its own for this path: the boundary is the set of Python
+ * call sites in reference main.py / wis/audio.py.  Each entry point below
+ * names the reference expression it replaces.  Everything is `extern "C"`, plain pointers
+ * and sizes; the caller owns every host buffer, the library owns device memory (except
+ * where a `*_dev` pointer is explicitly handed in).  All functions return WIS_OK (0) or a
+ * negative WIS_E_* code; the message is available from wis_last_error() (thread-local).
+ * No exceptions cross the boundary.  No CPU fallback exists: without a gfx950 device every
+ * compute entry point fails with WIS_E_HIP.
+ */
+#ifndef WIS_HIP_H
+#define WIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WIS_ABI_VERSION 1
+
+#define WIS_OK             0
+#define WIS_E_ARG         -1   /* bad argument */
+#define WIS_E_FORMAT      -2   /* malformed audio container / weight index */
+#define WIS_E_NOMEM       -3
+#define WIS_E_CHECKSUM    -4   /* FLAC MD5 mismatch */
+#define WIS_E_HIP         -5   /* HIP runtime error or no usable device */
+#define WIS_E_STATE       -6   /* capacity exceeded / handle misuse */
+#define WIS_E_UNSUPPORTED -7
+
+/* audio front-end constants: reference wis/audio.py:17-25 */
+#define WIS_SAMPLE_RATE 16000
+#define WIS_N_FFT       400
+#define WIS_HOP         160
+#define WIS_N_MELS      80
+#define WIS_N_SAMPLES   480000   /* 30 s window */
+#define WIS_N_FRAMES    3000
+
+typedef struct wis_model wis_model_t;
+
+/* ---- library ------------------------------------------------------------------------ */
+int         wis_version(void);              /* returns WIS_ABI_VERSION */
+const char* wis_last_error(void);           /* valid until the next call on this thread */
+int         wis_device_count(void);         /* replaces torch.cuda.device_count(), main.py:252-262 */
+/* replaces ctranslate2.get_supported_compute_types(device), main.py:454 — writes a
+ * NUL-terminated comma list ("float16,float32") */
+int         wis_supported_compute_types(int device, char* out, size_t out_cap);
+
+/* ---- a1: container decode (replaces librosa.load(audio_file, sr=16000, mono=True),
+ * main.py:579).  FLAC or RIFF/WAVE bytes -> malloc'ed mono f32 PCM; free with
+ * wis_audio_free.  md5_status_out: 1 verified, -1 no signature present (WAV / unsigned). */
+int  wis_audio_decode(const void* bytes, size_t n_bytes, float** pcm_out,
+                      int64_t* n_samples_out, int* sample_rate_out, int* md5_status_out);
+void wis_audio_free(float* pcm);
+
+/* ---- a2+a3: log-mel front-end (replaces wis.audio.log_mel_spectrogram(pad_or_trim(x)),
+ * wis/audio.py:28-51,72-103; call sites main.py:606-614).
+ * pcm: n_win windows, window w has n_samples[w] valid samples starting at pcm + w*stride
+ * (zero-padded / truncated to 480000 on device: pad_or_trim).  mel_out: [n_win][80][3000] f32.
+ * pcm_on_device / mel_on_device select host or device pointers for each side. */
+int wis_logmel(int device, const float* pcm, int64_t stride, const int64_t* n_samples, int n_win,
+               int pcm_on_device, float* mel_out, int mel_on_device);
+
+/* ---- a6: model lifecycle (replaces ctranslate2.models.Whisper(path, device=..,
+ * compute_type=.., device_index=[..]), main.py:341-444).  One handle = one replica on one
+ * GPU; the Python shim creates one per listed device_index entry. */
+typedef struct {
+  int32_t d_model, n_heads, n_enc_layers, n_dec_layers;
+  int32_t n_vocab;        /* 51865 multilingual */
+  int32_t n_audio_ctx;    /* 1500 */
+  int32_t n_text_ctx;     /* 448 */
+  int32_t n_mels;         /* 80 */
+  int32_t max_batch;      /* utterances (30 s windows) per device batch */
+  int32_t max_beam;       /* largest beam_size that will be requested */
+  int32_t eot, sot, no_timestamps, no_speech;   /* 50257, 50258, 50363, 50362 */
+  const int32_t* suppress_ids;       int32_t n_suppress;        /* CT2 config.json:suppress_ids */
+  const int32_t* suppress_ids_begin; int32_t n_suppress_begin;  /* [220, 50257] */
+  const int32_t* lang_ids;           int32_t n_lang;            /* 50259..50357 */
+} wis_config_t;
+
+#define WIS_DT_F32 0
+#define WIS_DT_F16 1
+/* One weight tensor inside the arena.  Names follow the CTranslate2 WhisperSpec variable
+ * names, e.g. "encoder/layer_0/self_attention/linear_0/weight". */
+typedef struct {
+  const char* name;
+  int32_t     dtype;       /* WIS_DT_* */
+  int32_t     rank;
+  int64_t     shape[4];
+  uint64_t    offset;      /* byte offset into the arena */
+} wis_tensor_t;
+
+/* arena: ONE contiguous block holding every tensor (host memory, or device memory on
+ * `device` when arena_on_device != 0 — e.g. the buffer a RCCL broadcast just filled).
+ * Weights are re-packed on the GPU into the kernels' layouts; the arena is not retained. */
+int  wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_bytes,
+                      int arena_on_device, const wis_tensor_t* tensors, int n_tensors,
+                      int device, wis_model_t** out);
+void wis_model_destroy(wis_model_t* m);
+size_t wis_model_device_bytes(const wis_model_t* m);
+
+/* ---- a7-a13: generate (replaces whisper_model.generate(features, [prompt]*B,
+ * beam_size=.., return_scores=False) and results[i].sequences_ids[0], main.py:685-693,707,713;
+ * decoding defaults are CTranslate2 4.1.0's because WIS passes none). */
+#define WIS_IN_MEL_HOST 0   /* f32 [B][80][3000] host   (StorageView.from_array, main.py:638,685) */
+#define WIS_IN_MEL_DEV  1   /* same, device memory */
+#define WIS_IN_PCM_HOST 2   /* f32 [B][480000] host: log-mel runs on the GPU, mel never leaves HBM */
+#define WIS_IN_PCM_DEV  3
+
+typedef struct {
+  int32_t input_kind;       /* WIS_IN_* */
+  int32_t beam_size;        /* 1 = greedy (CT2 GreedySearch), >1 = beam search */
+  int32_t max_new_tokens;   /* 0 => min(n_text_ctx/2, n_text_ctx - P) = 224 */
+  float   length_penalty;   /* CT2 default 1 */
+  float   patience;         /* CT2 default 1 */
+  int32_t suppress_blank;   /* CT2 default 1: suppress_ids_begin masked at the first step */
+  int32_t suppress_default; /* CT2 suppress_tokens=[-1]: mask cfg.suppress_ids every step */
+  int32_t fixed_new_tokens; /* measurement convention: EOT masked until this many
+                               tokens were generated, then forced.  0 = off (product default) */
+  int32_t sync_every;       /* decode steps enqueued between host checks of the done flag; 0 => 4 */
+} wis_gen_opts_t;
+
+/* out_ids: [B][max_new] (max_new = resolved max_new_tokens), out_len: [B], out_score: [B]
+ * (length-normalised log-prob of the returned hypothesis) or NULL.  Blocking; one call at a
+ * time per handle (the shim serialises per replica). */
+int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
+                 const wis_gen_opts_t* opts, int32_t* out_ids, int32_t* out_len, float* out_score);
+
+/* ---- a14: language detection (replaces whisper_model.detect_language(features),
+ * main.py:637-643): probabilities over cfg.lang_ids, [B][n_lang]. */
+int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int B, float* lang_probs);
+
+/* ---- parity taps (teacher-forced); not used by the product path -------------------- */
+/* encoder output [B][1500][d] f32 */
+int wis_debug_encode(wis_model_t* m, const float* input, int input_kind, int B, float* enc_out);
+/* logits [B][T][n_vocab] f32 for decoder inputs dec_in [B][T] (no suppression applied) */
+int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B,
+                     const int32_t* dec_in, int T, float* logits);
+
+/* ---- timing taps: wall/device ms of the stages of the LAST wis_generate on this handle */
+typedef struct {
+  float logmel_ms, encoder_ms, crosskv_ms, prefill_ms, decode_ms, total_ms;
+  int32_t decode_steps;
+  int32_t reserved;
+} wis_timing_t;
+int wis_last_timing(const wis_model_t* m, wis_timing_t* t);
+
+/* ---- roofline tap (bench.py): launch the decoder's weight-streaming skinny-GEMM kernel once over
+ * EVERY decoder weight matrix of the model (6 per layer + the vocabulary projection = the weight
+ * stream of one decode step, >> the 256 MiB Infinity Cache for the large sizes), `passes` times,
+ * with M activation rows, bracketed by HIP events on the model's stream.  Outputs: total device
+ * milliseconds, launches per pass, algorithmic (weight) bytes per pass. */
+int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, int* launches_per_pass,
+                            double* bytes_per_pass);
+
+/* ---- raw device helpers + single-kernel entry points (used by tests/, bench.py roofline
+ * timing and __graft_entry__; all pointers below are DEVICE pointers on `device`) -------- */
+int wis_dev_alloc(int device, size_t bytes, void** out);
+int wis_dev_free(int device, void* p);
+int wis_dev_h2d(int device, void* dst, const void* src, size_t bytes);
+int wis_dev_d2h(int device, void* dst, const void* src, size_t bytes);
+int wis_dev_sync(int device);
+
+/* C[M][N] = epilogue(A[M][K](lda) . W[N][K]^T + bias): the encoder MFMA GEMM.
+ * flags: 1 = GELU, 2 = add residual (f32, [M][N]) , 4 = output f32 (else f16) */
+int wis_op_gemm(int device, const void* A_f16, int lda, const void* W_f16, const float* bias,
+                const float* residual, void* C, int M, int N, int K, int flags);
+/* y f16 [M][d] = LayerNorm(x f32 [M][d]) * gamma + beta, eps 1e-5 */
+int wis_op_layernorm(int device, const float* x, const float* gamma, const float* beta,
+                     void* y_f16, int M, int d);
+/* non-causal MHA over T keys: qk f16 [B*T][2d] (Q pre-scaled | K), vt f16 [B][H][64][Tpad],
+ * out f16 [B*T][d] */
+int wis_op_enc_attention(int device, const void* qk_f16, const void* vt_f16, void* out_f16,
+                         int B, int T, int Tpad, int H);
+/* skinny GEMM used by the decoder: y[M][N] = epi(LN?(x)[M][K] . W[N][K]^T + bias); W is the
+ * plain row-major f16 matrix (packed internally for the call).
+ * flags: 1 = GELU, 2 = residual add in place into y f32, 4 = y f32 (else f16), 8 = fuse LayerNorm
+ * (x is f32 [M][K], gamma/beta given); without 8, x is f16 [M][K]. */
+int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta,
+                const void* W_f16, const float* bias, void* y, int M, int N, int K, int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WIS_HIP_H */

@@ -1,0 +1,196 @@
+"""ORACLE (test infrastructure, NOT product code): plain-PyTorch fp32 CPU restatement of what
+`ctranslate2.models.Whisper.generate / detect_language` computes for WIS (call sites: reference
+main.py:535-537, 638-639, 685-693; result access main.py:707,713).
+
+PARITY UNPINNED: ctranslate2==4.1.0 (reference requirements.txt:22) is a third-party wheel that is
+neither vendored under /root/reference nor installed/installable offline, and the reference holds
+no tests, golden transcripts or fixtures for this boundary.  This file restates
+the published algorithm:
+  * forward math = Whisper (pre-LN transformer; erf-GELU; k_proj without bias; q scaled by
+    head_dim**-0.5; tied output projection) — cross-checked in tests/test_oracle_whisper.py against
+    the independent HF implementation `transformers.models.whisper.modeling_whisper`;
+  * decoding = CTranslate2 4.1.0 `BeamSearch::search` / `GreedySearch::search` with the defaults WIS
+    leaves in force (beam_size from the request, patience 1, length_penalty 1, num_hypotheses 1,
+    max_length 448, suppress_blank, suppress_tokens=[-1]) — restated from recall.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EOT, SOT = 50257, 50258
+
+
+def _t(w, name):
+    return torch.from_numpy(np.asarray(w[name], dtype=np.float32))
+
+
+class WhisperRef:
+    """weights: name -> ndarray in CTranslate2 WhisperSpec naming (wis_hip.weights)."""
+
+    def __init__(self, weights, d_model, n_layers, n_heads, n_vocab=51865, n_text_ctx=448, enc_pos=None):
+        self.d, self.L, self.H, self.V, self.ctx = d_model, n_layers, n_heads, n_vocab, n_text_ctx
+        self.w = {k: _t(weights, k) for k in weights}
+        if enc_pos is None and "encoder/position_encodings/encodings" in self.w:
+            enc_pos = self.w["encoder/position_encodings/encodings"].numpy()
+        if enc_pos is None:
+            half = d_model // 2
+            inc = np.log(10000.0) / (half - 1)
+            inv = np.exp(-inc * np.arange(half)).astype(np.float32)
+            t = np.arange(1500, dtype=np.float32)[:, None] * inv[None, :]
+            enc_pos = np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+        self.enc_pos = torch.from_numpy(np.asarray(enc_pos, np.float32))
+
+    # ---- building blocks ---------------------------------------------------------------
+    def _ln(self, x, p):
+        return F.layer_norm(x, (self.d,), self.w[p + "/gamma"], self.w[p + "/beta"], 1e-5)
+
+    def _lin(self, x, p):
+        return F.linear(x, self.w[p + "/weight"], self.w[p + "/bias"])
+
+    def _mha(self, q, k, v, mask=None):
+        B, Tq, _ = q.shape
+        Tk = k.shape[1]
+        H, dh = self.H, self.d // self.H
+        q = q.view(B, Tq, H, dh).transpose(1, 2) * dh ** -0.5
+        k = k.view(B, Tk, H, dh).transpose(1, 2)
+        v = v.view(B, Tk, H, dh).transpose(1, 2)
+        s = q @ k.transpose(-1, -2)
+        if mask is not None:
+            s = s + mask
+        return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Tq, self.d)
+
+    # ---- encoder ---------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, mel):
+        x = torch.as_tensor(np.asarray(mel, np.float32))
+        x = F.gelu(F.conv1d(x, self.w["encoder/conv1/weight"], self.w["encoder/conv1/bias"], padding=1))
+        x = F.gelu(F.conv1d(x, self.w["encoder/conv2/weight"], self.w["encoder/conv2/bias"], stride=2, padding=1))
+        x = x.permute(0, 2, 1) + self.enc_pos
+        for l in range(self.L):
+            p = f"encoder/layer_{l}/"
+            h = self._ln(x, p + "self_attention/layer_norm")
+            q, k, v = self._lin(h, p + "self_attention/linear_0").split(self.d, dim=-1)
+            x = x + self._lin(self._mha(q, k, v), p + "self_attention/linear_1")
+            h = self._ln(x, p + "ffn/layer_norm")
+            x = x + self._lin(F.gelu(self._lin(h, p + "ffn/linear_0")), p + "ffn/linear_1")
+        return self._ln(x, "encoder/layer_norm")
+
+    # ---- decoder: teacher-forced logits for a token prefix ---------------------------------
+    @torch.no_grad()
+    def decode_logits(self, tokens, memory):
+        """tokens [N, T] (int), memory [N, 1500, d] -> logits [N, T, V] (no logits processors)."""
+        tok = torch.as_tensor(np.asarray(tokens, np.int64))
+        N, T = tok.shape
+        x = self.w["decoder/embeddings/weight"][tok] + self.w["decoder/position_encodings/encodings"][:T]
+        mask = torch.full((T, T), float("-inf")).triu(1)
+        for l in range(self.L):
+            p = f"decoder/layer_{l}/"
+            h = self._ln(x, p + "self_attention/layer_norm")
+            q, k, v = self._lin(h, p + "self_attention/linear_0").split(self.d, dim=-1)
+            x = x + self._lin(self._mha(q, k, v, mask), p + "self_attention/linear_1")
+            h = self._ln(x, p + "attention/layer_norm")
+            q = self._lin(h, p + "attention/linear_0")
+            k, v = self._lin(memory, p + "attention/linear_1").split(self.d, dim=-1)
+            x = x + self._lin(self._mha(q, k, v), p + "attention/linear_2")
+            h = self._ln(x, p + "ffn/layer_norm")
+            x = x + self._lin(F.gelu(self._lin(h, p + "ffn/linear_0")), p + "ffn/linear_1")
+        x = self._ln(x, "decoder/layer_norm")
+        return x @ self.w["decoder/embeddings/weight"].t()
+
+    # ---- logits processors -----------------------------------------------
+    @staticmethod
+    def apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank=True, fixed_new=0):
+        """logits [rows, V] float tensor (modified copy).  `fixed_new` is the measurement convention of SURVEY §8d
+        (EOT masked until `fixed_new` tokens exist, then forced); 0 = off."""
+        lg = logits.clone()
+        if suppress_ids is not None and len(suppress_ids):
+            lg[:, list(suppress_ids)] = float("-inf")
+        if suppress_blank and step == 0:
+            lg[:, list(suppress_begin)] = float("-inf")
+        if fixed_new > 0:
+            if step < fixed_new:
+                lg[:, EOT] = float("-inf")
+            else:
+                keep = lg[:, EOT].clone()
+                lg[:] = float("-inf")
+                lg[:, EOT] = keep
+        return lg
+
+    # ---- search: CTranslate2 BeamSearch::search (beam_size 1 degenerates to GreedySearch) ------
+    @torch.no_grad()
+    def generate(self, mel, prompt, beam_size=5, max_new_tokens=0, length_penalty=1.0, patience=1.0, suppress_ids=(),
+                 suppress_begin=(220, EOT), suppress_blank=True, fixed_new=0, memory=None, return_trace=False):
+        """One utterance: mel [80,3000] (or memory [1500,d]), prompt list[int] -> (ids, score, trace).
+
+        The prompt minus its last token primes the decoder; the last prompt token is the first decoder input
+        (CT2 models/whisper.cc).  2*beam candidates per step over the flattened beam x vocab log-probs + cumulative
+        score (ties: lower flat id first); a candidate in the top `beam` that is EOT (or on the last step) is a
+        finished hypothesis (EOT not included, raw cumulative score stored) and its slot is refilled from the next
+        non-EOT candidate beyond the first `beam`; the utterance ends when `round(beam*patience)` hypotheses exist
+        (allow_early_exit additionally requires the top candidate to be finished and is only active for patience 1,
+        length_penalty 0), or on the last step; hypotheses are ranked by score / len**length_penalty.
+        trace = per-step list of (top1-top2 candidate score margin) for the margin rule of SURVEY §8c."""
+        if memory is None:
+            memory = self.encode(np.asarray(mel, np.float32)[None])[0]
+        memory = torch.as_tensor(np.asarray(memory, np.float32))
+        P = len(prompt)
+        max_new = max_new_tokens if max_new_tokens > 0 else min(self.ctx // 2, self.ctx - P)
+        k = beam_size
+        ncand = 2 * k
+        max_cand = max(1, int(round(k * patience)))
+        allow_early_exit = (patience == 1 and length_penalty == 0)
+        V = self.V
+        seqs = [list(prompt) for _ in range(k)]           # full decoder inputs per live beam
+        cum = [0.0] + [float("-inf")] * (k - 1)           # GPU path: beams tiled up front
+        hyps = []                                         # (raw_score, tokens)
+        trace = []
+        mem_k = memory[None].expand(k, -1, -1)
+        for step in range(max_new):
+            logits = self.decode_logits(np.asarray(seqs), mem_k)[:, -1, :].float()
+            logits = self.apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank, fixed_new)
+            logp = torch.log_softmax(logits, dim=-1)
+            flat = (logp + torch.tensor(cum, dtype=torch.float32)[:, None]).reshape(-1)
+            # top-ncand, ties by lower flat index: stable sort on (-value)
+            vals, order = torch.sort(flat, descending=True, stable=True)
+            cand_score = vals[:ncand].tolist()
+            cand_flat = order[:ncand].tolist()
+            trace.append(cand_score[0] - cand_score[1] if ncand > 1 else float("inf"))
+            cand_word = [f % V for f in cand_flat]
+            cand_org = [f // V for f in cand_flat]
+            is_last = step + 1 >= max_new
+            nxt, second, top_finished = [], k, False
+            for kk in range(k):
+                choice = kk
+                eos = cand_word[kk] == EOT
+                if eos or is_last:
+                    if kk == 0:
+                        top_finished = True
+                    gen = seqs[cand_org[kk]][P:] + ([] if eos else [cand_word[kk]])
+                    hyps.append((cand_score[kk], gen))
+                    for j in range(second, ncand):
+                        if cand_word[j] != EOT:
+                            choice, second = j, j + 1
+                            break
+                nxt.append(choice)
+            finished = is_last or ((top_finished and len(hyps) >= max_cand) if allow_early_exit else len(hyps) >= max_cand)
+            if finished:
+                break
+            seqs = [seqs[cand_org[c]] + [cand_word[c]] for c in nxt]
+            cum = [cand_score[c] for c in nxt]
+
+        def norm(h):
+            s, toks = h
+            return s / (len(toks) ** length_penalty) if length_penalty != 0 else s
+        best = max(range(len(hyps)), key=lambda i: (norm(hyps[i]), -i))
+        out = (hyps[best][1], norm(hyps[best]))
+        return out + (trace,) if return_trace else out
+
+    @torch.no_grad()
+    def detect_language(self, mel, lang_ids):
+        """CT2 Whisper::detect_language: one decoder step on [sot], softmax restricted to the language tokens."""
+        memory = self.encode(np.asarray(mel, np.float32)[None])
+        lg = self.decode_logits(np.array([[SOT]]), memory)[0, -1]
+        return torch.softmax(lg[list(lang_ids)], dim=-1).numpy()

@@ -1,0 +1,173 @@
+"""-m gpu: model-level parity of the HIP path (through the C-ABI / the ctranslate2-compatible shim)
+against the CPU oracle on the same seeded synthetic weights (no checkpoint exists offline).
+
+Tolerances (written here as the test bar):
+  * encoder output rel-L2 <= 2e-3 (f16 MFMA path vs fp32 oracle)
+  * teacher-forced logits: max abs error <= 5e-2 and rel-L2 <= 5e-3
+  * greedy / beam token ids identical wherever the oracle's per-step top1-top2 margin exceeds MARGIN;
+    otherwise the returned hypothesis score must agree within 1e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MARGIN = 0.02
+PROMPT = [50258, 50259, 50359, 50363]
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def mels(golden_dir):
+    return np.stack([np.load(os.path.join(golden_dir, f"logmel_{c}.npz"))["mel"] for c in ("3sec", "10sec")]).astype(np.float32)
+
+
+def _make(size, **kw):
+    from oracle.whisper_ref import WhisperRef
+    from wis_hip import ctranslate2 as ct2, weights as W
+    w = W.synthetic_weights(size, seed=1234, std=0.02, emb_std=0.06, ln_jitter=0.1)
+    a = W.arch(size)
+    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=4, max_beam=5, **kw)
+    ref = WhisperRef(w, a["d_model"], a["n_layers"], a["n_heads"])
+    return model, ref, w, a
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return _make("tiny")
+
+
+@pytest.fixture(scope="module")
+def base():
+    return _make("base")
+
+
+def _handle(model):
+    return model._replicas[0].handle
+
+
+@pytest.mark.parametrize("which", ["tiny", "base"])
+def test_encoder_parity(which, request, mels, lib):
+    import ctypes as C
+    from wis_hip import _lib
+    model, ref, w, a = request.getfixturevalue(which)
+    B = 2
+    out = np.zeros((B, 1500, a["d_model"]), np.float32)
+    _lib.check(lib.wis_debug_encode(_handle(model), _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, B, out.ctypes.data_as(C.POINTER(C.c_float))))
+    exp = ref.encode(mels).numpy()
+    e = _relerr(out, exp)
+    print(f"encoder {which}: rel-L2 {e:.3e}, max abs {np.abs(out - exp).max():.3e}")
+    assert e <= 2e-3
+
+
+@pytest.mark.parametrize("which", ["tiny", "base"])
+def test_teacher_forced_logits(which, request, mels, lib):
+    import ctypes as C
+    from wis_hip import _lib
+    model, ref, w, a = request.getfixturevalue(which)
+    B, T = 2, 7
+    rng = np.random.default_rng(3)
+    dec_in = np.concatenate([np.tile(np.array(PROMPT, np.int32), (B, 1)), rng.integers(0, 50000, size=(B, T - 4)).astype(np.int32)], axis=1)
+    dec_in = np.ascontiguousarray(dec_in)
+    out = np.zeros((B, T, a["n_vocab"]), np.float32)
+    _lib.check(lib.wis_debug_logits(_handle(model), _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T,
+                                    out.ctypes.data_as(C.POINTER(C.c_float))))
+    mem = ref.encode(mels)
+    exp = ref.decode_logits(dec_in, mem).numpy()
+    e, mx = _relerr(out, exp), np.abs(out - exp).max()
+    print(f"logits {which}: rel-L2 {e:.3e}, max abs {mx:.3e}, logit std {exp.std():.3f}")
+    assert mx <= 5e-2 and e <= 5e-3
+
+
+def _check_generate(model, ref, mel, beam, fixed_new, max_new=0):
+    from wis_hip import ctranslate2 as ct2, weights as W
+    feats = ct2.StorageView.from_array(mel)
+    kw = dict(beam_size=beam, fixed_new_tokens=fixed_new)
+    res = model.generate(feats, [PROMPT] * mel.shape[0], **kw)
+    n_exact = 0
+    for b in range(mel.shape[0]):
+        ids, score, trace = ref.generate(mel[b], PROMPT, beam_size=beam, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN,
+                                         fixed_new=fixed_new, max_new_tokens=max_new, return_trace=True)
+        got, gscore = res[b].sequences_ids[0], res[b].scores[0]
+        margin = min(trace) if trace else 1.0
+        print(f"  utt {b} beam {beam}: oracle len {len(ids)} score {score:.5f} min-margin {margin:.4f} | hip len {len(got)} score {gscore:.5f}")
+        if margin > MARGIN:
+            assert got == ids, (got, ids)
+            n_exact += 1
+        assert abs(gscore - score) <= 1e-2
+        assert all(0 <= t < 51865 for t in got) and W.EOT not in got
+    return n_exact
+
+
+def test_generate_greedy_fixed(tiny, mels):
+    model, ref, w, a = tiny
+    assert _check_generate(model, ref, mels, 1, 8) >= 1
+
+
+def test_generate_beam5_fixed(tiny, mels):
+    model, ref, w, a = tiny
+    _check_generate(model, ref, mels, 5, 8)
+
+
+def test_generate_beam3_base(base, mels):
+    model, ref, w, a = base
+    _check_generate(model, ref, mels[:1], 3, 6)
+
+
+def test_generate_natural_termination(tiny, mels):
+    """No measurement convention: the run ends on the max-length step (random weights rarely emit EOT);
+    exercises is_last handling and the hypothesis bookkeeping."""
+    from wis_hip import ctranslate2 as ct2, weights as W
+    model, ref, w, a = tiny
+    feats = ct2.StorageView.from_array(mels[:1])
+    res = model.generate(feats, [PROMPT], beam_size=5, max_length=2 * 10)     # max_new = min(10, 20 - 4) = 10
+    ids, score, trace = ref.generate(mels[0], PROMPT, beam_size=5, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN,
+                                     max_new_tokens=10, return_trace=True)
+    got = res[0].sequences_ids[0]
+    print(f"natural: oracle {ids} ({score:.5f}) hip {got} ({res[0].scores[0]:.5f}) margin {min(trace):.4f}")
+    assert len(got) <= 10
+    if min(trace) > MARGIN:
+        assert got == ids
+    assert abs(res[0].scores[0] - score) <= 1e-2
+
+
+def test_batch_invariance_and_determinism(tiny, mels):
+    from wis_hip import ctranslate2 as ct2
+    model, ref, w, a = tiny
+    m3 = np.ascontiguousarray(np.stack([mels[0], mels[1], mels[0]]))
+    r1 = model.generate(ct2.StorageView.from_array(m3), [PROMPT] * 3, beam_size=5, fixed_new_tokens=6)
+    r2 = model.generate(ct2.StorageView.from_array(m3), [PROMPT] * 3, beam_size=5, fixed_new_tokens=6)
+    single = model.generate(ct2.StorageView.from_array(mels[:1]), [PROMPT], beam_size=5, fixed_new_tokens=6)
+    assert [r.sequences_ids for r in r1] == [r.sequences_ids for r in r2]          # bit-deterministic replay
+    assert r1[0].sequences_ids == r1[2].sequences_ids == single[0].sequences_ids    # batch composition does not change an utterance
+
+
+def test_detect_language(tiny, mels):
+    from wis_hip import ctranslate2 as ct2, weights as W
+    model, ref, w, a = tiny
+    out = model.detect_language(ct2.StorageView.from_array(mels[:1]))
+    exp = ref.detect_language(mels[0], W.LANG_IDS)
+    probs = {k: v for k, v in out[0]}
+    from wis_hip.languages import LANGUAGE_CODES
+    got = np.array([probs[f"<|{c}|>"] for c in LANGUAGE_CODES])
+    print(f"detect_language: max abs prob err {np.abs(got - exp).max():.3e}, top {out[0][0]}")
+    assert abs(sum(probs.values()) - 1.0) < 1e-3
+    assert np.abs(got - exp).max() < 2e-3
+    assert out[0][0][1] == max(probs.values())
+
+
+def test_pcm_input_matches_mel_input(tiny, golden_dir, lib):
+    """WIS_IN_PCM_HOST (log-mel fused on device) must give the same tokens as the mel boundary."""
+    from wis_hip import _lib, audio, ctranslate2 as ct2
+    model, ref, w, a = tiny
+    pcm, _ = audio.load_audio(os.path.join(golden_dir, "clips", "3sec.flac"))
+    x = np.ascontiguousarray(audio.pad_or_trim(pcm)[None])
+    mel = audio.log_mel_spectrogram(x[0]).numpy()[None]
+    r_mel = model.generate(ct2.StorageView.from_array(np.ascontiguousarray(mel)), [PROMPT], beam_size=5, fixed_new_tokens=6)
+    r_pcm = model._generate_chunk(model._replicas[0], x, [PROMPT], 4, 5, 224, 1.0, 1.0, True, True, 6, _lib.WIS_IN_PCM_HOST)
+    assert r_mel[0].sequences_ids == r_pcm[0].sequences_ids

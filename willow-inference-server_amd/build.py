@@ -1,0 +1,76 @@
+"""Build libwis_hip.so (gfx950) in-tree: hipcc for the HIP sources, gcc for the plain-C audio IO.
+
+    python willow-inference-server_amd/build.py [--force]
+
+The .so lands in willow-inference-server_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libwis_hip.so")
+
+HIP_SOURCES = ["logmel.hip", "enc_kernels.hip", "dec_kernels.hip", "model.hip"]
+C_SOURCES = ["audio_io.c"]
+HEADERS = ["common.hpp", "kernels.hpp", os.path.join(ROOT, "include", "wis_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off"]
+C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIP_FLAGS + C_FLAGS).encode())
+    return h.hexdigest()
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + os.path.basename(cmd[-1]))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in HIP_SOURCES + C_SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, src + ".o")
+        stamp = obj + ".sha"
+        dig = _digest([path] + hdrs)
+        if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dig:
+            if verbose:
+                print("[build] compiling", src, flush=True)
+            if src.endswith(".c"):
+                _run(["gcc"] + C_FLAGS + ["-c", path, "-o", obj])
+            else:
+                _run([HIPCC] + HIP_FLAGS + ["-c", path, "-o", obj])
+            with open(stamp, "w") as f:
+                f.write(dig)
+        objs.append(obj)
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        if verbose:
+            print("[build] linking", os.path.relpath(LIB, ROOT), flush=True)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,389 @@
+// enc_kernels.hip — Whisper encoder kernels for gfx950.
+//
+// The reference runs this inside ctranslate2.models.Whisper.generate (call site reference
+// main.py:687-693; forward math SURVEY §3.4 / Appendix B): conv1+GELU, conv2(stride 2)+GELU
+// +sinusoid positions, L x pre-LN {fused QKV, non-causal MHA over T=1500, out-proj, GELU-FFN},
+// final LN, then per decoder layer the cross-attention K/V projection of the encoder memory.
+//
+// MI355X mapping:
+//  * one MFMA GEMM template (v_mfma_f32_32x32x16_f16, fp32 accumulate, 128x128x32 tiles,
+//    64-wide waves in a 2x2 grid, LDS double-buffered with register prefetch, 80-byte row
+//    pitch = conflict-free ds_read_b128 fragment reads) serves conv1/conv2 (implicit im2col:
+//    the time-major, zero-padded activation makes a k=3 window ONE contiguous 3C-long row, so
+//    a conv is a GEMM whose A rows overlap: row pitch C for stride 1, 2C for stride 2), QKV,
+//    out-proj, FFN and the cross-K/V projection.  The weight tile is the MFMA A operand and the
+//    activation tile the B operand, so each lane ends up with 4 CONSECUTIVE output features of
+//    one row: bias / GELU / residual / position add / layout scatter are fused in the epilogue.
+//  * the residual stream is fp32 in HBM (LayerNorm reads fp32, writes fp16 for the next GEMM).
+//  * attention is flash-style per (128 queries, head): S^T = K.Q^T so a lane owns ONE query
+//    (softmax max/sum are in-lane + one half-swap), P feeds the PV MFMA straight from the
+//    accumulator registers (the key order inside a 16-key MFMA step is permuted identically for
+//    P and V^T), V arrives pre-transposed ([dh][T]) from the QKV epilogue.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace wis {
+
+// =======================================================================================
+// LayerNorm: fp32 [M][d] -> f16 [M][d]; one 64-lane wave per row, two-pass in registers.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, f16* __restrict__ y, int M, int d) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int n4 = d >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * d);
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) { v[i] = x4[idx]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  f16x4* y4 = reinterpret_cast<f16x4*>(y + (size_t)row * d);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      const float4 g = g4[idx], b = b4[idx];
+      f16x4 o;
+      o[0] = (f16)((v[i].x - mean) * rstd * g.x + b.x);
+      o[1] = (f16)((v[i].y - mean) * rstd * g.y + b.y);
+      o[2] = (f16)((v[i].z - mean) * rstd * g.z + b.z);
+      o[3] = (f16)((v[i].w - mean) * rstd * g.w + b.w);
+      y4[idx] = o;
+    }
+  }
+}
+
+int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, f16* y, int M, int d) {
+  if (d % 4 || d > 2048) { set_error("layernorm: d=%d unsupported", d); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, y, M, d);
+  return WIS_OK;
+}
+
+// =======================================================================================
+// GEMM  C[m][n] = epi( sum_k A(m)[k] * W[n][k] ),  A rows addressed as
+//   A + (m / a_rpb) * a_bs + (m % a_rpb) * a_rs     (implicit im2col for the convs).
+constexpr int BM = 128, BN = 128, BK = 32, LSTR = 40;  // LDS row pitch 40 f16 = 80 B
+
+template <class Epi>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
+  __shared__ __attribute__((aligned(16))) f16 sA[2][BM * LSTR];
+  __shared__ __attribute__((aligned(16))) f16 sW[2][BN * LSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // loader mapping: thread moves two 16-byte chunks of each tile: chunk c -> row c>>2, k-offset (c&3)*8
+  const int lrow0 = tid >> 2, lrow1 = (tid + 256) >> 2, lkc = (tid & 3) * 8;
+  int lm0 = m0 + lrow0; if (lm0 > p.M - 1) lm0 = p.M - 1;
+  int lm1 = m0 + lrow1; if (lm1 > p.M - 1) lm1 = p.M - 1;
+  const f16* ga0 = p.A + (int64_t)(lm0 / p.a_rpb) * p.a_bs + (int64_t)(lm0 % p.a_rpb) * p.a_rs + lkc;
+  const f16* ga1 = p.A + (int64_t)(lm1 / p.a_rpb) * p.a_bs + (int64_t)(lm1 % p.a_rpb) * p.a_rs + lkc;
+  const f16* gw0 = p.W + (int64_t)(n0 + lrow0) * p.K + lkc;
+  const f16* gw1 = p.W + (int64_t)(n0 + lrow1) * p.K + lkc;
+  const int soff0 = lrow0 * LSTR + lkc, soff1 = lrow1 * LSTR + lkc;
+  uint4 ra0, ra1, rw0, rw1;
+#define WIS_GLOAD(kt)                                                   \
+  ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK);               \
+  ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK);               \
+  rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK);               \
+  rw1 = *reinterpret_cast<const uint4*>(gw1 + (kt) * BK);
+#define WIS_SSTORE(buf)                                                 \
+  *reinterpret_cast<uint4*>(&sA[buf][soff0]) = ra0;                     \
+  *reinterpret_cast<uint4*>(&sA[buf][soff1]) = ra1;                     \
+  *reinterpret_cast<uint4*>(&sW[buf][soff0]) = rw0;                     \
+  *reinterpret_cast<uint4*>(&sW[buf][soff1]) = rw1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = p.K / BK;
+  WIS_GLOAD(0) WIS_SSTORE(0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { WIS_GLOAD(kt + 1) }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 wf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wf[i] = *reinterpret_cast<const f16x8*>(&sW[cur][(wn * 64 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
+        af[i] = *reinterpret_cast<const f16x8*>(&sA[cur][(wm * 64 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (kt + 1 < nk) { WIS_SSTORE(cur ^ 1) }
+    __syncthreads();
+  }
+#undef WIS_GLOAD
+#undef WIS_SSTORE
+  // D[i = n][j = m]: lane holds m = l31, n = (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + l31;
+      if (m < p.M) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * r4 + 4 * hi;
+          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
+          epi(m, n, v);
+        }
+      }
+    }
+}
+
+template <class Epi>
+static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
+  if (p.N % BN || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%32)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(gemm_f16_kernel<Epi>, dim3(p.N / BN, cdiv(p.M, BM)), dim3(256), 0, st, p, epi);
+  return WIS_OK;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return f32x4{t.x, t.y, t.z, t.w}; }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4h(f16* p, f32x4 v) { f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; *reinterpret_cast<f16x4*>(p) = o; }
+__device__ __forceinline__ f32x4 gelu4(f32x4 v) { return f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])}; }
+
+// generic runtime-flag epilogue (wis_op_gemm, FFN, out-proj)
+struct EpiGeneric {
+  const float* bias; const float* resid; void* C; int N; int flags;  // 1 gelu, 2 resid, 4 out f32
+  __device__ void operator()(int m, int n, f32x4 v) const {
+    if (bias) v += ld4(bias + n);
+    if (flags & 1) v = gelu4(v);
+    const size_t o = (size_t)m * N + n;
+    if (flags & 2) v += ld4(resid + o);
+    if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
+  }
+};
+// conv1: GELU(acc + b) -> f16 time-major padded image [B][T+2][N], row t+1
+struct EpiConv1 {
+  const float* bias; f16* C; int N; int T;
+  __device__ void operator()(int m, int n, f32x4 v) const {
+    v = gelu4(v + ld4(bias + n));
+    const int b = m / T, t = m - b * T;
+    st4h(C + ((size_t)b * (T + 2) + t + 1) * N + n, v);
+  }
+};
+// conv2: GELU(acc + b) + pos[t] -> fp32 residual stream [B*T][N]
+struct EpiConv2 {
+  const float* bias; const float* pos; float* X; int N; int T;
+  __device__ void operator()(int m, int n, f32x4 v) const {
+    v = gelu4(v + ld4(bias + n));
+    const int t = m % T;
+    v += ld4(pos + (size_t)t * N + n);
+    st4(X + (size_t)m * N + n, v);
+  }
+};
+// fused QKV: [Q*s | K] -> f16 [M][2d]; V -> V^T f16 [B][H][64][Tpad]
+struct EpiQKV {
+  const float* bias; f16* qk; f16* vt; int d; int T; int Tpad; int H;
+  __device__ void operator()(int m, int n, f32x4 v) const {
+    v += ld4(bias + n);
+    if (n < 2 * d) { st4h(qk + (size_t)m * 2 * d + n, v); return; }
+    const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
+    f16* o = vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
+  }
+};
+// cross-attention K/V projection of the encoder memory for ONE decoder layer:
+//   K -> Kx f16 [B][H][8][T][8]  (16-byte dh-groups contiguous along T: coalesced lane-per-key reads)
+//   V -> Vx f16 [B][H][T][64]
+struct EpiCrossKV {
+  const float* bias; f16* kx; f16* vx; int d; int T; int H;
+  __device__ void operator()(int m, int n, f32x4 v) const {
+    v += ld4(bias + n);
+    const int b = m / T, t = m - b * T;
+    if (n < d) {
+      const int h = n >> 6, dh = n & 63, g = dh >> 3, j = dh & 7;
+      st4h(kx + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8 + j), v);
+    } else {
+      const int nn = n - d, h = nn >> 6, dh = nn & 63;
+      st4h(vx + (((size_t)(b * H + h) * T + t) * 64 + dh), v);
+    }
+  }
+};
+
+int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const float* resid, void* C, int flags) {
+  EpiGeneric e{bias, resid, C, p.N, flags};
+  return launch_gemm_t(st, p, e);
+}
+int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C, int T) {
+  EpiConv1 e{bias, C, p.N, T};
+  return launch_gemm_t(st, p, e);
+}
+int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T) {
+  EpiConv2 e{bias, pos, X, p.N, T};
+  return launch_gemm_t(st, p, e);
+}
+int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H) {
+  EpiQKV e{bias, qk, vt, d, T, Tpad, H};
+  return launch_gemm_t(st, p, e);
+}
+int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vx, int d, int T, int H) {
+  EpiCrossKV e{bias, kx, vx, d, T, H};
+  return launch_gemm_t(st, p, e);
+}
+
+// =======================================================================================
+// Encoder self-attention (non-causal, dh = 64).  grid (ceil(T/128), H, B), block 256.
+constexpr int AKT = 64, ASTR = 72;  // 64-key tiles, LDS row pitch 72 f16 = 144 B
+
+__global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ qk, const f16* __restrict__ vt,
+                                                       f16* __restrict__ out, int T, int Tpad, int H, int d) {
+  __shared__ __attribute__((aligned(16))) f16 sK[2][AKT * ASTR];
+  __shared__ __attribute__((aligned(16))) f16 sV[2][64 * ASTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  const int q_c = q_row < T ? q_row : T - 1;
+  const int ld = 2 * d;
+
+  f16x8 qf[4];
+  {
+    const f16* qp = qk + (size_t)(b * T + q_c) * ld + h * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const f16x8*>(qp + kk * 16 + hi * 8);
+  }
+  // tile loaders: 64 rows x 8 chunks of 16 B for K and for V^T
+  const f16* kbase = qk + (size_t)b * T * ld + d + h * 64;
+  const f16* vbase = vt + (size_t)(b * H + h) * 64 * Tpad;
+  const int lrow0 = tid >> 3, lrow1 = (tid + 256) >> 3, lch = (tid & 7) * 8;
+  const f16* vp0 = vbase + (size_t)lrow0 * Tpad + lch;
+  const f16* vp1 = vbase + (size_t)lrow1 * Tpad + lch;
+  const int so0 = lrow0 * ASTR + lch, so1 = lrow1 * ASTR + lch;
+  uint4 rk0, rk1, rv0, rv1;
+#define WIS_GLOAD(kt)                                                                      \
+  {                                                                                        \
+    int key0 = (kt) * AKT + lrow0; if (key0 > T - 1) key0 = T - 1;                          \
+    int key1 = (kt) * AKT + lrow1; if (key1 > T - 1) key1 = T - 1;                          \
+    rk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)key0 * ld + lch);                \
+    rk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)key1 * ld + lch);                \
+    rv0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * AKT);                               \
+    rv1 = *reinterpret_cast<const uint4*>(vp1 + (kt) * AKT);                               \
+  }
+#define WIS_SSTORE(buf)                                                                    \
+  *reinterpret_cast<uint4*>(&sK[buf][so0]) = rk0;                                          \
+  *reinterpret_cast<uint4*>(&sK[buf][so1]) = rk1;                                          \
+  *reinterpret_cast<uint4*>(&sV[buf][so0]) = rv0;                                          \
+  *reinterpret_cast<uint4*>(&sV[buf][so1]) = rv1;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = cdiv(T, AKT);
+  WIS_GLOAD(0) WIS_SSTORE(0)
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) WIS_GLOAD(kt + 1)
+    // S^T[key][q] = K . Q^T  (A = K rows, B = Q rows)
+    f32x16 st[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(&sK[cur][(t2 * 32 + l31) * ASTR + kk * 16 + hi * 8]);
+        st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[t2], 0, 0, 0);
+      }
+    }
+    const int key_base = kt * AKT + 4 * hi;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_base + t2 * 32 + (r & 3) + 8 * (r >> 2);
+        if (key >= T) st[t2][r] = -INFINITY;
+        mx = fmaxf(mx, st[t2][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float pv = __expf(st[t2][r] - m_new); st[t2][r] = pv; rs += pv; }
+    l_run = l_run * alpha + rs; m_run = m_new;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
+    // P fragments straight from the accumulators: k-step s of 16 keys <-> S-tile s>>1, regs 8(s&1)..+7;
+    // slot j of half `hi` is key 16s + 8(j>>2) + 4hi + (j&3)  (same permutation used for V^T below)
+    f16x8 pf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[s][j] = (f16)st[s >> 1][8 * (s & 1) + j];
+    // O^T[dh][q] += V^T . P^T   (A = V^T rows (dh), B = P rows (q))
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f16* vr = &sV[cur][(dt * 32 + l31) * ASTR + 16 * s + 4 * hi];
+        const f16x4 v0 = *reinterpret_cast<const f16x4*>(vr);
+        const f16x4 v1 = *reinterpret_cast<const f16x4*>(vr + 8);
+        const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[dt], 0, 0, 0);
+      }
+    if (kt + 1 < ntiles) { WIS_SSTORE(cur ^ 1) }
+    __syncthreads();
+  }
+#undef WIS_GLOAD
+#undef WIS_SSTORE
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_row < T) {
+    f16* op = out + (size_t)(b * T + q_row) * d + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dh = dt * 32 + 8 * r4 + 4 * hi;
+        f32x4 v = {o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv, o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv};
+        st4h(op + dh, v);
+      }
+  }
+}
+
+int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H) {
+  if (Tpad < cdiv(T, AKT) * AKT || Tpad % 8) { set_error("enc_attention: Tpad=%d too small for T=%d", Tpad, T); return WIS_E_ARG; }
+  hipLaunchKernelGGL(enc_attn_kernel, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64);
+  return WIS_OK;
+}
+
+}  // namespace wis

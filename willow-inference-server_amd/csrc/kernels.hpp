@@ -1,0 +1,87 @@
+// kernels.hpp — launch wrappers shared between the kernel files and the model driver.
+#pragma once
+#include "common.hpp"
+
+namespace wis {
+
+// ---- encoder ---------------------------------------------------------------------------
+struct GemmP {
+  const f16* A; int64_t a_bs; int a_rs; int a_rpb;   // A row m -> A + (m / a_rpb)*a_bs + (m % a_rpb)*a_rs
+  const f16* W;                                      // [N][K] row-major
+  int M, N, K;
+};
+static inline GemmP gemm_plain(const f16* A, int lda, const f16* W, int M, int N, int K) {
+  GemmP p; p.A = A; p.a_bs = 0; p.a_rs = lda; p.a_rpb = 0x7fffffff; p.W = W; p.M = M; p.N = N; p.K = K; return p;
+}
+int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, f16* y, int M, int d);
+int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const float* resid, void* C, int flags);
+int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C, int T);
+int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
+int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);
+int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vx, int d, int T, int H);
+int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H);
+
+// ---- decoder ---------------------------------------------------------------------------
+constexpr int MAX_ROWS = 48;      // decoder rows per step: B*beam (decode) or B*(P-1) (prefill)
+constexpr int MAX_R = 8;          // rows per utterance (beam or prompt prefix length)
+constexpr int MAX_CAND = 2 * MAX_R;
+
+// per-row decode metadata (device arrays, length MAX_ROWS)
+struct RowMeta {
+  int* tok;     // input token of the row
+  int* pos;     // text position of the row (KV-cache index it writes)
+  int* slot;    // physical KV slot the row writes
+  int* lslot;   // logical slot whose ancestry table the row reads
+};
+
+// skinny GEMM (decoder): y = epi(LN?(x) . Wp^T + b), Wp packed in MFMA 16x16x32 A-fragment order
+enum { GV_GELU = 1, GV_RESID = 2, GV_OUT_F32 = 4, GV_LN = 8, GV_QKV = 16 };
+struct GemvP {
+  const void* x;                 // f32 [M][K] when GV_LN else f16 [M][K]
+  const float* gamma; const float* beta;
+  const f16* Wp; const float* bias;
+  void* y;                       // [M][N] f32 (GV_OUT_F32 / GV_RESID in place) or f16
+  int M, N, K, flags;
+  // GV_QKV epilogue: n < d -> q (f32 [M][d]); d <= n < 2d -> K cache; n >= 2d -> V cache
+  float* q; f16* kc; f16* vc; const int* slot; const int* pos; int d; int ctx;   // cache [slots][ctx][d]
+};
+int launch_gemv(hipStream_t st, const GemvP& p);
+// pack W [N][K] f16 row-major -> Wp [Npad/16][K/32][64][8]; rows >= N are zero; scale rows
+// [0, n_scale) by `scale` (folds the 1/sqrt(dh) query scaling into the projection)
+int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale);
+
+int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d);
+int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* lslot,
+                         const int* pos, f16* out, int M, int H, int d, int ctx);
+// cross attention of R rows per utterance over the utterance's T encoder keys.
+//   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vx f16 [B][H][T][64] -> out f16 [B*R][d]
+int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vx, f16* out, float* part, unsigned* counters,
+                          int B, int R, int H, int d, int T, int chunks);
+
+// sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
+struct SampleCfg {
+  int n_vocab, n_vocab_pad, eot, beam, n_cand, max_new, fixed_new, suppress_blank, greedy;
+  float length_penalty; int max_hyp; int allow_early_exit; int max_candidates;
+};
+constexpr int STAT_CHUNKS = 16;
+int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
+                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg);
+struct BeamState {
+  int* step_u;      // [B] generated-token count so far
+  int* done;        // [B]
+  int* n_hyp;       // [B]
+  float* cum;       // [B*beam] cumulative log-prob of live beams
+  int* alive;       // [B*beam][max_new] token history of live beams
+  int* anc;         // [B*beam][ctx] ancestry: physical slot holding position p of this logical slot
+  float* hyp_score; // [B][max_hyp] raw cumulative score
+  int* hyp_len;     // [B][max_hyp]
+  int* hyp_tok;     // [B][max_hyp][max_new]
+  int* all_done;    // [1] (also mirrored to pinned host memory by the driver)
+  int* out_ids; int* out_len; float* out_score;   // final result [B][max_new], [B], [B]
+};
+int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
+                     const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg);
+// language detection: softmax over lang_ids of the row's logits
+int launch_lang_probs(hipStream_t st, const float* logits, int ld, const int* lang_ids, int n_lang, float* probs, int B);
+
+}  // namespace wis

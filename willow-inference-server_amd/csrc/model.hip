@@ -1,0 +1,818 @@
+// model.hip — model lifecycle, weight re-packing, the generate / detect_language drivers and
+// the C-ABI entry points of libwis_hip.so (include/wis_hip.h).
+//
+// Replaces the ctranslate2.models.Whisper object the reference builds at main.py:341-444 and
+// drives at main.py:535-537, 638-639, 685-693.  One handle = one replica on one GPU: weights are
+// converted ONCE into the layouts the kernels stream (row-major f16 [N][K] for the encoder MFMA
+// GEMM, MFMA-fragment-packed for the decoder's skinny GEMMs), all activations / KV caches live in
+// HBM for the handle's lifetime, and a decode step (~260 kernels) is captured once into a HIP
+// graph and replayed: every step-dependent value (positions, tokens, beam ancestry, scores)
+// lives in device memory, so the host only launches graphs and polls a done counter.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+using namespace wis;
+
+namespace wis {
+void build_mel_filters(float* out);
+
+// ---- small utility kernels -------------------------------------------------------------
+// generic convert: src (f16|f32) [rows][cols] -> dst (f16|f32) [rows][dst_ld]; rows < n_scale scaled
+__global__ void convert_kernel(const void* __restrict__ src, int src_f16, void* __restrict__ dst, int dst_f16,
+                               int64_t rows, int64_t cols, int64_t dst_ld, int64_t n_scale, float scale) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i - r * cols;
+    float v = src_f16 ? (float)reinterpret_cast<const f16*>(src)[i] : reinterpret_cast<const float*>(src)[i];
+    if (r < n_scale) v *= scale;
+    if (dst_f16) reinterpret_cast<f16*>(dst)[r * dst_ld + c] = (f16)v; else reinterpret_cast<float*>(dst)[r * dst_ld + c] = v;
+  }
+}
+// conv weight [out][in][3] -> f16 [out][3*cpad], element (o, k*cpad + c) = W[o][c][k]; padding zero
+__global__ void conv_pack_kernel(const void* __restrict__ src, int src_f16, f16* __restrict__ dst, int out, int in, int cpad) {
+  const int64_t total = (int64_t)out * 3 * cpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(i / (3 * cpad)), rem = (int)(i - (int64_t)o * 3 * cpad), k = rem / cpad, c = rem - k * cpad;
+    float v = 0.f;
+    if (c < in) {
+      const int64_t s = ((int64_t)o * in + c) * 3 + k;
+      v = src_f16 ? (float)reinterpret_cast<const f16*>(src)[s] : reinterpret_cast<const float*>(src)[s];
+    }
+    dst[i] = (f16)v;
+  }
+}
+// mel f32 [B][80][3000] -> conv1 input image f16 [B][3002][96]
+__global__ void mel_to_image_kernel(const float* __restrict__ mel, f16* __restrict__ img) {
+  __shared__ float s_t[80][65];
+  const int tid = threadIdx.x, w = blockIdx.y, f0 = blockIdx.x * 64;
+  for (int o = tid; o < 80 * 64; o += 256) {
+    const int m = o >> 6, f = o & 63;
+    if (f0 + f < 3000) s_t[m][f] = mel[((size_t)w * 80 + m) * 3000 + f0 + f];
+  }
+  __syncthreads();
+  for (int o = tid; o < 64 * 96; o += 256) {
+    const int f = o / 96, c = o - f * 96;
+    if (f0 + f < 3000) img[((size_t)w * 3002 + f0 + f + 1) * 96 + c] = (c < 80) ? (f16)s_t[c][f] : (f16)0.f;
+  }
+}
+__global__ void f16_to_f32_kernel(const f16* __restrict__ s, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
+}
+}  // namespace wis
+
+// ---------------------------------------------------------------------------------------
+struct EncLayerW {
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  f16 *w_qkv, *w_out, *w_f1, *w_f2;
+  float *b_qkv, *b_out, *b_f1, *b_f2;
+};
+struct DecLayerW {
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+  f16 *p_qkv, *p_out, *p_cq, *p_cout, *p_f1, *p_f2;   // MFMA-fragment packed
+  f16 *w_ckv;                                        // row-major [2d][d] (encoder-side GEMM)
+  float *b_qkv, *b_out, *b_cq, *b_ckv, *b_cout, *b_f1, *b_f2;
+};
+
+struct GraphKey {
+  int B, beam, P, max_new, fixed_new, suppress_blank, suppress_default, early_exit; float lp, patience;
+  bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+struct wis_model {
+  wis_config_t cfg;
+  int device;
+  DeviceCtx* ctx;
+  hipStream_t st;
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  // weights
+  f16 *w_conv1, *w_conv2; float *b_conv1, *b_conv2, *enc_pos, *enc_ln_g, *enc_ln_b;
+  std::vector<EncLayerW> enc;
+  std::vector<DecLayerW> dec;
+  f16 *emb, *dec_pos, *p_proj; float *dec_ln_g, *dec_ln_b;
+  float *bias_all, *bias_begin; int* d_lang_ids;
+  int n_vocab_pad;
+  // activations
+  int Tpad;
+  f16 *img, *c1, *xn, *qk, *vt, *ao, *hbuf, *mem;
+  float* x;
+  std::vector<f16*> kx, vx;             // per decoder layer cross K / V
+  std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d]
+  // decode state
+  float *dx, *dq, *logits, *part; f16 *dao, *dh; unsigned* counters;
+  RowMeta rm; BeamState bs;
+  float *st_max, *st_sum, *st_val; int* st_idx;
+  float* d_in; int64_t* d_nsamp; float* d_probs;
+  int* h_pin;      // pinned host scratch
+  hipEvent_t ev[8];
+  wis_timing_t timing;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  bool use_graph;
+};
+
+namespace {
+
+template <class T>
+int dalloc(wis_model* m, T** p, size_t n_elems) {
+  void* q = nullptr;
+  size_t b = n_elems * sizeof(T); if (b == 0) b = 16;
+  hipError_t e = hipMalloc(&q, b);
+  if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", b, hipGetErrorString(e)); return WIS_E_NOMEM; }
+  m->allocs.push_back(q); m->bytes += b; *p = reinterpret_cast<T*>(q);
+  return WIS_OK;
+}
+inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+struct TensorSrc { const void* p; int f16; int64_t rows, cols; };
+
+struct Loader {
+  const wis_tensor_t* t; int n; const char* arena;   // arena: DEVICE base pointer
+  size_t arena_bytes;
+  const wis_tensor_t* find(const std::string& name) const {
+    for (int i = 0; i < n; ++i) if (name == t[i].name) return &t[i];
+    return nullptr;
+  }
+  int get(const std::string& name, int64_t rows, int64_t cols, TensorSrc* out) const {
+    const wis_tensor_t* x = find(name);
+    if (!x) { set_error("weight '%s' missing from the index", name.c_str()); return WIS_E_FORMAT; }
+    int64_t ne = 1; for (int i = 0; i < x->rank; ++i) ne *= x->shape[i];
+    if (ne != rows * cols) { set_error("weight '%s': %lld elements, expected %lld", name.c_str(), (long long)ne, (long long)(rows * cols)); return WIS_E_FORMAT; }
+    const size_t es = x->dtype == WIS_DT_F16 ? 2 : 4;
+    if (x->dtype != WIS_DT_F16 && x->dtype != WIS_DT_F32) { set_error("weight '%s': dtype %d unsupported", name.c_str(), x->dtype); return WIS_E_FORMAT; }
+    if (x->offset + (size_t)ne * es > arena_bytes) { set_error("weight '%s' exceeds the arena", name.c_str()); return WIS_E_FORMAT; }
+    out->p = arena + x->offset; out->f16 = x->dtype == WIS_DT_F16; out->rows = rows; out->cols = cols;
+    return WIS_OK;
+  }
+};
+
+int to_f32(wis_model* m, const Loader& L, const std::string& name, int64_t n, float** out, int64_t n_scale = 0, float scale = 1.f) {
+  TensorSrc s; WIS_RET(L.get(name, n, 1, &s));
+  WIS_RET(dalloc(m, out, (size_t)n));
+  hipLaunchKernelGGL(convert_kernel, dim3(blocks_for(n)), dim3(256), 0, m->st, s.p, s.f16, *out, 0, n, (int64_t)1, (int64_t)1, n_scale, scale);
+  return WIS_OK;
+}
+int to_f16_mat(wis_model* m, const Loader& L, const std::string& name, int64_t rows, int64_t cols, f16** out, int64_t n_scale = 0, float scale = 1.f) {
+  TensorSrc s; WIS_RET(L.get(name, rows, cols, &s));
+  WIS_RET(dalloc(m, out, (size_t)rows * cols));
+  hipLaunchKernelGGL(convert_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, m->st, s.p, s.f16, *out, 1, rows, cols, cols, n_scale, scale);
+  return WIS_OK;
+}
+// row-major source -> MFMA-fragment packed (through a temporary f16 image)
+int to_packed(wis_model* m, const Loader& L, const std::string& name, int N, int K, f16** out, f16* tmp, int n_scale = 0, float scale = 1.f, int* npad_out = nullptr) {
+  TensorSrc s; WIS_RET(L.get(name, N, K, &s));
+  const int Npad = cdiv(N, 16) * 16;
+  WIS_RET(dalloc(m, out, (size_t)Npad * K));
+  hipLaunchKernelGGL(convert_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, m->st, s.p, s.f16, tmp, 1, (int64_t)N, (int64_t)K, (int64_t)K, (int64_t)0, 1.f);
+  WIS_RET(launch_pack_gemv(m->st, tmp, *out, N, Npad, K, n_scale, scale));
+  if (npad_out) *npad_out = Npad;
+  return WIS_OK;
+}
+
+int load_weights(wis_model* m, const Loader& L) {
+  const wis_config_t& c = m->cfg;
+  const int d = c.d_model, V = c.n_vocab;
+  const float qs = 0.125f;   // 1/sqrt(64), folded into the query projections (exact: power of two)
+  f16* tmp = nullptr;        // staging for packed conversions: largest matrix = embeddings [V][d]
+  {
+    size_t big = (size_t)V * d; if ((size_t)4 * d * d > big) big = (size_t)4 * d * d;
+    WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), big * 2));
+  }
+  int rc = WIS_OK;
+  do {
+    // ---- encoder
+    {
+      TensorSrc s;
+      if ((rc = L.get("encoder/conv1/weight", d, (int64_t)c.n_mels * 3, &s))) break;
+      if ((rc = dalloc(m, &m->w_conv1, (size_t)d * 3 * 96))) break;
+      hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks_for((int64_t)d * 288)), dim3(256), 0, m->st, s.p, s.f16, m->w_conv1, d, c.n_mels, 96);
+      if ((rc = L.get("encoder/conv2/weight", d, (int64_t)d * 3, &s))) break;
+      if ((rc = dalloc(m, &m->w_conv2, (size_t)d * 3 * d))) break;
+      hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks_for((int64_t)d * 3 * d)), dim3(256), 0, m->st, s.p, s.f16, m->w_conv2, d, d, d);
+    }
+    if ((rc = to_f32(m, L, "encoder/conv1/bias", d, &m->b_conv1))) break;
+    if ((rc = to_f32(m, L, "encoder/conv2/bias", d, &m->b_conv2))) break;
+    if (L.find("encoder/position_encodings/encodings")) {
+      if ((rc = to_f32(m, L, "encoder/position_encodings/encodings", (int64_t)c.n_audio_ctx * d, &m->enc_pos))) break;
+    } else {
+      // Whisper sinusoids: inc = ln(10000)/(d/2-1); pos[t] = [sin(t inv) | cos(t inv)]
+      std::vector<float> pe((size_t)c.n_audio_ctx * d);
+      const int half = d / 2; const double inc = log(10000.0) / (half - 1);
+      for (int t = 0; t < c.n_audio_ctx; ++t)
+        for (int i = 0; i < half; ++i) {
+          const float inv = (float)exp(-inc * i);           // fp32 table like torch.exp(float32)
+          const float a = (float)t * inv;
+          pe[(size_t)t * d + i] = sinf(a); pe[(size_t)t * d + half + i] = cosf(a);
+        }
+      if ((rc = dalloc(m, &m->enc_pos, pe.size()))) break;
+      WIS_HIP_CHECK(hipMemcpyAsync(m->enc_pos, pe.data(), pe.size() * 4, hipMemcpyHostToDevice, m->st));
+      WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+    }
+    if ((rc = to_f32(m, L, "encoder/layer_norm/gamma", d, &m->enc_ln_g))) break;
+    if ((rc = to_f32(m, L, "encoder/layer_norm/beta", d, &m->enc_ln_b))) break;
+    m->enc.resize(c.n_enc_layers);
+    for (int l = 0; l < c.n_enc_layers && !rc; ++l) {
+      const std::string p = "encoder/layer_" + std::to_string(l) + "/";
+      EncLayerW& w = m->enc[l];
+      if ((rc = to_f32(m, L, p + "self_attention/layer_norm/gamma", d, &w.ln1_g))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/layer_norm/beta", d, &w.ln1_b))) break;
+      if ((rc = to_f16_mat(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.w_qkv, d, qs))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/linear_0/bias", 3 * d, &w.b_qkv, d, qs))) break;
+      if ((rc = to_f16_mat(m, L, p + "self_attention/linear_1/weight", d, d, &w.w_out))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/linear_1/bias", d, &w.b_out))) break;
+      if ((rc = to_f32(m, L, p + "ffn/layer_norm/gamma", d, &w.ln2_g))) break;
+      if ((rc = to_f32(m, L, p + "ffn/layer_norm/beta", d, &w.ln2_b))) break;
+      if ((rc = to_f16_mat(m, L, p + "ffn/linear_0/weight", 4 * d, d, &w.w_f1))) break;
+      if ((rc = to_f32(m, L, p + "ffn/linear_0/bias", 4 * d, &w.b_f1))) break;
+      if ((rc = to_f16_mat(m, L, p + "ffn/linear_1/weight", d, 4 * d, &w.w_f2))) break;
+      if ((rc = to_f32(m, L, p + "ffn/linear_1/bias", d, &w.b_f2))) break;
+    }
+    if (rc) break;
+    // ---- decoder
+    if ((rc = to_f16_mat(m, L, "decoder/embeddings/weight", V, d, &m->emb))) break;
+    if ((rc = to_packed(m, L, "decoder/embeddings/weight", V, d, &m->p_proj, tmp, 0, 1.f, &m->n_vocab_pad))) break;
+    if ((rc = to_f16_mat(m, L, "decoder/position_encodings/encodings", c.n_text_ctx, d, &m->dec_pos))) break;
+    if ((rc = to_f32(m, L, "decoder/layer_norm/gamma", d, &m->dec_ln_g))) break;
+    if ((rc = to_f32(m, L, "decoder/layer_norm/beta", d, &m->dec_ln_b))) break;
+    m->dec.resize(c.n_dec_layers);
+    for (int l = 0; l < c.n_dec_layers && !rc; ++l) {
+      const std::string p = "decoder/layer_" + std::to_string(l) + "/";
+      DecLayerW& w = m->dec[l];
+      if ((rc = to_f32(m, L, p + "self_attention/layer_norm/gamma", d, &w.ln1_g))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/layer_norm/beta", d, &w.ln1_b))) break;
+      if ((rc = to_packed(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.p_qkv, tmp, d, qs))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/linear_0/bias", 3 * d, &w.b_qkv, d, qs))) break;
+      if ((rc = to_packed(m, L, p + "self_attention/linear_1/weight", d, d, &w.p_out, tmp))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/linear_1/bias", d, &w.b_out))) break;
+      if ((rc = to_f32(m, L, p + "attention/layer_norm/gamma", d, &w.ln2_g))) break;
+      if ((rc = to_f32(m, L, p + "attention/layer_norm/beta", d, &w.ln2_b))) break;
+      if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs))) break;
+      if ((rc = to_f32(m, L, p + "attention/linear_0/bias", d, &w.b_cq, d, qs))) break;
+      if ((rc = to_f16_mat(m, L, p + "attention/linear_1/weight", 2 * d, d, &w.w_ckv))) break;
+      if ((rc = to_f32(m, L, p + "attention/linear_1/bias", 2 * d, &w.b_ckv))) break;
+      if ((rc = to_packed(m, L, p + "attention/linear_2/weight", d, d, &w.p_cout, tmp))) break;
+      if ((rc = to_f32(m, L, p + "attention/linear_2/bias", d, &w.b_cout))) break;
+      if ((rc = to_f32(m, L, p + "ffn/layer_norm/gamma", d, &w.ln3_g))) break;
+      if ((rc = to_f32(m, L, p + "ffn/layer_norm/beta", d, &w.ln3_b))) break;
+      if ((rc = to_packed(m, L, p + "ffn/linear_0/weight", 4 * d, d, &w.p_f1, tmp))) break;
+      if ((rc = to_f32(m, L, p + "ffn/linear_0/bias", 4 * d, &w.b_f1))) break;
+      if ((rc = to_packed(m, L, p + "ffn/linear_1/weight", d, 4 * d, &w.p_f2, tmp))) break;
+      if ((rc = to_f32(m, L, p + "ffn/linear_1/bias", d, &w.b_f2))) break;
+    }
+  } while (0);
+  hipError_t e = hipStreamSynchronize(m->st);
+  hipFree(tmp);
+  if (rc) return rc;
+  if (e != hipSuccess) { set_error("weight conversion failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+  return WIS_OK;
+}
+
+int alloc_buffers(wis_model* m) {
+  const wis_config_t& c = m->cfg;
+  const int d = c.d_model, H = c.n_heads, Bm = c.max_batch, T = c.n_audio_ctx, L = c.n_dec_layers;
+  const int slots = Bm * c.max_beam, ctx = c.n_text_ctx;
+  m->Tpad = cdiv(T, 64) * 64;
+  WIS_RET(dalloc(m, &m->img, (size_t)Bm * 3002 * 96));
+  WIS_RET(dalloc(m, &m->c1, (size_t)Bm * 3002 * d));
+  WIS_RET(dalloc(m, &m->x, (size_t)Bm * T * d));
+  WIS_RET(dalloc(m, &m->xn, (size_t)Bm * T * d));
+  WIS_RET(dalloc(m, &m->qk, (size_t)Bm * T * 2 * d));
+  WIS_RET(dalloc(m, &m->vt, (size_t)Bm * H * 64 * m->Tpad));
+  WIS_RET(dalloc(m, &m->ao, (size_t)Bm * T * d));
+  WIS_RET(dalloc(m, &m->hbuf, (size_t)Bm * T * 4 * d));
+  WIS_RET(dalloc(m, &m->mem, (size_t)Bm * T * d));
+  WIS_HIP_CHECK(hipMemsetAsync(m->img, 0, (size_t)Bm * 3002 * 96 * 2, m->st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->c1, 0, (size_t)Bm * 3002 * d * 2, m->st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->vt, 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
+  m->kx.resize(L); m->vx.resize(L); m->kc.resize(L); m->vc.resize(L);
+  for (int l = 0; l < L; ++l) {
+    WIS_RET(dalloc(m, &m->kx[l], (size_t)Bm * H * 8 * T * 8));
+    WIS_RET(dalloc(m, &m->vx[l], (size_t)Bm * H * T * 64));
+    WIS_RET(dalloc(m, &m->kc[l], (size_t)slots * ctx * d));
+    WIS_RET(dalloc(m, &m->vc[l], (size_t)slots * ctx * d));
+  }
+  WIS_RET(dalloc(m, &m->dx, (size_t)MAX_ROWS * d));
+  WIS_RET(dalloc(m, &m->dq, (size_t)MAX_ROWS * d));
+  WIS_RET(dalloc(m, &m->dao, (size_t)MAX_ROWS * d));
+  WIS_RET(dalloc(m, &m->dh, (size_t)MAX_ROWS * 4 * d));
+  WIS_RET(dalloc(m, &m->logits, (size_t)MAX_ROWS * m->n_vocab_pad));
+  WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * MAX_R * 66));
+  WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
+  WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bm * H * 4, m->st));
+  WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
+  WIS_RET(dalloc(m, &m->rm.slot, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.lslot, MAX_ROWS));
+  const int max_new = 256, max_hyp = 2 * MAX_R;
+  WIS_RET(dalloc(m, &m->bs.step_u, Bm)); WIS_RET(dalloc(m, &m->bs.done, Bm)); WIS_RET(dalloc(m, &m->bs.n_hyp, Bm));
+  WIS_RET(dalloc(m, &m->bs.cum, slots));
+  WIS_RET(dalloc(m, &m->bs.alive, (size_t)slots * max_new));
+  WIS_RET(dalloc(m, &m->bs.anc, (size_t)slots * ctx));
+  WIS_RET(dalloc(m, &m->bs.hyp_score, (size_t)Bm * max_hyp)); WIS_RET(dalloc(m, &m->bs.hyp_len, (size_t)Bm * max_hyp));
+  WIS_RET(dalloc(m, &m->bs.hyp_tok, (size_t)Bm * max_hyp * max_new));
+  WIS_RET(dalloc(m, &m->bs.all_done, 4));
+  WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
+  WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_CHUNKS)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_CHUNKS));
+  WIS_RET(dalloc(m, &m->st_val, (size_t)MAX_ROWS * STAT_CHUNKS * MAX_CAND)); WIS_RET(dalloc(m, &m->st_idx, (size_t)MAX_ROWS * STAT_CHUNKS * MAX_CAND));
+  WIS_RET(dalloc(m, &m->d_in, (size_t)Bm * WIS_N_SAMPLES));
+  WIS_RET(dalloc(m, &m->d_nsamp, Bm));
+  WIS_RET(dalloc(m, &m->d_probs, (size_t)Bm * (c.n_lang > 0 ? c.n_lang : 1)));
+  WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 65536, hipHostMallocDefault));
+  for (int i = 0; i < 8; ++i) WIS_HIP_CHECK(hipEventCreate(&m->ev[i]));
+  return WIS_OK;
+}
+
+// ---- input -> conv1 image --------------------------------------------------------------
+int stage_input(wis_model* m, const float* input, int kind, int B) {
+  hipStream_t st = m->st;
+  if (kind == WIS_IN_PCM_HOST || kind == WIS_IN_PCM_DEV) {
+    const float* dp = input;
+    if (kind == WIS_IN_PCM_HOST) {
+      WIS_HIP_CHECK(hipMemcpyAsync(m->d_in, input, (size_t)B * WIS_N_SAMPLES * 4, hipMemcpyHostToDevice, st));
+      dp = m->d_in;
+    }
+    int64_t* hn = reinterpret_cast<int64_t*>(m->h_pin);
+    for (int b = 0; b < B; ++b) hn[b] = WIS_N_SAMPLES;
+    WIS_HIP_CHECK(hipMemcpyAsync(m->d_nsamp, hn, (size_t)B * 8, hipMemcpyHostToDevice, st));
+    WIS_RET(logmel_device(m->ctx, st, dp, WIS_N_SAMPLES, m->d_nsamp, B, nullptr, m->img));
+  } else if (kind == WIS_IN_MEL_HOST || kind == WIS_IN_MEL_DEV) {
+    const float* dm = input;
+    if (kind == WIS_IN_MEL_HOST) {
+      WIS_HIP_CHECK(hipMemcpyAsync(m->d_in, input, (size_t)B * 80 * 3000 * 4, hipMemcpyHostToDevice, st));
+      dm = m->d_in;
+    }
+    hipLaunchKernelGGL(mel_to_image_kernel, dim3(cdiv(3000, 64), B), dim3(256), 0, st, dm, m->img);
+  } else { set_error("bad input_kind %d", kind); return WIS_E_ARG; }
+  return WIS_OK;
+}
+
+// ---- encoder + cross K/V ---------------------------------------------------------------
+int run_encoder(wis_model* m, int B) {
+  const wis_config_t& c = m->cfg; hipStream_t st = m->st;
+  const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, M = B * T;
+  {  // conv1: implicit im2col over the [3002][96] image, K = 288
+    GemmP p; p.A = m->img; p.a_bs = (int64_t)3002 * 96; p.a_rs = 96; p.a_rpb = 3000; p.W = m->w_conv1; p.M = B * 3000; p.N = d; p.K = 288;
+    WIS_RET(launch_gemm_conv1(st, p, m->b_conv1, m->c1, 3000));
+  }
+  {  // conv2 (stride 2) + GELU + positions -> fp32 residual stream
+    GemmP p; p.A = m->c1; p.a_bs = (int64_t)3002 * d; p.a_rs = 2 * d; p.a_rpb = T; p.W = m->w_conv2; p.M = M; p.N = d; p.K = 3 * d;
+    WIS_RET(launch_gemm_conv2(st, p, m->b_conv2, m->enc_pos, m->x, T));
+  }
+  for (int l = 0; l < c.n_enc_layers; ++l) {
+    const EncLayerW& w = m->enc[l];
+    WIS_RET(launch_layernorm(st, m->x, w.ln1_g, w.ln1_b, m->xn, M, d));
+    WIS_RET(launch_gemm_qkv(st, gemm_plain(m->xn, d, w.w_qkv, M, 3 * d, d), w.b_qkv, m->qk, m->vt, d, T, m->Tpad, H));
+    WIS_RET(launch_enc_attention(st, m->qk, m->vt, m->ao, B, T, m->Tpad, H));
+    WIS_RET(launch_gemm_generic(st, gemm_plain(m->ao, d, w.w_out, M, d, d), w.b_out, m->x, m->x, 2 | 4));
+    WIS_RET(launch_layernorm(st, m->x, w.ln2_g, w.ln2_b, m->xn, M, d));
+    WIS_RET(launch_gemm_generic(st, gemm_plain(m->xn, d, w.w_f1, M, 4 * d, d), w.b_f1, nullptr, m->hbuf, 1));
+    WIS_RET(launch_gemm_generic(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), w.b_f2, m->x, m->x, 2 | 4));
+  }
+  WIS_RET(launch_layernorm(st, m->x, m->enc_ln_g, m->enc_ln_b, m->mem, M, d));
+  return WIS_OK;
+}
+int run_cross_kv(wis_model* m, int B) {
+  const wis_config_t& c = m->cfg;
+  const int d = c.d_model, T = c.n_audio_ctx;
+  for (int l = 0; l < c.n_dec_layers; ++l)
+    WIS_RET(launch_gemm_crosskv(m->st, gemm_plain(m->mem, d, m->dec[l].w_ckv, B * T, 2 * d, d), m->dec[l].b_ckv, m->kx[l], m->vx[l], d, T, c.n_heads));
+  return WIS_OK;
+}
+
+// ---- one decoder forward over the current row metadata ---------------------------------
+int dec_forward(wis_model* m, int M, int R, int B, bool want_logits) {
+  const wis_config_t& c = m->cfg; hipStream_t st = m->st;
+  const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
+  int chunks = 256 / (B * H); if (chunks < 1) chunks = 1; if (chunks > 8) chunks = 8;
+  WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
+  for (int l = 0; l < c.n_dec_layers; ++l) {
+    const DecLayerW& w = m->dec[l];
+    GemvP g; memset(&g, 0, sizeof(g));
+    // self-attention block
+    g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
+    g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
+    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.lslot, m->rm.pos, m->dao, M, H, d, ctx));
+    memset(&g, 0, sizeof(g));
+    g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
+    WIS_RET(launch_gemv(st, g));
+    // cross-attention block
+    memset(&g, 0, sizeof(g));
+    g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, chunks));
+    memset(&g, 0, sizeof(g));
+    g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
+    WIS_RET(launch_gemv(st, g));
+    // FFN
+    memset(&g, 0, sizeof(g));
+    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU;
+    WIS_RET(launch_gemv(st, g));
+    memset(&g, 0, sizeof(g));
+    g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID;
+    WIS_RET(launch_gemv(st, g));
+  }
+  if (want_logits) {
+    GemvP g; memset(&g, 0, sizeof(g));
+    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    WIS_RET(launch_gemv(st, g));
+  }
+  return WIS_OK;
+}
+
+int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot) {
+  const size_t n = tok.size();
+  int* h = m->h_pin + 1024;
+  memcpy(h, tok.data(), n * 4); memcpy(h + MAX_ROWS, pos.data(), n * 4); memcpy(h + 2 * MAX_ROWS, slot.data(), n * 4); memcpy(h + 3 * MAX_ROWS, lslot.data(), n * 4);
+  WIS_HIP_CHECK(hipMemcpyAsync(m->rm.tok, h, n * 4, hipMemcpyHostToDevice, m->st));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->rm.pos, h + MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->rm.slot, h + 2 * MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->rm.lslot, h + 3 * MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
+  // the pinned staging area is reused by the next upload: make sure the copies are done
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  return WIS_OK;
+}
+
+int check_batch(wis_model* m, int B, int beam) {
+  if (B < 1 || B > m->cfg.max_batch) { set_error("batch %d outside [1, max_batch=%d]", B, m->cfg.max_batch); return WIS_E_STATE; }
+  if (beam < 1 || beam > m->cfg.max_beam || beam > MAX_R) { set_error("beam_size %d outside [1, %d]", beam, m->cfg.max_beam < MAX_R ? m->cfg.max_beam : MAX_R); return WIS_E_STATE; }
+  if (B * beam > MAX_ROWS) { set_error("B*beam = %d exceeds %d decoder rows per device batch", B * beam, MAX_ROWS); return WIS_E_STATE; }
+  return WIS_OK;
+}
+
+}  // namespace
+
+// =======================================================================================
+extern "C" {
+
+int wis_version(void) { return WIS_ABI_VERSION; }
+const char* wis_last_error(void) { return get_error(); }
+int wis_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int wis_supported_compute_types(int device, char* out, size_t cap) {
+  (void)device;
+  const char* s = "float16,float32";
+  if (!out || cap < strlen(s) + 1) { set_error("buffer too small"); return WIS_E_ARG; }
+  strcpy(out, s); return WIS_OK;
+}
+
+int wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_bytes, int arena_on_device,
+                     const wis_tensor_t* tensors, int n_tensors, int device, wis_model_t** out) {
+  if (!cfg || !arena || !tensors || !out || n_tensors <= 0) { set_error("wis_model_create: bad argument"); return WIS_E_ARG; }
+  if (cfg->d_model % 128 || cfg->d_model != cfg->n_heads * 64 || cfg->d_model > 2048 || cfg->n_mels != 80 || cfg->n_audio_ctx != 1500 ||
+      cfg->n_text_ctx > 512 || cfg->max_batch < 1 || cfg->max_beam < 1 || cfg->max_beam > MAX_R || cfg->n_vocab < 1024) {
+    set_error("wis_model_create: unsupported config (d_model %% 128, head_dim 64, n_mels 80, n_audio_ctx 1500, max_beam <= %d)", MAX_R);
+    return WIS_E_UNSUPPORTED;
+  }
+  DeviceCtx* ctx; WIS_RET(get_ctx(device, &ctx));
+  wis_model* m = new wis_model();
+  m->cfg = *cfg; m->device = device; m->ctx = ctx;
+  m->use_graph = getenv("WIS_NO_GRAPH") == nullptr;
+  memset(&m->timing, 0, sizeof(m->timing));
+  int rc = WIS_OK;
+  void* d_arena = nullptr;
+  do {
+    if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess) { set_error("stream create failed"); rc = WIS_E_HIP; break; }
+    const char* base = reinterpret_cast<const char*>(arena);
+    if (!arena_on_device) {
+      if (hipMalloc(&d_arena, arena_bytes) != hipSuccess) { set_error("hipMalloc(arena %zu) failed", arena_bytes); rc = WIS_E_NOMEM; break; }
+      if (hipMemcpy(d_arena, arena, arena_bytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("arena upload failed"); rc = WIS_E_HIP; break; }
+      base = reinterpret_cast<const char*>(d_arena);
+    }
+    Loader L{tensors, n_tensors, base, arena_bytes};
+    if ((rc = load_weights(m, L))) break;
+    // logits processors as additive masks (0 / -inf) over the padded vocabulary
+    {
+      std::vector<float> ba(m->n_vocab_pad, 0.f), bb(m->n_vocab_pad, 0.f);
+      for (int i = 0; i < cfg->n_suppress; ++i) if (cfg->suppress_ids[i] >= 0 && cfg->suppress_ids[i] < cfg->n_vocab) ba[cfg->suppress_ids[i]] = -INFINITY;
+      for (int i = 0; i < cfg->n_suppress_begin; ++i) if (cfg->suppress_ids_begin[i] >= 0 && cfg->suppress_ids_begin[i] < cfg->n_vocab) bb[cfg->suppress_ids_begin[i]] = -INFINITY;
+      if ((rc = dalloc(m, &m->bias_all, ba.size())) || (rc = dalloc(m, &m->bias_begin, bb.size()))) break;
+      hipMemcpy(m->bias_all, ba.data(), ba.size() * 4, hipMemcpyHostToDevice);
+      hipMemcpy(m->bias_begin, bb.data(), bb.size() * 4, hipMemcpyHostToDevice);
+      if ((rc = dalloc(m, &m->d_lang_ids, (size_t)(cfg->n_lang > 0 ? cfg->n_lang : 1)))) break;
+      if (cfg->n_lang > 0) hipMemcpy(m->d_lang_ids, cfg->lang_ids, (size_t)cfg->n_lang * 4, hipMemcpyHostToDevice);
+    }
+    m->cfg.suppress_ids = nullptr; m->cfg.suppress_ids_begin = nullptr; m->cfg.lang_ids = nullptr;   // caller-owned memory is not retained
+    if ((rc = alloc_buffers(m))) break;
+    if (hipStreamSynchronize(m->st) != hipSuccess) { set_error("model init failed"); rc = WIS_E_HIP; break; }
+  } while (0);
+  if (d_arena) hipFree(d_arena);
+  if (rc) { wis_model_destroy(m); return rc; }
+  *out = m;
+  return WIS_OK;
+}
+
+void wis_model_destroy(wis_model_t* m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  if (m->st) hipStreamSynchronize(m->st);
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  for (void* p : m->allocs) hipFree(p);
+  if (m->h_pin) hipHostFree(m->h_pin);
+  for (int i = 0; i < 8; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
+  if (m->st) hipStreamDestroy(m->st);
+  delete m;
+}
+size_t wis_model_device_bytes(const wis_model_t* m) { return m ? m->bytes : 0; }
+
+int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
+                 const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score) {
+  if (!m || !input || !prompt || !o || !out_ids || !out_len) { set_error("wis_generate: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  const wis_config_t& c = m->cfg;
+  const int beam = o->beam_size < 1 ? 1 : o->beam_size;
+  WIS_RET(check_batch(m, B, beam));
+  if (P < 1 || P - 1 > MAX_R || B * (P - 1) > MAX_ROWS) { set_error("prompt length %d unsupported (1..%d)", P, MAX_R + 1); return WIS_E_UNSUPPORTED; }
+  int max_new = o->max_new_tokens > 0 ? o->max_new_tokens : std::min(c.n_text_ctx / 2, c.n_text_ctx - P);
+  if (max_new > 256) max_new = 256;
+  if (P - 1 + max_new > c.n_text_ctx) max_new = c.n_text_ctx - (P - 1);
+  for (int i = 0; i < B * P; ++i) if (prompt[i] < 0 || prompt[i] >= c.n_vocab) { set_error("prompt token %d out of range", prompt[i]); return WIS_E_ARG; }
+  hipStream_t st = m->st;
+  const int ctx = c.n_text_ctx;
+  auto t0 = std::chrono::steady_clock::now();
+
+  WIS_HIP_CHECK(hipEventRecord(m->ev[0], st));
+  WIS_RET(stage_input(m, input, o->input_kind, B));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[1], st));
+  WIS_RET(run_encoder(m, B));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[2], st));
+  WIS_RET(run_cross_kv(m, B));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[3], st));
+
+  // ---- decode state
+  const int Mrows = B * beam;
+  {
+    std::vector<int> anc((size_t)Mrows * ctx);
+    for (int r = 0; r < Mrows; ++r)
+      for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = (p < P - 1) ? (r / beam) * beam : r;
+    std::vector<float> cum(Mrows);
+    for (int r = 0; r < Mrows; ++r) cum[r] = (r % beam == 0) ? 0.f : -INFINITY;   // CT2 GPU path: beams tiled up front, scores [0, -inf, ...]
+    WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, st));
+    WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->bs.step_u, 0, (size_t)B * 4, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->bs.done, 0, (size_t)B * 4, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->bs.n_hyp, 0, (size_t)B * 4, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->bs.all_done, 0, 16, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->bs.out_len, 0, (size_t)B * 4, st));
+    WIS_HIP_CHECK(hipStreamSynchronize(st));   // host vectors go out of scope
+  }
+  // ---- prefill: prompt[:-1] through the decoder, one pass, rows (b, i)
+  if (P > 1) {
+    const int R = P - 1;
+    std::vector<int> tok(B * R), pos(B * R), slot(B * R), ls(B * R);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < R; ++i) { tok[b * R + i] = prompt[b * P + i]; pos[b * R + i] = i; slot[b * R + i] = b * beam; ls[b * R + i] = b * beam; }
+    WIS_RET(upload_rows(m, tok, pos, slot, ls));
+    WIS_RET(dec_forward(m, B * R, R, B, false));
+  }
+  WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
+  {
+    std::vector<int> tok(Mrows), pos(Mrows), slot(Mrows), ls(Mrows);
+    for (int r = 0; r < Mrows; ++r) { tok[r] = prompt[(r / beam) * P + P - 1]; pos[r] = P - 1; slot[r] = r; ls[r] = r; }
+    WIS_RET(upload_rows(m, tok, pos, slot, ls));
+  }
+  SampleCfg sc; memset(&sc, 0, sizeof(sc));
+  sc.n_vocab = c.n_vocab; sc.n_vocab_pad = m->n_vocab_pad; sc.eot = c.eot; sc.beam = beam; sc.n_cand = 2 * beam; sc.max_new = max_new;
+  sc.fixed_new = o->fixed_new_tokens; sc.suppress_blank = o->suppress_blank; sc.greedy = beam == 1;
+  sc.length_penalty = o->length_penalty; sc.max_hyp = 2 * MAX_R;
+  const float patience = o->patience > 0.f ? o->patience : 1.f;
+  sc.max_candidates = (int)lroundf((float)beam * patience); if (sc.max_candidates < 1) sc.max_candidates = 1;
+  if (sc.max_candidates > sc.max_hyp - beam) sc.max_candidates = sc.max_hyp - beam > 0 ? sc.max_hyp - beam : 1;
+  // CT2: allow_early_exit = patience == 1 && length_penalty == 0 && coverage_penalty == 0
+  sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
+
+  auto one_step = [&]() -> int {
+    WIS_RET(dec_forward(m, Mrows, beam, B, true));
+    WIS_RET(launch_logit_stats(st, m->logits, o->suppress_default ? m->bias_all : nullptr, m->bias_begin, m->bs.step_u,
+                               m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc));
+    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc));
+    return WIS_OK;
+  };
+  hipGraphExec_t gexec = nullptr;
+  if (m->use_graph) {
+    GraphKey key; memset(&key, 0, sizeof(key));
+    key.B = B; key.beam = beam; key.P = P; key.max_new = max_new; key.fixed_new = sc.fixed_new; key.suppress_blank = sc.suppress_blank;
+    key.suppress_default = o->suppress_default; key.early_exit = sc.allow_early_exit; key.lp = sc.length_penalty; key.patience = patience;
+    auto it = m->graphs.find(key);
+    if (it != m->graphs.end()) gexec = it->second;
+    else {
+      hipGraph_t graph = nullptr;
+      WIS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = one_step();
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) { set_error("graph capture failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+      e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e != hipSuccess) { set_error("graph instantiate failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+      m->graphs[key] = gexec;
+    }
+  }
+  int sync_every = o->sync_every > 0 ? o->sync_every : 4;
+  int steps = 0;
+  int* h_done = m->h_pin;   // pinned
+  *h_done = 0;
+  // with the measurement convention the step count is known: fixed_new tokens + the forced EOT
+  const int known = (sc.fixed_new > 0) ? std::min(max_new, sc.fixed_new + 1) : 0;
+  while (steps < max_new) {
+    int burst = known ? known - steps : std::min(sync_every, max_new - steps);
+    if (burst <= 0) break;
+    for (int i = 0; i < burst; ++i) {
+      if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
+    }
+    steps += burst;
+    WIS_HIP_CHECK(hipMemcpyAsync(h_done, m->bs.all_done, 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipStreamSynchronize(st));
+    if (*h_done >= B) break;
+  }
+  WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
+  if (*h_done < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, *h_done, B); return WIS_E_STATE; }
+  // results
+  std::vector<int32_t> ids((size_t)B * 256);
+  WIS_HIP_CHECK(hipMemcpyAsync(ids.data(), m->bs.out_ids, (size_t)B * 256 * 4, hipMemcpyDeviceToHost, st));
+  WIS_HIP_CHECK(hipMemcpyAsync(out_len, m->bs.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  std::vector<float> sc_h(B);
+  WIS_HIP_CHECK(hipMemcpyAsync(sc_h.data(), m->bs.out_score, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  WIS_HIP_CHECK(hipStreamSynchronize(st));
+  // out_ids is laid out [B][256] on device (allocation constant); caller's is [B][max_new]
+  for (int b = 0; b < B; ++b) {
+    if (out_len[b] > max_new) out_len[b] = max_new;
+    for (int t = 0; t < max_new; ++t) out_ids[(size_t)b * max_new + t] = t < out_len[b] ? ids[(size_t)b * max_new + t] : 0;
+    if (out_score) out_score[b] = sc_h[b];
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  float ms;
+  hipEventElapsedTime(&ms, m->ev[0], m->ev[1]); m->timing.logmel_ms = ms;
+  hipEventElapsedTime(&ms, m->ev[1], m->ev[2]); m->timing.encoder_ms = ms;
+  hipEventElapsedTime(&ms, m->ev[2], m->ev[3]); m->timing.crosskv_ms = ms;
+  hipEventElapsedTime(&ms, m->ev[3], m->ev[4]); m->timing.prefill_ms = ms;
+  hipEventElapsedTime(&ms, m->ev[4], m->ev[5]); m->timing.decode_ms = ms;
+  m->timing.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  m->timing.decode_steps = steps;
+  return WIS_OK;
+}
+
+int wis_last_timing(const wis_model_t* m, wis_timing_t* t) {
+  if (!m || !t) { set_error("wis_last_timing: bad argument"); return WIS_E_ARG; }
+  *t = m->timing; return WIS_OK;
+}
+
+// rows (b): R = 1, identity ancestry
+static int single_row_setup(wis_model* m, int B, const std::vector<int>& tok, int pos) {
+  const int ctx = m->cfg.n_text_ctx;
+  if (pos == 0) {
+    std::vector<int> anc((size_t)B * ctx);
+    for (int r = 0; r < B; ++r) for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = r;
+    WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, m->st));
+    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  }
+  std::vector<int> ps(B, pos), slot(B), ls(B);
+  for (int r = 0; r < B; ++r) { slot[r] = r; ls[r] = r; }
+  return upload_rows(m, tok, ps, slot, ls);
+}
+
+int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int B, float* lang_probs) {
+  if (!m || !input || !lang_probs) { set_error("wis_detect_language: bad argument"); return WIS_E_ARG; }
+  if (m->cfg.n_lang <= 0) { set_error("model has no lang_ids"); return WIS_E_UNSUPPORTED; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, B, 1));
+  WIS_RET(stage_input(m, input, input_kind, B));
+  WIS_RET(run_encoder(m, B));
+  WIS_RET(run_cross_kv(m, B));
+  std::vector<int> tok(B, m->cfg.sot);
+  WIS_RET(single_row_setup(m, B, tok, 0));
+  WIS_RET(dec_forward(m, B, 1, B, true));
+  WIS_RET(launch_lang_probs(m->st, m->logits, m->n_vocab_pad, m->d_lang_ids, m->cfg.n_lang, m->d_probs, B));
+  WIS_HIP_CHECK(hipMemcpyAsync(lang_probs, m->d_probs, (size_t)B * m->cfg.n_lang * 4, hipMemcpyDeviceToHost, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  return WIS_OK;
+}
+
+int wis_debug_encode(wis_model_t* m, const float* input, int input_kind, int B, float* enc_out) {
+  if (!m || !input || !enc_out) { set_error("wis_debug_encode: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, B, 1));
+  WIS_RET(stage_input(m, input, input_kind, B));
+  WIS_RET(run_encoder(m, B));
+  const int64_t n = (int64_t)B * m->cfg.n_audio_ctx * m->cfg.d_model;
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(blocks_for(n)), dim3(256), 0, m->st, m->mem, m->x, n);   // x is free after the encoder
+  WIS_HIP_CHECK(hipMemcpyAsync(enc_out, m->x, (size_t)n * 4, hipMemcpyDeviceToHost, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  return WIS_OK;
+}
+
+int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, const int32_t* dec_in, int T, float* logits) {
+  if (!m || !input || !dec_in || !logits || T < 1 || T > m->cfg.n_text_ctx) { set_error("wis_debug_logits: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, B, 1));
+  WIS_RET(stage_input(m, input, input_kind, B));
+  WIS_RET(run_encoder(m, B));
+  WIS_RET(run_cross_kv(m, B));
+  const int V = m->cfg.n_vocab;
+  for (int t = 0; t < T; ++t) {
+    std::vector<int> tok(B);
+    for (int b = 0; b < B; ++b) tok[b] = dec_in[b * T + t];
+    WIS_RET(single_row_setup(m, B, tok, t));
+    WIS_RET(dec_forward(m, B, 1, B, true));
+    for (int b = 0; b < B; ++b)
+      WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t) * V, m->logits + (size_t)b * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
+    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  }
+  return WIS_OK;
+}
+
+int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, int* launches_per_pass, double* bytes_per_pass) {
+  if (!m || M < 1 || M > MAX_ROWS || passes < 1 || !total_ms) { set_error("wis_bench_weight_stream: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  const int d = m->cfg.d_model; hipStream_t st = m->st;
+  int launches = 0; double bytes = 0;
+  auto pass = [&](bool count) -> int {
+    for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
+      const DecLayerW& w = m->dec[l];
+      struct { const f16* wp; const float* b; const float* g; const float* be; int N, K; bool ln; } mats[6] = {
+        {w.p_qkv, w.b_qkv, w.ln1_g, w.ln1_b, 3 * d, d, true}, {w.p_out, w.b_out, nullptr, nullptr, d, d, false},
+        {w.p_cq, w.b_cq, w.ln2_g, w.ln2_b, d, d, true},        {w.p_cout, w.b_cout, nullptr, nullptr, d, d, false},
+        {w.p_f1, w.b_f1, w.ln3_g, w.ln3_b, 4 * d, d, true},    {w.p_f2, w.b_f2, nullptr, nullptr, d, 4 * d, false}};
+      for (auto& t : mats) {
+        GemvP g; memset(&g, 0, sizeof(g));
+        g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.gamma = t.g; g.beta = t.be; g.Wp = t.wp; g.bias = t.b;
+        g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
+        WIS_RET(launch_gemv(st, g));
+        if (count) { ++launches; bytes += (double)t.N * t.K * 2; }
+      }
+    }
+    GemvP g; memset(&g, 0, sizeof(g));
+    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    WIS_RET(launch_gemv(st, g));
+    if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * 2; }
+    return WIS_OK;
+  };
+  WIS_HIP_CHECK(hipMemsetAsync(m->dx, 0, (size_t)MAX_ROWS * d * 4, st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->dh, 0, (size_t)MAX_ROWS * 4 * d * 2, st));
+  WIS_RET(pass(true));   // warm-up pass (also counts launches / bytes)
+  WIS_HIP_CHECK(hipEventRecord(m->ev[6], st));
+  for (int i = 0; i < passes; ++i) WIS_RET(pass(false));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[7], st));
+  WIS_HIP_CHECK(hipStreamSynchronize(st));
+  WIS_HIP_CHECK(hipEventElapsedTime(total_ms, m->ev[6], m->ev[7]));
+  if (launches_per_pass) *launches_per_pass = launches;
+  if (bytes_per_pass) *bytes_per_pass = bytes;
+  return WIS_OK;
+}
+
+// ---- raw device helpers + single-kernel entry points -----------------------------------
+int wis_dev_alloc(int device, size_t bytes, void** out) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  WIS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 16)); return WIS_OK;
+}
+int wis_dev_free(int device, void* p) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipFree(p)); return WIS_OK; }
+int wis_dev_h2d(int device, void* dst, const void* src, size_t bytes) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return WIS_OK; }
+int wis_dev_d2h(int device, void* dst, const void* src, size_t bytes) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return WIS_OK; }
+int wis_dev_sync(int device) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipDeviceSynchronize()); return WIS_OK; }
+
+int wis_op_gemm(int device, const void* A, int lda, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K, int flags) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  WIS_RET(launch_gemm_generic(ctx_stream(c), gemm_plain(reinterpret_cast<const f16*>(A), lda, reinterpret_cast<const f16*>(W), M, N, K), bias, residual, C, flags));
+  WIS_HIP_CHECK(hipGetLastError());
+  WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
+  return WIS_OK;
+}
+int wis_op_layernorm(int device, const float* x, const float* gamma, const float* beta, void* y, int M, int d) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  WIS_RET(launch_layernorm(ctx_stream(c), x, gamma, beta, reinterpret_cast<f16*>(y), M, d));
+  WIS_HIP_CHECK(hipGetLastError());
+  WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
+  return WIS_OK;
+}
+int wis_op_enc_attention(int device, const void* qk, const void* vt, void* out, int B, int T, int Tpad, int H) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  WIS_RET(launch_enc_attention(ctx_stream(c), reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H));
+  WIS_HIP_CHECK(hipGetLastError());
+  WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
+  return WIS_OK;
+}
+int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y, int M, int N, int K, int flags) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  hipStream_t st = ctx_stream(c);
+  if (flags & GV_QKV) { set_error("wis_op_gemv: flag 16 is internal"); return WIS_E_ARG; }
+  const int Npad = cdiv(N, 16) * 16;
+  f16* wp = nullptr;
+  WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Npad * K * 2));
+  int rc = launch_pack_gemv(st, reinterpret_cast<const f16*>(W), wp, N, Npad, K, 0, 1.f);
+  if (!rc) {
+    GemvP g; memset(&g, 0, sizeof(g));
+    g.x = x; g.gamma = gamma; g.beta = beta; g.Wp = wp; g.bias = bias; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags;
+    rc = launch_gemv(st, g);
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(wp);
+  if (rc) return rc;
+  if (e != hipSuccess) { set_error("wis_op_gemv: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+  return WIS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""Drop-in for the reference's `wis/audio.py` (same public names, reference main.py:52-57), with the
+arithmetic moved to the GPU:
+
+    from wis_hip.audio import log_mel_spectrogram, pad_or_trim, chunk_iter, find_longest_common_sequence
+
+`log_mel_spectrogram` runs the hand-written gfx950 kernels of csrc/logmel.hip through the C-ABI
+(`wis_logmel`); it raises if libwis_hip.so or a GPU is missing (no CPU fallback).  `pad_or_trim`,
+`chunk_iter` and `find_longest_common_sequence` are integer/host logic and keep the reference's
+semantics exactly (wis/audio.py:28-51, 119-134, 139-159).  `load_audio` replaces the
+`librosa.load(audio_file, sr=16000, mono=True)` call of main.py:579.
+"""
+import ctypes as C
+import io
+
+import numpy as np
+
+from . import _lib
+
+SAMPLE_RATE = 16000
+N_FFT = 400
+N_MELS = 80
+HOP_LENGTH = 160
+CHUNK_LENGTH = 30
+N_SAMPLES = CHUNK_LENGTH * SAMPLE_RATE
+N_FRAMES = N_SAMPLES // HOP_LENGTH
+
+chunk_length_s = 22
+stride_length_s = [4, 4]
+chunk_len = chunk_length_s * SAMPLE_RATE
+stride_left = stride_length_s[0] * SAMPLE_RATE
+stride_right = stride_length_s[1] * SAMPLE_RATE
+
+
+def load_audio(audio_file):
+    """FLAC / WAV path, bytes or file-like -> (float32 mono PCM in [-1, 1), sample_rate).
+
+    Container decode is host C code inside libwis_hip.so (wis_audio_decode); FLAC streams are MD5-verified."""
+    if isinstance(audio_file, (bytes, bytearray, memoryview)):
+        data = bytes(audio_file)
+    elif hasattr(audio_file, "read"):
+        if hasattr(audio_file, "seek"):
+            audio_file.seek(0)
+        data = audio_file.read()
+    else:
+        with open(audio_file, "rb") as f:
+            data = f.read()
+    lib = _lib.load()
+    p, n, sr, md = C.POINTER(C.c_float)(), C.c_int64(), C.c_int(), C.c_int()
+    _lib.check(lib.wis_audio_decode(data, len(data), C.byref(p), C.byref(n), C.byref(sr), C.byref(md)))
+    try:
+        pcm = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
+    finally:
+        lib.wis_audio_free(p)
+    if sr.value != SAMPLE_RATE:
+        raise ValueError(f"audio is {sr.value} Hz; the ASR path takes {SAMPLE_RATE} Hz input (resampling is out of scope)")
+    return pcm, sr.value
+
+
+def pad_or_trim(array, length: int = N_SAMPLES, *, axis: int = -1):
+    """Zero-pad on the right / truncate `axis` to `length` samples (numpy arrays)."""
+    array = np.asarray(array)
+    n = array.shape[axis]
+    if n > length:
+        array = np.take(array, np.arange(length), axis=axis)
+    elif n < length:
+        widths = [(0, 0)] * array.ndim
+        widths[axis] = (0, length - n)
+        array = np.pad(array, widths)
+    return array
+
+
+class MelFeatures:
+    """What the reference's `log_mel_spectrogram(...)` result is used for: `.numpy()` (main.py:608,614)."""
+
+    def __init__(self, arr):
+        self._arr = arr
+
+    def numpy(self):
+        return self._arr
+
+    @property
+    def shape(self):
+        return self._arr.shape
+
+    def __array__(self, dtype=None, copy=None):
+        return self._arr if dtype is None else self._arr.astype(dtype)
+
+
+def log_mel_spectrogram(audio, n_mels: int = N_MELS, device: int = 0):
+    """float32 [480000] (or [n, 480000]) -> MelFeatures wrapping float32 [80, 3000] (or [n, 80, 3000])."""
+    assert n_mels == 80, f"Unsupported n_mels: {n_mels}"
+    x = np.ascontiguousarray(np.asarray(audio, dtype=np.float32))
+    single = x.ndim == 1
+    if single:
+        x = x[None]
+    if x.ndim != 2 or x.shape[1] != N_SAMPLES:
+        raise ValueError(f"log_mel_spectrogram expects pad_or_trim'ed audio of {N_SAMPLES} samples, got {x.shape}")
+    _lib.require_gpu()
+    n = x.shape[0]
+    out = np.empty((n, N_MELS, N_FRAMES), np.float32)
+    ns = (C.c_int64 * n)(*([N_SAMPLES] * n))
+    _lib.check(_lib.load().wis_logmel(device, _lib.ptr(x), N_SAMPLES, ns, n, 0, _lib.ptr(out), 0))
+    return MelFeatures(out[0] if single else out)
+
+
+def chunk_iter(inputs):
+    """22 s windows with 4 s of context each side, stepping 14 s; yields (chunk, (len, left, right))."""
+    assert isinstance(inputs, np.ndarray), "chunk_iter only takes numpy array"
+    total = inputs.shape[0]
+    step = chunk_len - stride_left - stride_right
+    start = 0
+    while start < total:
+        piece = inputs[start:start + chunk_len]
+        left = stride_left if start else 0
+        right = 0 if start + step + stride_left >= total else stride_right
+        if piece.shape[0] > left:
+            yield piece, (piece.shape[0], left, right)
+        start += step
+
+
+def find_longest_common_sequence(sequences, tokenizer):
+    """Stitch per-window token id lists: for each next window choose the overlap length i that maximises
+    matches/i + i/10000 with matches > 1 and append the remainder.  `tokenizer.all_special_ids` are dropped first."""
+    special = set(tokenizer.all_special_ids)
+    merged = [t for t in sequences[0][0] if t not in special]
+    for entry in sequences[1:]:
+        cand = [t for t in entry[0] if t not in special]
+        cut, best = 0, 0.0
+        for i in range(1, len(cand) + 1):
+            tail, head = merged[-i:], cand[:i]
+            hits = sum(1 for a, b in zip(tail, head) if a == b) if len(tail) == len(head) else 0
+            score = hits / i + i / 10000.0
+            if hits > 1 and score > best:
+                cut, best = i, score
+        merged.extend(cand[cut:])
+    return np.array(merged)

@@ -1,0 +1,250 @@
+"""Call-compatible stand-in for the slice of `ctranslate2` the reference uses:
+
+    ctranslate2.models.Whisper(path, device=, compute_type=, inter_threads=, device_index=[..] | intra_threads=)
+    ctranslate2.StorageView.from_array(ndarray f32 [B, 80, 3000])
+    model.generate(features, [prompt] * B, beam_size=int, return_scores=False) -> results[i].sequences_ids[0]
+    model.detect_language(features) -> [[("<|xx|>", prob), ...], ...]
+    ctranslate2.get_supported_compute_types(device)
+
+(reference main.py:341-444, 454, 535-537, 638-639, 685-693, 707, 713).  The arithmetic runs in the
+hand-written HIP kernels of libwis_hip.so; there is no CPU fallback and no dependency on CTranslate2.
+
+`model_path` is either a CTranslate2 Whisper model directory (model.bin [+ config.json]) or the
+string "synthetic:<size>[:seed]" for seeded synthetic weights at the true shapes (no checkpoint exists
+offline).
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _lib, weights as W
+from .languages import LANGUAGE_CODES
+
+
+def get_supported_compute_types(device="cuda", device_index=0):
+    buf = C.create_string_buffer(64)
+    _lib.check(_lib.load().wis_supported_compute_types(device_index, buf, 64))
+    return set(buf.value.decode().split(","))
+
+
+class StorageView:
+    """Zero-copy wrapper of a host ndarray (ctranslate2.StorageView.from_array, main.py:638,685)."""
+
+    def __init__(self, array):
+        self.array = array
+
+    @classmethod
+    def from_array(cls, array):
+        a = np.asarray(array)
+        if a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("StorageView.from_array expects a C-contiguous float32 array")
+        return cls(a)
+
+    @property
+    def shape(self):
+        return list(self.array.shape)
+
+
+class WhisperGenerationResult:
+    def __init__(self, sequences_ids, scores, no_speech_prob=0.0):
+        self.sequences_ids = sequences_ids
+        self.sequences = [[str(t) for t in s] for s in sequences_ids]
+        self.scores = scores
+        self.no_speech_prob = no_speech_prob
+
+    def __repr__(self):
+        return f"WhisperGenerationResult(sequences_ids={self.sequences_ids}, scores={self.scores})"
+
+
+class _Replica:
+    def __init__(self, handle, device):
+        self.handle, self.device = handle, device
+        self.lock = threading.Lock()
+        self.inflight = 0
+
+
+def make_config(a, max_batch, max_beam, suppress_ids=None, suppress_begin=None, lang_ids=None, n_vocab=None):
+    sup = np.asarray(W.SUPPRESS_IDS if suppress_ids is None else suppress_ids, np.int32)
+    beg = np.asarray(W.SUPPRESS_IDS_BEGIN if suppress_begin is None else suppress_begin, np.int32)
+    lang = np.asarray(W.LANG_IDS if lang_ids is None else lang_ids, np.int32)
+    cfg = _lib.Config()
+    cfg.d_model, cfg.n_heads = a["d_model"], a["n_heads"]
+    cfg.n_enc_layers = cfg.n_dec_layers = a["n_layers"]
+    cfg.n_vocab = n_vocab or a["n_vocab"]
+    cfg.n_audio_ctx, cfg.n_text_ctx, cfg.n_mels = a["n_audio_ctx"], a["n_text_ctx"], a["n_mels"]
+    cfg.max_batch, cfg.max_beam = max_batch, max_beam
+    cfg.eot, cfg.sot, cfg.no_timestamps, cfg.no_speech = W.EOT, W.SOT, W.NO_TIMESTAMPS, W.NO_SPEECH
+    cfg.suppress_ids = sup.ctypes.data_as(C.POINTER(C.c_int32)); cfg.n_suppress = len(sup)
+    cfg.suppress_ids_begin = beg.ctypes.data_as(C.POINTER(C.c_int32)); cfg.n_suppress_begin = len(beg)
+    cfg.lang_ids = lang.ctypes.data_as(C.POINTER(C.c_int32)); cfg.n_lang = len(lang)
+    cfg._keep = (sup, beg, lang)
+    return cfg
+
+
+def make_tensor_index(index):
+    arr = (_lib.Tensor * len(index))()
+    keep = []
+    for i, e in enumerate(index):
+        nm = e["name"].encode()
+        keep.append(nm)
+        arr[i].name = nm
+        arr[i].dtype = _lib.WIS_DT_F16 if e["dtype"] == "f16" else _lib.WIS_DT_F32
+        arr[i].rank = len(e["shape"])
+        for j, s in enumerate(e["shape"]):
+            arr[i].shape[j] = s
+        arr[i].offset = e["offset"]
+    arr._keep = keep
+    return arr
+
+
+def create_handle(a, arena, index, device, max_batch=8, max_beam=5, arena_device_ptr=None, n_vocab=None, **cfgkw):
+    """arena: uint8 ndarray (host) or None with arena_device_ptr = (ptr, nbytes) already on `device`."""
+    cfg = make_config(a, max_batch, max_beam, n_vocab=n_vocab, **cfgkw)
+    tens = make_tensor_index(index)
+    h = C.c_void_p()
+    if arena_device_ptr is not None:
+        p, nbytes = arena_device_ptr
+        rc = _lib.load().wis_model_create(C.byref(cfg), C.c_void_p(p), nbytes, 1, tens, len(index), device, C.byref(h))
+    else:
+        rc = _lib.load().wis_model_create(C.byref(cfg), _lib.ptr(arena), arena.nbytes, 0, tens, len(index), device, C.byref(h))
+    _lib.check(rc)
+    return h
+
+
+class Whisper:
+    """One replica per entry of `device_index` (reference: `device_index=[*range(cuda_num_devices)]`, main.py:295)."""
+
+    is_multilingual = True
+
+    def __init__(self, model_path, device="cuda", device_index=0, compute_type="default", inter_threads=1, intra_threads=0,
+                 max_batch=8, max_beam=5, weights=None, arch=None, **_ignored):
+        if device not in ("cuda", "auto", "hip", "gpu"):
+            raise ValueError(f"wis_hip runs on MI355X GPUs only (device={device!r}); there is no CPU path")
+        _lib.require_gpu()
+        self.compute_type = "float16"
+        if weights is None:
+            weights, arch = self._load(model_path)
+        self.arch = arch
+        devs = list(device_index) if isinstance(device_index, (list, tuple)) else [int(device_index)]
+        arena, index = W.build_arena(weights)
+        self._replicas = [_Replica(create_handle(arch, arena, index, d, max_batch, max_beam), d) for d in devs]
+        self.max_batch, self.max_beam = max_batch, max_beam
+        self._pick = threading.Lock()
+
+    @staticmethod
+    def _load(model_path):
+        if isinstance(model_path, str) and model_path.startswith("synthetic:"):
+            parts = model_path.split(":")
+            size = parts[1]
+            seed = int(parts[2]) if len(parts) > 2 else 1234
+            return W.synthetic_weights(size, seed=seed), W.arch(size)
+        if not os.path.isdir(model_path):
+            raise FileNotFoundError(f"{model_path}: not a CTranslate2 model directory (or use 'synthetic:<size>')")
+        w, _cfg = W.load_model_dir(model_path)
+        d = w["decoder/embeddings/weight"].shape[1]
+        for name, (dd, L, H) in W.ARCH.items():
+            if dd == d:
+                a = W.arch(name)
+                a["n_vocab"] = w["decoder/embeddings/weight"].shape[0]
+                return w, a
+        raise ValueError(f"unsupported d_model {d}")
+
+    def __del__(self):
+        try:
+            for r in getattr(self, "_replicas", []):
+                if r.handle:
+                    _lib.load().wis_model_destroy(r.handle)
+                    r.handle = None
+        except Exception:
+            pass
+
+    def _acquire(self):
+        with self._pick:
+            r = min(self._replicas, key=lambda x: x.inflight)
+            r.inflight += 1
+        return r
+
+    def _release(self, r):
+        with self._pick:
+            r.inflight -= 1
+
+    @staticmethod
+    def _features(features):
+        a = features.array if isinstance(features, StorageView) else np.asarray(features)
+        if a.dtype != np.float32:
+            a = a.astype(np.float32)
+        a = np.ascontiguousarray(a)
+        if a.ndim != 3 or a.shape[1:] != (80, 3000):
+            raise ValueError(f"features must be [batch, 80, 3000] float32, got {a.shape}")
+        return a
+
+    def generate(self, features, prompts, *, asynchronous=False, beam_size=5, patience=1, num_hypotheses=1, length_penalty=1,
+                 repetition_penalty=1, no_repeat_ngram_size=0, max_length=448, return_scores=False, return_no_speech_prob=False,
+                 max_initial_timestamp_index=50, suppress_blank=True, suppress_tokens=(-1,), sampling_topk=1,
+                 sampling_temperature=1, fixed_new_tokens=0, input_kind=_lib.WIS_IN_MEL_HOST):
+        if num_hypotheses != 1 or repetition_penalty != 1 or no_repeat_ngram_size != 0 or sampling_topk != 1:
+            raise NotImplementedError("only the decoding options WIS uses are implemented (defaults of CTranslate2 4.1.0)")
+        mel = self._features(features)
+        B = mel.shape[0]
+        if len(prompts) != B:
+            raise ValueError("one prompt per batch item")
+        P = len(prompts[0])
+        if any(len(p) != P for p in prompts):
+            raise ValueError("all prompts must have the same length")
+        max_new = min(max_length // 2, max_length - P)
+        per_call = max(1, min(self.max_batch, 48 // max(beam_size, 1), 48 // max(P - 1, 1)))
+        results = []
+        r = self._acquire()
+        try:
+            with r.lock:
+                for s in range(0, B, per_call):
+                    e = min(B, s + per_call)
+                    results.extend(self._generate_chunk(r, mel[s:e], prompts[s:e], P, beam_size, max_new, float(length_penalty),
+                                                        float(patience), suppress_blank, list(suppress_tokens) == [-1],
+                                                        fixed_new_tokens, input_kind))
+        finally:
+            self._release(r)
+        return results
+
+    def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
+        B = mel.shape[0]
+        o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
+        pr = np.ascontiguousarray(np.asarray(prompts, np.int32).reshape(B, P))
+        ids = np.zeros((B, max_new), np.int32)
+        lens = np.zeros(B, np.int32)
+        scores = np.zeros(B, np.float32)
+        _lib.check(_lib.load().wis_generate(r.handle, _lib.ptr(mel), B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
+                                            ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            scores.ctypes.data_as(C.POINTER(C.c_float))))
+        return [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
+
+    def detect_language(self, features):
+        mel = self._features(features)
+        B = mel.shape[0]
+        n_lang = len(W.LANG_IDS)
+        out = []
+        r = self._acquire()
+        try:
+            with r.lock:
+                for s in range(0, B, self.max_batch):
+                    m = mel[s:s + self.max_batch]
+                    probs = np.zeros((m.shape[0], n_lang), np.float32)
+                    _lib.check(_lib.load().wis_detect_language(r.handle, _lib.ptr(m), _lib.WIS_IN_MEL_HOST, m.shape[0],
+                                                               probs.ctypes.data_as(C.POINTER(C.c_float))))
+                    for row in probs:
+                        order = np.argsort(-row, kind="stable")
+                        out.append([(f"<|{LANGUAGE_CODES[i]}|>", float(row[i])) for i in order])
+        finally:
+            self._release(r)
+        return out
+
+    def last_timing(self, replica=0):
+        t = _lib.Timing()
+        _lib.check(_lib.load().wis_last_timing(self._replicas[replica].handle, C.byref(t)))
+        return t.as_dict()
+
+
+class models:  # namespace shim: `ctranslate2.models.Whisper`
+    Whisper = Whisper

@@ -1,0 +1,195 @@
+"""Whisper weight sets for the wis_hip engine.
+
+The reference loads CTranslate2 model directories (`models/tovera-wis-whisper-*`, reference
+main.py:341-444, utils.sh:99-108).  No checkpoint exists offline, so this module provides
+  * the architecture table of the five sizes WIS serves (main.py:564-573),
+  * seeded synthetic weights at the TRUE shapes (N(0, 0.02^2) linears/convs/embeddings,
+    LayerNorm gamma 1 / beta 0) under the CTranslate2 WhisperSpec variable names,
+  * the flat arena + tensor index that `wis_model_create` consumes,
+  * a reader for a real CTranslate2 `model.bin` (format: SURVEY Appendix C) when one is mounted.
+The oracle (oracle/whisper_ref.py) consumes the same name -> array dict, so both sides see
+bit-identical (f16-rounded) weights.
+"""
+import json
+import os
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+# size -> (d_model, layers (enc = dec), heads); "large" is large-v2 (utils.sh:264-271)
+ARCH = {
+    "tiny": (384, 4, 6),
+    "base": (512, 6, 8),
+    "small": (768, 12, 12),
+    "medium": (1024, 24, 16),
+    "large": (1280, 32, 20),
+}
+N_VOCAB = 51865
+N_AUDIO_CTX = 1500
+N_TEXT_CTX = 448
+N_MELS = 80
+
+# special ids of the multilingual vocabulary
+EOT, SOT, TRANSLATE, TRANSCRIBE, NO_SPEECH, NO_TIMESTAMPS = 50257, 50258, 50358, 50359, 50362, 50363
+LANG_IDS = list(range(50259, 50358))
+# CT2 config.json:suppress_ids of the released multilingual checkpoints = the 86 non-speech ids
+# of the HF generation config + <|translate|> + <|transcribe|>
+SUPPRESS_IDS = [1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 359, 503, 522, 542, 873,
+                893, 902, 918, 922, 931, 1350, 1853, 1982, 2460, 2627, 3246, 3253, 3268, 3536, 3846, 3961, 4183, 4667, 6585,
+                6647, 7273, 9061, 9383, 10428, 10929, 11938, 12033, 12331, 12562, 13793, 14157, 14635, 15265, 15618, 16553,
+                16604, 18362, 18956, 20075, 21675, 22520, 26130, 26161, 26435, 28279, 29464, 31650, 32302, 32470, 36865,
+                42863, 47425, 49870, 50254, 50258, 50358, 50359, 50360, 50361, 50362]
+SUPPRESS_IDS_BEGIN = [220, EOT]
+
+
+def arch(size):
+    if size == "large-v2":
+        size = "large"
+    d, L, H = ARCH[size]
+    return dict(size=size, d_model=d, n_layers=L, n_heads=H, n_vocab=N_VOCAB, n_audio_ctx=N_AUDIO_CTX, n_text_ctx=N_TEXT_CTX, n_mels=N_MELS)
+
+
+def tensor_shapes(d, L, n_vocab=N_VOCAB, n_text_ctx=N_TEXT_CTX):
+    """name -> (shape, kind) in CTranslate2 WhisperSpec naming; kind in {w, b, g, beta, emb}."""
+    t = {}
+    t["encoder/conv1/weight"] = ((d, N_MELS, 3), "w")
+    t["encoder/conv1/bias"] = ((d,), "b")
+    t["encoder/conv2/weight"] = ((d, d, 3), "w")
+    t["encoder/conv2/bias"] = ((d,), "b")
+    for side, n in (("encoder", L), ("decoder", L)):
+        for l in range(n):
+            p = f"{side}/layer_{l}/"
+            t[p + "self_attention/layer_norm/gamma"] = ((d,), "g")
+            t[p + "self_attention/layer_norm/beta"] = ((d,), "beta")
+            t[p + "self_attention/linear_0/weight"] = ((3 * d, d), "w")
+            t[p + "self_attention/linear_0/bias"] = ((3 * d,), "bqkv")
+            t[p + "self_attention/linear_1/weight"] = ((d, d), "w")
+            t[p + "self_attention/linear_1/bias"] = ((d,), "b")
+            if side == "decoder":
+                t[p + "attention/layer_norm/gamma"] = ((d,), "g")
+                t[p + "attention/layer_norm/beta"] = ((d,), "beta")
+                t[p + "attention/linear_0/weight"] = ((d, d), "w")
+                t[p + "attention/linear_0/bias"] = ((d,), "b")
+                t[p + "attention/linear_1/weight"] = ((2 * d, d), "w")
+                t[p + "attention/linear_1/bias"] = ((2 * d,), "bkv")
+                t[p + "attention/linear_2/weight"] = ((d, d), "w")
+                t[p + "attention/linear_2/bias"] = ((d,), "b")
+            t[p + "ffn/layer_norm/gamma"] = ((d,), "g")
+            t[p + "ffn/layer_norm/beta"] = ((d,), "beta")
+            t[p + "ffn/linear_0/weight"] = ((4 * d, d), "w")
+            t[p + "ffn/linear_0/bias"] = ((4 * d,), "b")
+            t[p + "ffn/linear_1/weight"] = ((d, 4 * d), "w")
+            t[p + "ffn/linear_1/bias"] = ((d,), "b")
+        t[f"{side}/layer_norm/gamma"] = ((d,), "g")
+        t[f"{side}/layer_norm/beta"] = ((d,), "beta")
+    t["decoder/embeddings/weight"] = ((n_vocab, d), "emb")
+    t["decoder/position_encodings/encodings"] = ((n_text_ctx, d), "w")
+    return t
+
+
+def sinusoids(length=N_AUDIO_CTX, channels=1280):
+    """Whisper encoder positions, float32 like the HF / openai tables."""
+    inc = np.log(10000.0) / (channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2)).astype(np.float32)
+    t = np.arange(length, dtype=np.float32)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+
+
+def synthetic_weights(size, seed=1234, std=0.02, emb_std=None, ln_jitter=0.0, threads=8, n_vocab=N_VOCAB):
+    """Deterministic synthetic weights (f16) for `size`; each tensor has its own stream so generation order and
+    threading do not matter.  K-projection bias is zero (Whisper's k_proj has no bias)."""
+    a = arch(size)
+    d, L = a["d_model"], a["n_layers"]
+    shapes = tensor_shapes(d, L, n_vocab)
+    emb_std = std if emb_std is None else emb_std
+
+    def gen(item):
+        name, (shape, kind) = item
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+        if kind == "g":
+            v = np.ones(shape, np.float32)
+            if ln_jitter:
+                v += ln_jitter * rng.standard_normal(shape, dtype=np.float32)
+        elif kind == "beta":
+            v = np.zeros(shape, np.float32)
+            if ln_jitter:
+                v += ln_jitter * rng.standard_normal(shape, dtype=np.float32)
+        else:
+            v = rng.standard_normal(shape, dtype=np.float32)
+            v *= np.float32(emb_std if kind == "emb" else std)
+            if kind == "bqkv":
+                v[d:2 * d] = 0.0
+            elif kind == "bkv":
+                v[:d] = 0.0
+        return name, v.astype(np.float16)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        out = dict(ex.map(gen, shapes.items()))
+    return out
+
+
+def build_arena(weights):
+    """name -> ndarray (f16 / f32)  =>  (arena uint8 ndarray, index list of dicts)."""
+    index, off = [], 0
+    for name, v in weights.items():
+        assert v.dtype in (np.float16, np.float32), (name, v.dtype)
+        off = (off + 255) & ~255
+        index.append(dict(name=name, dtype="f16" if v.dtype == np.float16 else "f32", shape=list(v.shape), offset=off))
+        off += v.nbytes
+    arena = np.zeros(off, np.uint8)
+    for e in index:
+        v = np.ascontiguousarray(weights[e["name"]])
+        arena[e["offset"]:e["offset"] + v.nbytes] = v.view(np.uint8).reshape(-1)
+    return arena, index
+
+
+def read_ct2_model_bin(path):
+    """Reader for a CTranslate2 `model.bin` (binary version 6, WhisperSpec; layout per SURVEY Appendix C — written from
+    recall of CTranslate2 4.1.0, unverified offline).  Returns name -> ndarray.  int8 variables are rejected: WIS's models
+    were exported with --quantization float16 (utils.sh:71,104)."""
+    dtypes = {0: np.float32, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.float16}
+    out, aliases = {}, {}
+    with open(path, "rb") as f:
+        def rd(fmt):
+            return struct.unpack("<" + fmt, f.read(struct.calcsize("<" + fmt)))
+
+        def rstr():
+            (n,) = rd("H")
+            return f.read(n)[:-1].decode()
+
+        (ver,) = rd("I")
+        spec = rstr()
+        (rev,) = rd("I")
+        if "Whisper" not in spec:
+            raise ValueError(f"{path}: spec {spec!r} is not a Whisper model")
+        (nvar,) = rd("I")
+        for _ in range(nvar):
+            name = rstr()
+            (rank,) = rd("B")
+            dims = rd("I" * rank)
+            (dt,) = rd("B")
+            (nb,) = rd("I")
+            raw = f.read(nb)
+            if dt not in dtypes or dtypes[dt] in (np.int8, np.int16):
+                raise ValueError(f"{name}: quantised dtype id {dt} not supported (need float16/float32 export)")
+            out[name] = np.frombuffer(raw, dtype=dtypes[dt]).reshape(dims).copy()
+        (nal,) = rd("I")
+        for _ in range(nal):
+            al = rstr()
+            aliases[al] = rstr()
+    for al, tgt in aliases.items():
+        out.setdefault(al, out[tgt])
+    return out
+
+
+def load_model_dir(path):
+    """A CTranslate2 Whisper model directory -> (weights dict, config dict with suppress_ids / lang_ids)."""
+    w = read_ct2_model_bin(os.path.join(path, "model.bin"))
+    cfg = {}
+    cj = os.path.join(path, "config.json")
+    if os.path.exists(cj):
+        with open(cj) as f:
+            cfg = json.load(f)
+    return w, cfg
