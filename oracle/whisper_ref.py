@@ -30,8 +30,9 @@ def _t(w, name):
 class WhisperRef:
     """weights: name -> ndarray in CTranslate2 WhisperSpec naming (wis_hip.weights)."""
 
-    def __init__(self, weights, d_model, n_layers, n_heads, n_vocab=51865, n_text_ctx=448, enc_pos=None):
+    def __init__(self, weights, d_model, n_layers, n_heads, n_vocab=51865, n_text_ctx=448, enc_pos=None, eot=EOT, sot=SOT):
         self.d, self.L, self.H, self.V, self.ctx = d_model, n_layers, n_heads, n_vocab, n_text_ctx
+        self.eot, self.sot = eot, sot
         self.w = {k: _t(weights, k) for k in weights}
         if enc_pos is None and "encoder/position_encodings/encodings" in self.w:
             enc_pos = self.w["encoder/position_encodings/encodings"].numpy()
@@ -100,9 +101,46 @@ class WhisperRef:
         x = self._ln(x, "decoder/layer_norm")
         return x @ self.w["decoder/embeddings/weight"].t()
 
+    # ---- decoder: incremental form (self-attention KV cache, cross K/V projected once and shared by the beams) ----
+    @torch.no_grad()
+    def cross_kv(self, memory):
+        """memory [1500, d] -> per decoder layer (K, V) [1, 1500, d]; CT2 computes these once per utterance and does
+        not replicate them per beam."""
+        memory = torch.as_tensor(np.asarray(memory, np.float32))[None]
+        out = []
+        for l in range(self.L):
+            k, v = self._lin(memory, f"decoder/layer_{l}/attention/linear_1").split(self.d, dim=-1)
+            out.append((k, v))
+        return out
+
+    @torch.no_grad()
+    def decoder_step(self, tok, t0, cache, ckv):
+        """tok [N, Tn] tokens at positions t0..t0+Tn-1; cache = per-layer (K, V) [N, t0, d] or None (updated in place);
+        returns logits of the LAST fed position [N, V]."""
+        tok = torch.as_tensor(np.asarray(tok, np.int64))
+        N, Tn = tok.shape
+        x = self.w["decoder/embeddings/weight"][tok] + self.w["decoder/position_encodings/encodings"][t0:t0 + Tn]
+        mask = torch.full((Tn, t0 + Tn), float("-inf")).triu(t0 + 1) if Tn > 1 else None
+        for l in range(self.L):
+            p = f"decoder/layer_{l}/"
+            h = self._ln(x, p + "self_attention/layer_norm")
+            q, k, v = self._lin(h, p + "self_attention/linear_0").split(self.d, dim=-1)
+            if cache[l] is not None:
+                k, v = torch.cat([cache[l][0], k], dim=1), torch.cat([cache[l][1], v], dim=1)
+            cache[l] = (k, v)
+            x = x + self._lin(self._mha(q, k, v, mask), p + "self_attention/linear_1")
+            h = self._ln(x, p + "attention/layer_norm")
+            q = self._lin(h, p + "attention/linear_0")
+            ck, cv = ckv[l]
+            x = x + self._lin(self._mha(q, ck.expand(N, -1, -1), cv.expand(N, -1, -1)), p + "attention/linear_2")
+            h = self._ln(x, p + "ffn/layer_norm")
+            x = x + self._lin(F.gelu(self._lin(h, p + "ffn/linear_0")), p + "ffn/linear_1")
+        x = self._ln(x[:, -1], "decoder/layer_norm")
+        return x @ self.w["decoder/embeddings/weight"].t()
+
     # ---- logits processors (SURVEY §8 row a11) -----------------------------------------------
     @staticmethod
-    def apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank=True, fixed_new=0):
+    def apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank=True, fixed_new=0, eot=EOT):
         """logits [rows, V] float tensor (modified copy).  `fixed_new` is the measurement convention of SURVEY §8d
         (EOT masked until `fixed_new` tokens exist, then forced); 0 = off."""
         lg = logits.clone()
@@ -112,11 +150,11 @@ class WhisperRef:
             lg[:, list(suppress_begin)] = float("-inf")
         if fixed_new > 0:
             if step < fixed_new:
-                lg[:, EOT] = float("-inf")
+                lg[:, eot] = float("-inf")
             else:
-                keep = lg[:, EOT].clone()
+                keep = lg[:, eot].clone()
                 lg[:] = float("-inf")
-                lg[:, EOT] = keep
+                lg[:, eot] = keep
         return lg
 
     # ---- search: CTranslate2 BeamSearch::search (beam_size 1 degenerates to GreedySearch) ------
@@ -147,10 +185,15 @@ class WhisperRef:
         cum = [0.0] + [float("-inf")] * (k - 1)           # GPU path: beams tiled up front
         hyps = []                                         # (raw_score, tokens)
         trace = []
-        mem_k = memory[None].expand(k, -1, -1)
+        ckv = self.cross_kv(memory)
+        cache = [None] * self.L
+        if P > 1:                                         # prime the self-attention cache with prompt[:-1]
+            self.decoder_step(np.asarray([prompt[:-1]]), 0, cache, ckv)
+            cache = [(kk.expand(k, -1, -1).contiguous(), vv.expand(k, -1, -1).contiguous()) for kk, vv in cache]
+        last = [prompt[-1]] * k
         for step in range(max_new):
-            logits = self.decode_logits(np.asarray(seqs), mem_k)[:, -1, :].float()
-            logits = self.apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank, fixed_new)
+            logits = self.decoder_step(np.asarray(last)[:, None], P - 1 + step, cache, ckv).float()
+            logits = self.apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank, fixed_new, self.eot)
             logp = torch.log_softmax(logits, dim=-1)
             flat = (logp + torch.tensor(cum, dtype=torch.float32)[:, None]).reshape(-1)
             # top-ncand, ties by lower flat index: stable sort on (-value)
@@ -164,14 +207,14 @@ class WhisperRef:
             nxt, second, top_finished = [], k, False
             for kk in range(k):
                 choice = kk
-                eos = cand_word[kk] == EOT
+                eos = cand_word[kk] == self.eot
                 if eos or is_last:
                     if kk == 0:
                         top_finished = True
                     gen = seqs[cand_org[kk]][P:] + ([] if eos else [cand_word[kk]])
                     hyps.append((cand_score[kk], gen))
                     for j in range(second, ncand):
-                        if cand_word[j] != EOT:
+                        if cand_word[j] != self.eot:
                             choice, second = j, j + 1
                             break
                 nxt.append(choice)
@@ -180,6 +223,9 @@ class WhisperRef:
                 break
             seqs = [seqs[cand_org[c]] + [cand_word[c]] for c in nxt]
             cum = [cand_score[c] for c in nxt]
+            last = [cand_word[c] for c in nxt]
+            origin = torch.tensor([cand_org[c] for c in nxt])
+            cache = [(kk[origin], vv[origin]) for kk, vv in cache]     # CT2 gathers the self-attention state by beam origin
 
         def norm(h):
             s, toks = h
@@ -192,5 +238,5 @@ class WhisperRef:
     def detect_language(self, mel, lang_ids):
         """CT2 Whisper::detect_language: one decoder step on [sot], softmax restricted to the language tokens."""
         memory = self.encode(np.asarray(mel, np.float32)[None])
-        lg = self.decode_logits(np.array([[SOT]]), memory)[0, -1]
+        lg = self.decode_logits(np.array([[self.sot]]), memory)[0, -1]
         return torch.softmax(lg[list(lang_ids)], dim=-1).numpy()

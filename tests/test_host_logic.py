@@ -1,0 +1,154 @@
+"""not gpu: the host side of the boundary — the C-ABI library loads and exports every symbol include/wis_hip.h
+declares, container decode (FLAC MD5 known-answer tests), the wis.audio-compatible host logic, the weight
+arena, and loud failure without a GPU."""
+import hashlib
+import io
+import json
+import os
+import re
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    from wis_hip import _lib
+    hdr = open(os.path.join(ROOT, "include", "wis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wis_[a-z0-9_]+)\s*\(", hdr))
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.wis_version() == 1
+
+
+@pytest.mark.parametrize("clip,md5,n", [("3sec", "ad790df21d4d9d223d3f34227b5cfedd", 61440),
+                                        ("10sec", "c5b99673d012d9a8f5d19dd68874a121", 171008),
+                                        ("30sec", "3a541ad6463fe6e884e5995212b518fa", 467968)])
+def test_flac_decode_known_answer(golden_dir, clip, md5, n):
+    """STREAMINFO MD5 of the decoded PCM = the reference clips' signature."""
+    from wis_hip import audio
+    pcm, sr = audio.load_audio(os.path.join(golden_dir, "clips", clip + ".flac"))
+    assert sr == 16000 and pcm.shape == (n,) and pcm.dtype == np.float32
+    i16 = np.round(pcm * 32768.0).astype("<i2")
+    assert hashlib.md5(i16.tobytes()).hexdigest() == md5
+    meta = json.load(open(os.path.join(golden_dir, "chunker_lcs.json")))["clips"][clip]
+    assert i16[:8].tolist() == meta["first8"]
+    # file-like and bytes inputs (reference hands do_whisper a BytesIO, main.py:1297-1310)
+    raw = open(os.path.join(golden_dir, "clips", clip + ".flac"), "rb").read()
+    assert np.array_equal(audio.load_audio(io.BytesIO(raw))[0], pcm)
+    assert np.array_equal(audio.load_audio(raw)[0], pcm)
+
+
+def test_flac_corruption_is_detected(golden_dir):
+    from wis_hip import _lib, audio
+    raw = bytearray(open(os.path.join(golden_dir, "clips", "3sec.flac"), "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    with pytest.raises(_lib.WisError):
+        audio.load_audio(bytes(raw))
+    with pytest.raises(_lib.WisError):
+        audio.load_audio(b"not audio at all")
+
+
+def test_wav_decode_roundtrip():
+    """PCM-in-WAV as write_stream_wav produces it (reference main.py:98-105): mono / stereo, 16-bit."""
+    from wis_hip import audio
+    rng = np.random.default_rng(0)
+    x = rng.integers(-20000, 20000, size=(1600, 2)).astype("<i2")
+    for ch in (1, 2):
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as w:
+            w.setnchannels(ch); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(x[:, :ch].tobytes())
+        pcm, sr = audio.load_audio(buf.getvalue())
+        exp = (x[:, :ch].astype(np.float32) / 32768.0).mean(axis=1)
+        assert sr == 16000 and np.allclose(pcm, exp, atol=1e-7)
+    with pytest.raises(ValueError):
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000); w.writeframes(b"\0\0" * 80)
+        audio.load_audio(buf.getvalue())
+
+
+def test_audio_host_logic_matches_reference_golden(golden_dir):
+    from wis_hip import audio
+    cases = json.load(open(os.path.join(golden_dir, "chunker_lcs.json")))
+    for n, strides in cases["chunk_iter"].items():
+        assert [list(s) for _, s in audio.chunk_iter(np.zeros(int(n), np.float32))] == strides
+
+    class Tok:
+        all_special_ids = cases["lcs"][0]["special"]
+    for c in cases["lcs"]:
+        if isinstance(c["out"], str):
+            continue
+        seqs = [(s, (1, 0, 0)) for s in c["seqs"]]
+        assert audio.find_longest_common_sequence(seqs, Tok).tolist() == c["out"]
+    x = np.arange(5, dtype=np.float32)
+    assert audio.pad_or_trim(x, 3).tolist() == [0, 1, 2] and audio.pad_or_trim(x, 7).shape == (7,)
+    assert audio.N_SAMPLES == 480000 and audio.N_FRAMES == 3000 and audio.chunk_len == 352000
+
+
+def test_weight_arena_and_layout():
+    from wis_hip import weights as W
+    w = W.synthetic_weights("tiny", seed=7)
+    w2 = W.synthetic_weights("tiny", seed=7, threads=1)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)                  # thread-count independent
+    arena, index = W.build_arena(w)
+    idx2, total = W.synthetic_layout("tiny")
+    assert idx2 == index and total == arena.nbytes
+    e = next(i for i in index if i["name"] == "decoder/layer_3/attention/linear_1/bias")
+    v = arena[e["offset"]:e["offset"] + 2 * 768].view(np.float16)
+    assert np.array_equal(v, w[e["name"]]) and not v[:384].any()        # k_proj has no bias
+    a = W.arch("large")
+    n = sum(int(np.prod(s)) for s, _ in W.tensor_shapes(a["d_model"], a["n_layers"]).values())
+    assert abs(n / 1e6 - 1543.3) < 1.0                                   # large-v2: 1540.8 M params + both position tables
+    assert len(W.SUPPRESS_IDS) == 88 and W.SUPPRESS_IDS_BEGIN == [220, 50257] and len(W.LANG_IDS) == 99
+
+
+def test_ct2_model_bin_reader_roundtrip(tmp_path):
+    """model.bin layout per SURVEY Appendix C (binary version 6)."""
+    from wis_hip import weights as W
+
+    def wstr(f, s):
+        b = s.encode() + b"\0"
+        f.write(struct.pack("<H", len(b))); f.write(b)
+    vars_ = {"encoder/conv1/bias": np.arange(4, dtype=np.float16), "decoder/embeddings/weight": np.ones((3, 2), np.float32)}
+    p = tmp_path / "model.bin"
+    with open(p, "wb") as f:
+        f.write(struct.pack("<I", 6)); wstr(f, "WhisperSpec"); f.write(struct.pack("<I", 3)); f.write(struct.pack("<I", len(vars_)))
+        for name, v in vars_.items():
+            wstr(f, name); f.write(struct.pack("<B", v.ndim)); f.write(struct.pack("<" + "I" * v.ndim, *v.shape))
+            f.write(struct.pack("<B", 4 if v.dtype == np.float16 else 0)); f.write(struct.pack("<I", v.nbytes)); f.write(v.tobytes())
+        f.write(struct.pack("<I", 1)); wstr(f, "decoder/projection/weight"); wstr(f, "decoder/embeddings/weight")
+    out = W.read_ct2_model_bin(str(p))
+    assert np.array_equal(out["encoder/conv1/bias"], vars_["encoder/conv1/bias"])
+    assert np.array_equal(out["decoder/projection/weight"], vars_["decoder/embeddings/weight"])
+
+
+def test_product_path_fails_loudly_without_gpu(lib):
+    """No CPU fallback: compute entry points must raise when no HIP device is visible."""
+    from wis_hip import _lib, audio, ctranslate2 as ct2
+    if lib.wis_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.WisError):
+        audio.log_mel_spectrogram(np.zeros(480000, np.float32))
+    with pytest.raises(_lib.WisError):
+        ct2.Whisper("synthetic:tiny")
+    with pytest.raises(ValueError):
+        ct2.Whisper("synthetic:tiny", device="cpu")
+
+
+def test_no_oracle_import_in_product_code():
+    """The product package must never import the oracle (or the reference)."""
+    pkg = os.path.join(ROOT, "willow-inference-server_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".c", ".h")):
+                src = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+                assert "/root/reference" not in src, fn

@@ -1,0 +1,146 @@
+"""not gpu: the CT2-path oracle (oracle/whisper_ref.py).  Its forward math is cross-checked against the independent
+HF implementation (transformers.models.whisper.modeling_whisper); its search is checked on
+properties of CTranslate2's beam search that do not need the (unavailable) wheel: beam 1 == greedy argmax chain,
+wider beams never score worse, the measurement convention yields exactly S tokens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.whisper_ref import EOT, WhisperRef
+
+
+def small_weights(d=128, L=2, n_vocab=2000, seed=0, std=0.05):
+    from wis_hip import weights as W
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, (shape, kind) in W.tensor_shapes(d, L, n_vocab).items():
+        if kind == "pos":
+            out[name] = W.sinusoids(shape[0], shape[1])
+            continue
+        if kind == "g":
+            v = 1 + 0.1 * rng.standard_normal(shape)
+        elif kind == "beta":
+            v = 0.1 * rng.standard_normal(shape)
+        else:
+            v = std * rng.standard_normal(shape)
+            if kind == "bqkv":
+                v[d:2 * d] = 0
+            elif kind == "bkv":
+                v[:d] = 0
+        out[name] = v.astype(np.float16)
+    return out
+
+
+def to_hf(w, d, L, H, n_vocab):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = WhisperConfig(vocab_size=n_vocab, d_model=d, encoder_layers=L, decoder_layers=L, encoder_attention_heads=H,
+                        decoder_attention_heads=H, encoder_ffn_dim=4 * d, decoder_ffn_dim=4 * d, num_mel_bins=80,
+                        max_source_positions=1500, max_target_positions=448, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=1, suppress_tokens=None, begin_suppress_tokens=None)
+    m = WhisperForConditionalGeneration(cfg).eval().float()
+    t = lambda n: torch.from_numpy(np.asarray(w[n], np.float32))
+    sd = {}
+    sd["model.encoder.conv1.weight"], sd["model.encoder.conv1.bias"] = t("encoder/conv1/weight"), t("encoder/conv1/bias")
+    sd["model.encoder.conv2.weight"], sd["model.encoder.conv2.bias"] = t("encoder/conv2/weight"), t("encoder/conv2/bias")
+    for side, hf in (("encoder", "model.encoder"), ("decoder", "model.decoder")):
+        for l in range(L):
+            p, q = f"{side}/layer_{l}/", f"{hf}.layers.{l}."
+            qkv_w, qkv_b = t(p + "self_attention/linear_0/weight"), t(p + "self_attention/linear_0/bias")
+            for i, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                sd[q + f"self_attn.{nm}.weight"] = qkv_w[i * d:(i + 1) * d]
+                if nm != "k_proj":
+                    sd[q + f"self_attn.{nm}.bias"] = qkv_b[i * d:(i + 1) * d]
+            sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"] = t(p + "self_attention/linear_1/weight"), t(p + "self_attention/linear_1/bias")
+            sd[q + "self_attn_layer_norm.weight"], sd[q + "self_attn_layer_norm.bias"] = t(p + "self_attention/layer_norm/gamma"), t(p + "self_attention/layer_norm/beta")
+            if side == "decoder":
+                sd[q + "encoder_attn.q_proj.weight"], sd[q + "encoder_attn.q_proj.bias"] = t(p + "attention/linear_0/weight"), t(p + "attention/linear_0/bias")
+                kv_w, kv_b = t(p + "attention/linear_1/weight"), t(p + "attention/linear_1/bias")
+                sd[q + "encoder_attn.k_proj.weight"] = kv_w[:d]
+                sd[q + "encoder_attn.v_proj.weight"], sd[q + "encoder_attn.v_proj.bias"] = kv_w[d:], kv_b[d:]
+                sd[q + "encoder_attn.out_proj.weight"], sd[q + "encoder_attn.out_proj.bias"] = t(p + "attention/linear_2/weight"), t(p + "attention/linear_2/bias")
+                sd[q + "encoder_attn_layer_norm.weight"], sd[q + "encoder_attn_layer_norm.bias"] = t(p + "attention/layer_norm/gamma"), t(p + "attention/layer_norm/beta")
+            sd[q + "fc1.weight"], sd[q + "fc1.bias"] = t(p + "ffn/linear_0/weight"), t(p + "ffn/linear_0/bias")
+            sd[q + "fc2.weight"], sd[q + "fc2.bias"] = t(p + "ffn/linear_1/weight"), t(p + "ffn/linear_1/bias")
+            sd[q + "final_layer_norm.weight"], sd[q + "final_layer_norm.bias"] = t(p + "ffn/layer_norm/gamma"), t(p + "ffn/layer_norm/beta")
+        sd[f"{hf}.layer_norm.weight"], sd[f"{hf}.layer_norm.bias"] = t(f"{side}/layer_norm/gamma"), t(f"{side}/layer_norm/beta")
+    sd["model.decoder.embed_tokens.weight"] = t("decoder/embeddings/weight")
+    sd["model.decoder.embed_positions.weight"] = t("decoder/position_encodings/encodings")
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    # only tensors the oracle derives itself may be absent from our dict: k_proj biases do not exist; encoder positions are sinusoids
+    assert all("embed_positions" in k for k in missing), missing
+    assert not unexpected, unexpected
+    return m
+
+
+@pytest.fixture(scope="module")
+def setup():
+    d, L, H, V = 128, 2, 2, 2000
+    w = small_weights(d, L, V)
+    ref = WhisperRef(w, d, L, H, n_vocab=V, eot=2, sot=1)
+    rng = np.random.default_rng(1)
+    mel = (0.5 * rng.standard_normal((2, 80, 3000))).astype(np.float32)
+    return d, L, H, V, w, ref, mel
+
+
+def test_forward_matches_hf(setup):
+    d, L, H, V, w, ref, mel = setup
+    hf = to_hf(w, d, L, H, V)
+    with torch.no_grad():
+        enc_hf = hf.model.encoder(torch.from_numpy(mel)).last_hidden_state
+        enc = ref.encode(mel)
+        assert (enc - enc_hf).abs().max() < 2e-4
+        toks = np.array([[1, 5, 9, 700, 33], [1, 8, 1999, 4, 77]])
+        lg_hf = hf(input_features=torch.from_numpy(mel), decoder_input_ids=torch.from_numpy(toks)).logits
+        lg = ref.decode_logits(toks, enc)
+        assert (lg - lg_hf).abs().max() < 1e-3
+    # the sinusoid table the oracle derives equals HF's fixed encoder positions
+    # (f32 evaluation of sin/cos at arguments up to 1500 differs by ~1 ulp of the argument between implementations)
+    assert (ref.enc_pos - hf.model.encoder.embed_positions.weight.detach()).abs().max() < 1.5e-4
+
+
+def test_greedy_is_argmax_chain(setup):
+    d, L, H, V, w, ref, mel = setup
+    prompt = [1, 5, 9, 11]
+    ids, score = ref.generate(mel[0], prompt, beam_size=1, max_new_tokens=6, suppress_ids=[3, 4], suppress_begin=[7])
+    mem = ref.encode(mel[:1])
+    seq, lp = list(prompt), 0.0
+    for step in range(6):
+        lg = ref.decode_logits(np.array([seq]), mem)[0, -1].clone()
+        lg[[3, 4]] = float("-inf")
+        if step == 0:
+            lg[7] = float("-inf")
+        tok = int(lg.argmax())
+        lp += float(torch.log_softmax(lg, -1)[tok])
+        seq.append(tok)
+        if tok == 2:
+            break
+    assert ids == seq[len(prompt):]
+    assert abs(score - lp / len(ids)) < 1e-4            # length_penalty 1: mean log-prob
+
+
+def test_beam_search_properties(setup):
+    d, L, H, V, w, ref, mel = setup
+    prompt = [1, 5, 9, 11]
+    kw = dict(suppress_ids=[3, 4], suppress_begin=[7])
+    # measurement convention: exactly S tokens, EOT never inside
+    for beam in (1, 3, 5):
+        ids, score = ref.generate(mel[1], prompt, beam_size=beam, fixed_new=7, **kw)
+        assert len(ids) == 7 and 2 not in ids
+    # with a fixed length every hypothesis has the same length, so a wider beam can only find a better (or equal) score
+    s1 = ref.generate(mel[1], prompt, beam_size=1, fixed_new=7, **kw)[1]
+    s5 = ref.generate(mel[1], prompt, beam_size=5, fixed_new=7, **kw)[1]
+    assert s5 >= s1 - 1e-5
+    # max-length termination: at most max_new tokens
+    ids, _ = ref.generate(mel[0], prompt, beam_size=4, max_new_tokens=5, **kw)
+    assert 1 <= len(ids) <= 5
+
+
+def test_logits_processors():
+    lg = torch.zeros(2, 51865)
+    out = WhisperRef.apply_processors(lg, 0, [1, 2], [220, EOT], True, 0)
+    assert torch.isinf(out[:, [1, 2, 220, EOT]]).all() and torch.isfinite(out[:, 5]).all()
+    out = WhisperRef.apply_processors(lg, 1, [1, 2], [220, EOT], True, 0)
+    assert torch.isfinite(out[:, [220, EOT]]).all()
+    out = WhisperRef.apply_processors(lg, 3, [], [220], True, 3)
+    assert torch.isfinite(out[:, EOT]).all() and torch.isinf(out[:, 0]).all()

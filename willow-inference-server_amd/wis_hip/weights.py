@@ -58,6 +58,7 @@ def tensor_shapes(d, L, n_vocab=N_VOCAB, n_text_ctx=N_TEXT_CTX):
     t["encoder/conv1/bias"] = ((d,), "b")
     t["encoder/conv2/weight"] = ((d, d, 3), "w")
     t["encoder/conv2/bias"] = ((d,), "b")
+    t["encoder/position_encodings/encodings"] = ((N_AUDIO_CTX, d), "pos")     # fixed sinusoids, float32
     for side, n in (("encoder", L), ("decoder", L)):
         for l in range(n):
             p = f"{side}/layer_{l}/"
@@ -108,6 +109,8 @@ def synthetic_weights(size, seed=1234, std=0.02, emb_std=None, ln_jitter=0.0, th
     def gen(item):
         name, (shape, kind) = item
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+        if kind == "pos":
+            return name, sinusoids(shape[0], shape[1])
         if kind == "g":
             v = np.ones(shape, np.float32)
             if ln_jitter:
@@ -130,15 +133,29 @@ def synthetic_weights(size, seed=1234, std=0.02, emb_std=None, ln_jitter=0.0, th
     return out
 
 
+def arena_layout(shapes_dtypes):
+    """[(name, shape, numpy dtype)] -> (index list of dicts, total bytes).  Depends on shapes only, so every rank of a
+    multi-GPU job can compute it without holding the data (the arena itself arrives by RCCL broadcast)."""
+    index, off = [], 0
+    for name, shape, dt in shapes_dtypes:
+        dt = np.dtype(dt)
+        assert dt in (np.dtype(np.float16), np.dtype(np.float32)), (name, dt)
+        off = (off + 255) & ~255
+        index.append(dict(name=name, dtype="f16" if dt == np.float16 else "f32", shape=[int(x) for x in shape], offset=off))
+        off += int(np.prod(shape)) * dt.itemsize
+    return index, off
+
+
+def synthetic_layout(size, n_vocab=N_VOCAB):
+    a = arch(size)
+    shapes = tensor_shapes(a["d_model"], a["n_layers"], n_vocab)
+    return arena_layout([(n, s, np.float32 if k == "pos" else np.float16) for n, (s, k) in shapes.items()])
+
+
 def build_arena(weights):
     """name -> ndarray (f16 / f32)  =>  (arena uint8 ndarray, index list of dicts)."""
-    index, off = [], 0
-    for name, v in weights.items():
-        assert v.dtype in (np.float16, np.float32), (name, v.dtype)
-        off = (off + 255) & ~255
-        index.append(dict(name=name, dtype="f16" if v.dtype == np.float16 else "f32", shape=list(v.shape), offset=off))
-        off += v.nbytes
-    arena = np.zeros(off, np.uint8)
+    index, total = arena_layout([(n, v.shape, v.dtype) for n, v in weights.items()])
+    arena = np.zeros(total, np.uint8)
     for e in index:
         v = np.ascontiguousarray(weights[e["name"]])
         arena[e["offset"]:e["offset"] + v.nbytes] = v.view(np.uint8).reshape(-1)
