@@ -148,6 +148,10 @@ typedef struct {
 } wis_timing_t;
 int wis_last_timing(const wis_model_t* m, wis_timing_t* t);
 
+/* ---- tuning tap: shader-clock stamps of the phases of decoder layer 0's kernels for one decode forward at
+ * text position `pos` (out: [6][16] uint64: QKV gemv, out-proj gemv, cross-attn, self-attn, FFN1 gemv, FFN2 gemv) */
+int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* out);
+
 /* ---- roofline tap (bench.py): launch the decoder's weight-streaming skinny-GEMM kernel once over
  * EVERY decoder weight matrix of the model (6 per layer + the vocabulary projection = the weight
  * stream of one decode step, >> the 256 MiB Infinity Cache for the large sizes), `passes` times,

@@ -1,0 +1,25 @@
+"""Tuning aid: print the phase stamps (shader clock cycles) of decoder layer 0's kernels for large-v2, beam 5."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "willow-inference-server_amd"))
+from wis_hip import _lib, ctranslate2 as ct2, weights as W
+
+size = sys.argv[1] if len(sys.argv) > 1 else "large"
+lib = _lib.load()
+a = W.arch(size)
+w = W.synthetic_weights(size)
+arena, index = W.build_arena(w)
+h = ct2.create_handle(a, arena, index, 0, max_batch=1, max_beam=5)
+out = np.zeros((6, 16), np.uint64)
+names = ["gemv QKV (LN)", "gemv out-proj", "cross-attn", "self-attn", "gemv FFN1 (LN)", "gemv FFN2"]
+for pos in (10,):
+    _lib.check(lib.wis_debug_phase_cycles(h, 1, 5, pos, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    for i, n in enumerate(names):
+        st = [int(v) for v in out[i] if v]
+        if st:
+            print(f"{n:16s} pos {pos}: total {st[-1] - st[0]:6d} cyc; phases {[st[j + 1] - st[j] for j in range(len(st) - 1)]}")

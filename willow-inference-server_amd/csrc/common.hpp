@@ -39,15 +39,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device-side helpers ---------------------------------------------------------------
+// 64-lane reductions: four DPP steps inside each 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror)
+// then the four row totals are combined through v_readlane -> a wave-uniform result in ~12 instructions,
+// instead of six dependent ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
+  const float a = readlane_f(v, 0), b = readlane_f(v, 16), c = readlane_f(v, 32), d = readlane_f(v, 48);
+  return (a + b) + (c + d);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const float a = readlane_f(v, 0), b = readlane_f(v, 16), c = readlane_f(v, 32), d = readlane_f(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+// shader-clock stamp for the optional phase profiler (wis_debug_phase_cycles)
+__device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
+  if (prof) prof[i] = __builtin_amdgcn_s_memtime();
 }
 // exact (erf) GELU, as torch.nn.functional.gelu default / CT2 GELU
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -56,9 +56,17 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 }
 
 // =======================================================================================
-// Skinny GEMM.  grid = Npad/16 workgroups of 4 waves; wave w streams k-steps of its quarter of
-// every staged K-chunk.  Dynamic LDS: xs f16 [M][KC+8] | red f32 [4][MB][64][4] | stats f32 [48][2]
-template <int MB>
+// Skinny GEMM.  grid = Npad/16 workgroups of 4 waves; wave w streams the k-steps of its quarter of
+// every staged K-chunk.  Dynamic LDS: xs f16 [M][KC+8] | red f32 [4][MB][64][4] | stats f32 [48][2] | sred f32 [4][8]
+//
+// Memory-latency structure (one dependent round trip): the activation loads (L2-hot, written by the
+// previous kernel) are issued FIRST, then a 16-deep prefetch of this wave's weight fragments (HBM);
+// vmcnt retires in order, so LayerNorm statistics and the f16 staging of x run from registers while
+// the weight stream is in flight, and the MFMAs consume the fragments as they land, refilling the ring.
+constexpr int GV_PF = 16;   // weight fragments in flight per wave (16 KiB)
+
+// MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
+template <int MB, int MODE>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = p.M, K = p.K;
@@ -66,19 +74,117 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   f16* xs = reinterpret_cast<f16*>(smem);
   float* red = reinterpret_cast<float*>(smem + (((size_t)M * xstr * 2 + 15) & ~(size_t)15));
   float* stats = red + 4 * MB * 64 * 4;
+  float* sred = stats + 2 * MAX_ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = blockIdx.x;
   const int ksteps = K / 32;
+  const int S = KC / 128;                        // k-steps per wave per chunk
+  const int ksl0 = wave * S;                     // first chunk-local k-step of this wave
+  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)nt * ksteps * 64 + lane;
+  const int k4n = K >> 2;                        // float4 per row
+  const bool ln = p.flags & GV_LN;
+  // fast LayerNorm path (host-selected, M <= 8, K <= 2048): the whole M x K activation lives in registers; thread
+  // owns float4 columns k4 = tid, tid + 256 of every row (no index arithmetic), statistics are a single shifted pass
+  // (c = x[r][0]: var = E[(x-c)^2] - E[x-c]^2) so the block needs ONE reduction + barrier before staging.
+  constexpr bool fast = MODE == 1;
+  constexpr int RMAX = fast ? 8 : 1;
+  float4 xv[RMAX][2], gv[2], bv[2];
+  float cshift[RMAX];
+  unsigned long long* pf = (blockIdx.x == 0 && tid == 0) ? p.prof : nullptr;
+  stamp(pf, 0);
+  if (fast) {
+    const float4* x4 = reinterpret_cast<const float4*>(p.x);
+    const float4* g4 = reinterpret_cast<const float4*>(p.gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(p.beta);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k4 = tid + 256 * j;
+      if (k4 < k4n) {
+        gv[j] = g4[k4]; bv[j] = b4[k4];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) if (r < M) xv[r][j] = x4[(size_t)r * k4n + k4];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) cshift[r] = (r < M) ? reinterpret_cast<const float*>(p.x)[(size_t)r * K] : 0.f;
+  }
+  // f16 activations (attention / FFN hidden output of the previous kernel): same idea, up to 13 x 16 B per thread
+  constexpr bool fastx = MODE == 2;
+  constexpr int NXH = fastx ? 13 : 1;
+  u32x4 xh[NXH];
+  if (fastx) {
+    const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
+#pragma unroll
+    for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < M * (K >> 3)) xh[i] = x8[idx]; }
+  }
+  // weight prefetch for chunk 0 (independent of x)
+  u32x4 wf[GV_PF];
+  {
+    const u32x4* wq = wp4 + (size_t)ksl0 * 64;
+#pragma unroll
+    for (int u = 0; u < GV_PF; ++u) if (u < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * 64);
+  }
 
-  if (p.flags & GV_LN) {
+  stamp(pf, 1);
+  if (fast) {
+    float sa[RMAX], sb[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      sa[r] = 0.f; sb[r] = 0.f;
+      if (r < M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (tid + 256 * j < k4n) {
+            const float a = xv[r][j].x - cshift[r], b = xv[r][j].y - cshift[r], c = xv[r][j].z - cshift[r], e = xv[r][j].w - cshift[r];
+            sa[r] += (a + b) + (c + e); sb[r] += (a * a + b * b) + (c * c + e * e);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      if (r < M) {
+        const float ta = wave_sum(sa[r]), tb = wave_sum(sb[r]);
+        if (lane == 0) { sred[wave * 16 + 2 * r] = ta; sred[wave * 16 + 2 * r + 1] = tb; }
+      }
+    }
+    __syncthreads();
+    stamp(pf, 2);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      if (r < M) {
+        const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) / (float)K;
+        const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) / (float)K;
+        const float mu = cshift[r] + A;
+        const float rs = 1.0f / sqrtf(fmaxf(Bq - A * A, 0.f) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k4 = tid + 256 * j;
+          if (k4 < k4n) {
+            f16x4 o;
+            o[0] = (f16)((xv[r][j].x - mu) * rs * gv[j].x + bv[j].x); o[1] = (f16)((xv[r][j].y - mu) * rs * gv[j].y + bv[j].y);
+            o[2] = (f16)((xv[r][j].z - mu) * rs * gv[j].z + bv[j].z); o[3] = (f16)((xv[r][j].w - mu) * rs * gv[j].w + bv[j].w);
+            *reinterpret_cast<f16x4*>(xs + (size_t)r * xstr + k4 * 4) = o;
+          }
+        }
+      }
+    }
+  } else if (fastx) {
+    const int c8 = K >> 3;
+#pragma unroll
+    for (int i = 0; i < NXH; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < M * c8) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
+    }
+  } else if (ln) {
     const float* xf = reinterpret_cast<const float*>(p.x);
     for (int r = wave; r < M; r += 4) {
       const float4* x4 = reinterpret_cast<const float4*>(xf + (size_t)r * K);
-      float s = 0.f;
-      for (int i = lane; i < K / 4; i += 64) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
-      const float mean = wave_sum(s) / (float)K;
+      float sm = 0.f;
+      for (int i = lane; i < k4n; i += 64) { const float4 v = x4[i]; sm += (v.x + v.y) + (v.z + v.w); }
+      const float mean = wave_sum(sm) / (float)K;
       float q = 0.f;
-      for (int i = lane; i < K / 4; i += 64) {
+      for (int i = lane; i < k4n; i += 64) {
         const float4 v = x4[i];
         const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
         q += (a * a + b * b) + (c * c + e * e);
@@ -92,59 +198,63 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   f32x4 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int xrow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) { int r = mb * 16 + (lane & 15); xrow[mb] = (r < M ? r : M - 1) * xstr + 8 * (lane >> 4); }
 
-  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)nt * ksteps * 64 + lane;
   const int c8n = KC / 8;
   for (int kc0 = 0; kc0 < K; kc0 += KC) {
-    // stage x[:, kc0:kc0+KC] (normalised) as f16
-    for (int idx = tid; idx < M * c8n; idx += 256) {
-      const int r = idx / c8n, c8 = idx - r * c8n, k = kc0 + c8 * 8;
-      f16x8 o;
-      if (p.flags & GV_LN) {
-        const float* xr = reinterpret_cast<const float*>(p.x) + (size_t)r * K + k;
-        const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
-        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + k), g1 = *reinterpret_cast<const float4*>(p.gamma + k + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(p.beta + k), b1 = *reinterpret_cast<const float4*>(p.beta + k + 4);
-        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-        o[0] = (f16)((a.x - mean) * rstd * g0.x + b0.x); o[1] = (f16)((a.y - mean) * rstd * g0.y + b0.y);
-        o[2] = (f16)((a.z - mean) * rstd * g0.z + b0.z); o[3] = (f16)((a.w - mean) * rstd * g0.w + b0.w);
-        o[4] = (f16)((b.x - mean) * rstd * g1.x + b1.x); o[5] = (f16)((b.y - mean) * rstd * g1.y + b1.y);
-        o[6] = (f16)((b.z - mean) * rstd * g1.z + b1.z); o[7] = (f16)((b.w - mean) * rstd * g1.w + b1.w);
-      } else {
-        o = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.x) + (size_t)r * K + k);
+    const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * 64;
+    if (kc0 > 0) {
+#pragma unroll
+      for (int u = 0; u < GV_PF; ++u) if (u < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * 64);
+    }
+    if (!fast && !fastx) {
+      // stage x[:, kc0:kc0+KC] (normalised) as f16
+      for (int idx = tid; idx < M * c8n; idx += 256) {
+        const int r = idx / c8n, c8 = idx - r * c8n, k = kc0 + c8 * 8;
+        f16x8 o;
+        if (ln) {
+          const float* xr = reinterpret_cast<const float*>(p.x) + (size_t)r * K + k;
+          const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + k), g1 = *reinterpret_cast<const float4*>(p.gamma + k + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(p.beta + k), b1 = *reinterpret_cast<const float4*>(p.beta + k + 4);
+          const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+          o[0] = (f16)((a.x - mean) * rstd * g0.x + b0.x); o[1] = (f16)((a.y - mean) * rstd * g0.y + b0.y);
+          o[2] = (f16)((a.z - mean) * rstd * g0.z + b0.z); o[3] = (f16)((a.w - mean) * rstd * g0.w + b0.w);
+          o[4] = (f16)((b.x - mean) * rstd * g1.x + b1.x); o[5] = (f16)((b.y - mean) * rstd * g1.y + b1.y);
+          o[6] = (f16)((b.z - mean) * rstd * g1.z + b1.z); o[7] = (f16)((b.w - mean) * rstd * g1.w + b1.w);
+        } else {
+          o = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.x) + (size_t)r * K + k);
+        }
+        *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) = o;
       }
-      *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) = o;
     }
     __syncthreads();
-    const int S = KC / 128;                        // k-steps per wave in this chunk
-    const int ksl0 = wave * S;                     // first local k-step of this wave
-    const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * 64;
-    int xrow[MB];
+    stamp(pf, 3);
+    for (int base = 0; base < S; base += GV_PF) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) { int r = mb * 16 + (lane & 15); xrow[mb] = (r < M ? r : M - 1) * xstr + 8 * (lane >> 4); }
-    for (int i = 0; i < S; i += 8) {
-      u32x4 wf[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) if (i + u < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)(i + u) * 64);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (i + u < S) {
+      for (int u = 0; u < GV_PF; ++u) {
+        if (base + u < S) {
           const f16x8 a = *reinterpret_cast<const f16x8*>(&wf[u]);
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
-            const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + i + u) * 32);
+            const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + base + u) * 32);
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb, acc[mb], 0, 0, 0);
           }
+          if (base + u + GV_PF < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)(base + u + GV_PF) * 64);
         }
       }
     }
     __syncthreads();
   }
+  stamp(pf, 4);
   // cross-wave reduction; D[i = n][j = m]: lane holds m = lane&15, n = 4*(lane>>4) + r
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
     *reinterpret_cast<float4*>(red + ((size_t)(wave * MB + mb) * 64 + lane) * 4) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
+  stamp(pf, 5);
   if (tid < MB * 64) {
     const int mb = tid >> 6, ln = tid & 63;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -181,6 +291,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       }
     }
   }
+  stamp(pf, 6);
 }
 
 int launch_gemv(hipStream_t st, const GemvP& p) {
@@ -188,7 +299,7 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int MB = cdiv(p.M, 16);
   // largest K-chunk (multiple of 128 dividing K) whose f16 image of M rows fits 64 KiB
   int KC = p.K;
-  const size_t aux = (size_t)4 * MB * 64 * 16 + MAX_ROWS * 8 + 16;   // red + stats (+ alignment)
+  const size_t aux = (size_t)4 * MB * 64 * 16 + MAX_ROWS * 8 + 4 * 16 * 4 + 16;   // red + stats + sred (+ alignment)
   while ((size_t)p.M * (KC + 8) * 2 + aux > 65536) {
     int next = 0;
     for (int c = KC - 128; c >= 128; c -= 128) if (p.K % c == 0) { next = c; break; }
@@ -198,11 +309,16 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const size_t lds = (((size_t)p.M * (KC + 8) * 2 + 15) & ~(size_t)15) + aux;
   const int npad = cdiv(p.N, 16) * 16;
   dim3 grid(npad / 16), block(256);
-  switch (MB) {
-    case 1: hipLaunchKernelGGL(gemv_kernel<1>, grid, block, lds, st, p, KC); break;
-    case 2: hipLaunchKernelGGL(gemv_kernel<2>, grid, block, lds, st, p, KC); break;
-    default: hipLaunchKernelGGL(gemv_kernel<3>, grid, block, lds, st, p, KC); break;
+  int mode = 0;
+  if (KC == p.K) {
+    if ((p.flags & GV_LN) && p.M <= 8 && p.K <= 2048) mode = 1;
+    else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
   }
+#define WIS_GV(MBv, MODEv) hipLaunchKernelGGL((gemv_kernel<MBv, MODEv>), grid, block, lds, st, p, KC)
+  if (MB == 1) { if (mode == 1) WIS_GV(1, 1); else if (mode == 2) WIS_GV(1, 2); else WIS_GV(1, 0); }
+  else if (MB == 2) { if (mode == 2) WIS_GV(2, 2); else WIS_GV(2, 0); }
+  else { if (mode == 2) WIS_GV(3, 2); else WIS_GV(3, 0); }
+#undef WIS_GV
   return WIS_OK;
 }
 
@@ -222,52 +338,89 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 
 // =======================================================================================
 // causal self-attention of one new token per row over its cached history.  grid (M, H), block 64.
+// The logical slot of row m is arithmetic ((m / rpu) * sstride + (m % rpu) * rmul: decode rows own their slot,
+// prefill rows share the utterance's first slot), so the dependent chain is two round trips:
+// {pos, ancestry} -> {K rows (lane = position), V prefetch (lane = dh) for the first 32 positions}.
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
-                                                           const int* __restrict__ anc, const int* __restrict__ lslot, const int* __restrict__ pos,
-                                                           f16* __restrict__ out, int d, int ctx) {
+                                                           const int* __restrict__ anc, const int* __restrict__ pos,
+                                                           f16* __restrict__ out, int d, int ctx, int rpu, int sstride, int rmul,
+                                                           unsigned long long* prof) {
   __shared__ float sq[64];
   __shared__ float sp[512];
   __shared__ int sa[512];
   const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  const int ls = lslot[m], len = pos[m] + 1;
+  unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
+  stamp(pf, 0);
+  const int ls = (m / rpu) * sstride + (m % rpu) * rmul;
+  const int* arow = anc + (size_t)ls * ctx;
+  int a0[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int p = lane + 64 * i; a0[i] = (p < ctx) ? arow[p] : 0; }   // issued before len is known
+  const int len = pos[m] + 1;
   sq[lane] = q[(size_t)m * d + h * 64 + lane];
-  for (int p = lane; p < len; p += 64) sa[p] = anc[(size_t)ls * ctx + p];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int p = lane + 64 * i; if (p < len) sa[p] = a0[i]; }
   __syncthreads();
+  stamp(pf, 1);
+  // V prefetch: lane = dh, first 32 positions
+  const f16* vbase = vc + h * 64 + lane;
+  f16 vreg[32];
+#pragma unroll
+  for (int pp = 0; pp < 32; ++pp) if (pp < len) vreg[pp] = vbase[((size_t)sa[pp] * ctx + pp) * d];
   float mx = -INFINITY;
   for (int p = lane; p < len; p += 64) {
     const f16* kr = kc + ((size_t)sa[p] * ctx + p) * d + h * 64;
+    f16x8 kv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kv[c] = *reinterpret_cast<const f16x8*>(kr + 8 * c);
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f16x8 kv = *reinterpret_cast<const f16x8*>(kr + 8 * c);
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot = fmaf((float)kv[j], sq[8 * c + j], dot);
-    }
+      for (int j = 0; j < 8; ++j) dot = fmaf((float)kv[c][j], sq[8 * c + j], dot);
     sp[p] = dot; mx = fmaxf(mx, dot);
   }
+  stamp(pf, 2);
   mx = wave_max(mx);
   float sum = 0.f;
   for (int p = lane; p < len; p += 64) { const float e = __expf(sp[p] - mx); sp[p] = e; sum += e; }
   sum = wave_sum(sum);
   __syncthreads();
+  stamp(pf, 3);
   float acc = 0.f;
-  for (int p = 0; p < len; ++p) acc = fmaf(sp[p], (float)vc[((size_t)sa[p] * ctx + p) * d + h * 64 + lane], acc);
+#pragma unroll
+  for (int pp = 0; pp < 32; ++pp) if (pp < len) acc = fmaf(sp[pp], (float)vreg[pp], acc);
+  for (int p = 32; p < len; ++p) acc = fmaf(sp[p], (float)vbase[((size_t)sa[p] * ctx + p) * d], acc);
   out[(size_t)m * d + h * 64 + lane] = (f16)(acc / sum);
+  stamp(pf, 4);
 }
-int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* lslot,
-                         const int* pos, f16* out, int M, int H, int d, int ctx) {
-  if (ctx > 512) { set_error("dec_self_attn: ctx=%d > 512", ctx); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, anc, lslot, pos, out, d, ctx);
+int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
+                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof) {
+  if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, anc, pos, out, d, ctx, rpu, sstride, rmul, prof);
   return WIS_OK;
 }
 
 // =======================================================================================
-// cross-attention.  grid (chunks, H, B), block 256.  dynamic LDS: scores f32 [R][CL]
+// cross-attention of the R query rows of one utterance over a chunk of <= 256 encoder keys.
+// grid (chunks, H, B), block 256.  One memory round trip: every K load (lane = key, 8 coalesced 16-byte
+// dh-groups) and every V load (lane = (key%32 slot, dh-group), 1 KiB per wave instruction) is issued up front;
+// scores / softmax / P.V then run from registers + LDS.  The chunk partials (o[64], max, sum) are published with
+// write-through (sc1) relaxed agent-scope stores and combined by the last-arriving workgroup, which reads them
+// back with sc1 loads: placement independent, no fences (guide §6 G16, "8-B/4-B agent atomics both sides").
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vx,
-                                                             f16* __restrict__ out, float* __restrict__ part, unsigned* __restrict__ counters,
-                                                             int H, int d, int T, int C, int CL) {
-  extern __shared__ __attribute__((aligned(16))) float ssc[];   // [R][CL]
+                                                             f16* __restrict__ out, float* part, unsigned* counters,
+                                                             int H, int d, int T, int C, int CL, unsigned long long* prof) {
+  __shared__ float ssc[R][256];
   __shared__ float sq[R][64];
   __shared__ float sred[4][R];
   __shared__ float so[4][R][64];
@@ -275,23 +428,36 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int klo = c * CL, khi = (klo + CL < T) ? klo + CL : T, n = khi - klo;
+  const int klo = c * CL, khi = (klo + CL < T) ? klo + CL : T, n = khi - klo;   // n <= 256
+  unsigned long long* pf = (c == 0 && h == 0 && b == 0 && tid == 0) ? prof : nullptr;
+  stamp(pf, 0);
 
+  // ---- all loads first
+  const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
+  u32x4 kr[8];
+  if (tid < n) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) kr[g] = *reinterpret_cast<const u32x4*>(kb + ((size_t)g * T + klo + tid) * 8);
+  }
+  const int g8 = tid & 7, kq = tid >> 3;
+  const f16* vb = vx + (size_t)(b * H + h) * T * 64 + 8 * g8;
+  u32x4 vr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int key = klo + kq + 32 * i; if (key < khi) vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)key * 64); }
   for (int i = tid; i < R * 64; i += 256) sq[i >> 6][i & 63] = q[(size_t)(b * R + (i >> 6)) * d + h * 64 + (i & 63)];
   __syncthreads();
+  stamp(pf, 1);
 
-  // ---- scores: one key per lane, K read as 8 coalesced 16-byte dh-groups
-  const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
-  float mx[R];
+  // ---- scores: one key per lane
+  float s[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
-  for (int key = klo + tid; key < khi; key += 256) {
-    float s[R];
+  for (int r = 0; r < R; ++r) s[r] = -INFINITY;
+  if (tid < n) {
 #pragma unroll
     for (int r = 0; r < R; ++r) s[r] = 0.f;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      const f16x8 kv = *reinterpret_cast<const f16x8*>(kb + ((size_t)g * T + key) * 8);
+      const f16x8 kv = *reinterpret_cast<const f16x8*>(&kr[g]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float kf = (float)kv[j];
@@ -299,47 +465,45 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
         for (int r = 0; r < R; ++r) s[r] = fmaf(kf, sq[r][8 * g + j], s[r]);
       }
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) { ssc[r * CL + key - klo] = s[r]; mx[r] = fmaxf(mx[r], s[r]); }
   }
+  stamp(pf, 2);
 #pragma unroll
-  for (int r = 0; r < R; ++r) { const float v = wave_max(mx[r]); if (lane == 0) sred[wave][r] = v; }
+  for (int r = 0; r < R; ++r) { const float v = wave_max(s[r]); if (lane == 0) sred[wave][r] = v; }
   __syncthreads();
   if (tid < R) smx[tid] = fmaxf(fmaxf(sred[0][tid], sred[1][tid]), fmaxf(sred[2][tid], sred[3][tid]));
   __syncthreads();
-  float sm[R];
+  float e[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) sm[r] = 0.f;
-  for (int i = tid; i < n; i += 256) {
+  for (int r = 0; r < R; ++r) { e[r] = (tid < n) ? __expf(s[r] - smx[r]) : 0.f; ssc[r][tid] = e[r]; }
 #pragma unroll
-    for (int r = 0; r < R; ++r) { const float e = __expf(ssc[r * CL + i] - smx[r]); ssc[r * CL + i] = e; sm[r] += e; }
-  }
-  __syncthreads();   // sred reuse + ssc visible
-#pragma unroll
-  for (int r = 0; r < R; ++r) { const float v = wave_sum(sm[r]); if (lane == 0) sred[wave][r] = v; }
+  for (int r = 0; r < R; ++r) { const float v = wave_sum(e[r]); if (lane == 0) sred[wave][r] = v; }
   __syncthreads();
   if (tid < R) ssum[tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+  stamp(pf, 3);
 
-  // ---- P.V: lane = (key sub-index kq, 8-wide dh group g); 8 keys x 128 B = 1 KiB per wave load
-  const int g = tid & 7, kq = tid >> 3;
-  const f16* vb = vx + (size_t)(b * H + h) * T * 64 + 8 * g;
+  // ---- P.V from the prefetched V registers
   float o[R][8];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[r][j] = 0.f;
-  for (int key = klo + kq; key < khi; key += 32) {
-    const f16x8 vv = *reinterpret_cast<const f16x8*>(vb + (size_t)key * 64);
-    float vf[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vf[j] = (float)vv[j];
+  for (int i = 0; i < 8; ++i) {
+    const int kk = kq + 32 * i;
+    if (kk < n) {
+      const f16x8 vv = *reinterpret_cast<const f16x8*>(&vr[i]);
+      float vf[8];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float pr = ssc[r * CL + key - klo];
+      for (int j = 0; j < 8; ++j) vf[j] = (float)vv[j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[r][j] = fmaf(pr, vf[j], o[r][j]);
+      for (int r = 0; r < R; ++r) {
+        const float pr = ssc[r][kk];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[r][j] = fmaf(pr, vf[j], o[r][j]);
+      }
     }
   }
+  stamp(pf, 4);
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -349,6 +513,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       if (lane < 8) so[wave][r][8 * lane + j] = v;
     }
   __syncthreads();
+  stamp(pf, 5);
   if (C == 1) {
     for (int i = tid; i < R * 64; i += 256) {
       const int r = i >> 6, dh = i & 63;
@@ -357,51 +522,48 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     }
     return;
   }
-  // ---- split-T: publish partial (o[64], max, sum) and let the last-arriving workgroup combine
+  // ---- split-T: publish the partial with write-through stores; the last-arriving workgroup combines
   float* pbase = part + ((size_t)(b * H + h) * C) * R * 66;
   for (int i = tid; i < R * 64; i += 256) {
     const int r = i >> 6, dh = i & 63;
     const float v = (so[0][r][dh] + so[1][r][dh]) + (so[2][r][dh] + so[3][r][dh]);
     float* pp = pbase + ((size_t)c * R + r) * 66;
-    pp[dh] = v;
-    if (dh == 0) { pp[64] = smx[r]; pp[65] = ssum[r]; }
+    st_sc1(pp + dh, v);
+    if (dh == 0) { st_sc1(pp + 64, smx[r]); st_sc1(pp + 65, ssum[r]); }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
   __syncthreads();
+  stamp(pf, 6);
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned prev = __hip_atomic_fetch_add(counters + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (prev == (unsigned)(C - 1));
-    if (last) {
-      __hip_atomic_store(counters + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (last) __hip_atomic_store(counters + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
     s_last = last;
   }
   __syncthreads();
+  stamp(pf, 7);
   if (!s_last) return;
   for (int i = tid; i < R * 64; i += 256) {
     const int r = i >> 6, dh = i & 63;
     float M_ = -INFINITY;
-    for (int cc = 0; cc < C; ++cc) M_ = fmaxf(M_, pbase[((size_t)cc * R + r) * 66 + 64]);
+    for (int cc = 0; cc < C; ++cc) M_ = fmaxf(M_, ld_sc1(pbase + ((size_t)cc * R + r) * 66 + 64));
     float L = 0.f, O = 0.f;
     for (int cc = 0; cc < C; ++cc) {
       const float* pp = pbase + ((size_t)cc * R + r) * 66;
-      const float w = __expf(pp[64] - M_);
-      L = fmaf(pp[65], w, L); O = fmaf(pp[dh], w, O);
+      const float w = __expf(ld_sc1(pp + 64) - M_);
+      L = fmaf(ld_sc1(pp + 65), w, L); O = fmaf(ld_sc1(pp + dh), w, O);
     }
     out[(size_t)(b * R + r) * d + h * 64 + dh] = (f16)(O / L);
   }
 }
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vx, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int chunks) {
+                          int B, int R, int H, int d, int T, int chunks, unsigned long long* prof) {
   if (R < 1 || R > MAX_R || chunks < 1) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(T, chunks);
-  const size_t lds = (size_t)R * CL * 4;
+  if (CL > 256 || chunks > 16) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (<= 16 chunks of <= 256 keys)", chunks, CL); return WIS_E_UNSUPPORTED; }
   dim3 grid(chunks, H, B), block(256);
-#define WIS_CA(RR) case RR: hipLaunchKernelGGL(dec_cross_attn_kernel<RR>, grid, block, lds, st, q, kx, vx, out, part, counters, H, d, T, chunks, CL); break;
+#define WIS_CA(RR) case RR: hipLaunchKernelGGL(dec_cross_attn_kernel<RR>, grid, block, 0, st, q, kx, vx, out, part, counters, H, d, T, chunks, CL, prof); break;
   switch (R) { WIS_CA(1) WIS_CA(2) WIS_CA(3) WIS_CA(4) WIS_CA(5) WIS_CA(6) WIS_CA(7) WIS_CA(8) }
 #undef WIS_CA
   return WIS_OK;

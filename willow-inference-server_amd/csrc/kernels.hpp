@@ -44,6 +44,7 @@ struct GemvP {
   int M, N, K, flags;
   // GV_QKV epilogue: n < d -> q (f32 [M][d]); d <= n < 2d -> K cache; n >= 2d -> V cache
   float* q; f16* kc; f16* vc; const int* slot; const int* pos; int d; int ctx;   // cache [slots][ctx][d]
+  unsigned long long* prof;      // optional phase stamps (workgroup 0)
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
 // pack W [N][K] f16 row-major -> Wp [Npad/16][K/32][64][8]; rows >= N are zero; scale rows
@@ -51,12 +52,13 @@ int launch_gemv(hipStream_t st, const GemvP& p);
 int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale);
 
 int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d);
-int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* lslot,
-                         const int* pos, f16* out, int M, int H, int d, int ctx);
+// logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
+int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
+                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr);
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vx f16 [B][H][T][64] -> out f16 [B*R][d]
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vx, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int chunks);
+                          int B, int R, int H, int d, int T, int chunks, unsigned long long* prof = nullptr);
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

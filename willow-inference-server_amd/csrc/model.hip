@@ -117,6 +117,8 @@ struct wis_model {
   wis_timing_t timing;
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph;
+  unsigned long long* d_prof;   // [6][16] phase stamps of layer 0 (wis_debug_phase_cycles)
+  bool prof_on;
 };
 
 namespace {
@@ -323,6 +325,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->d_in, (size_t)Bm * WIS_N_SAMPLES));
   WIS_RET(dalloc(m, &m->d_nsamp, Bm));
   WIS_RET(dalloc(m, &m->d_probs, (size_t)Bm * (c.n_lang > 0 ? c.n_lang : 1)));
+  WIS_RET(dalloc(m, &m->d_prof, (size_t)6 * 16));
   WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 65536, hipHostMallocDefault));
   for (int i = 0; i < 8; ++i) WIS_HIP_CHECK(hipEventCreate(&m->ev[i]));
   return WIS_OK;
@@ -386,36 +389,39 @@ int run_cross_kv(wis_model* m, int B) {
 }
 
 // ---- one decoder forward over the current row metadata ---------------------------------
-int dec_forward(wis_model* m, int M, int R, int B, bool want_logits) {
+// sstride / rmul: logical-slot mapping of the rows (decode rows: beam, 1; prefill rows: beam, 0; single rows: 1, 0)
+int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
-  int chunks = 256 / (B * H); if (chunks < 1) chunks = 1; if (chunks > 8) chunks = 8;
+  int chunks = 256 / (B * H); if (chunks < 6) chunks = 6; if (chunks > 12) chunks = 12;   // <= 256 keys per workgroup
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
+    unsigned long long* pr = (m->prof_on && l == 0) ? m->d_prof : nullptr;
     GemvP g; memset(&g, 0, sizeof(g));
     // self-attention block
     g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
+    g.prof = pr;
     WIS_RET(launch_gemv(st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.lslot, m->rm.pos, m->dao, M, H, d, ctx));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 48 : nullptr));
     memset(&g, 0, sizeof(g));
-    g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
+    g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 16 : nullptr;
     WIS_RET(launch_gemv(st, g));
     // cross-attention block
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     WIS_RET(launch_gemv(st, g));
-    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, chunks));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, chunks, pr ? pr + 32 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
     WIS_RET(launch_gemv(st, g));
     // FFN
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU;
+    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 64 : nullptr;
     WIS_RET(launch_gemv(st, g));
     memset(&g, 0, sizeof(g));
-    g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID;
+    g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
     WIS_RET(launch_gemv(st, g));
   }
   if (want_logits) {
@@ -567,7 +573,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     std::vector<int> tok(B * R), pos(B * R), slot(B * R), ls(B * R);
     for (int b = 0; b < B; ++b) for (int i = 0; i < R; ++i) { tok[b * R + i] = prompt[b * P + i]; pos[b * R + i] = i; slot[b * R + i] = b * beam; ls[b * R + i] = b * beam; }
     WIS_RET(upload_rows(m, tok, pos, slot, ls));
-    WIS_RET(dec_forward(m, B * R, R, B, false));
+    WIS_RET(dec_forward(m, B * R, R, B, false, beam, 0));
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
   {
@@ -586,7 +592,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
 
   auto one_step = [&]() -> int {
-    WIS_RET(dec_forward(m, Mrows, beam, B, true));
+    WIS_RET(dec_forward(m, Mrows, beam, B, true, beam, 1));
     WIS_RET(launch_logit_stats(st, m->logits, o->suppress_default ? m->bias_all : nullptr, m->bias_begin, m->bs.step_u,
                                m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc));
@@ -685,7 +691,7 @@ int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int 
   WIS_RET(run_cross_kv(m, B));
   std::vector<int> tok(B, m->cfg.sot);
   WIS_RET(single_row_setup(m, B, tok, 0));
-  WIS_RET(dec_forward(m, B, 1, B, true));
+  WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
   WIS_RET(launch_lang_probs(m->st, m->logits, m->n_vocab_pad, m->d_lang_ids, m->cfg.n_lang, m->d_probs, B));
   WIS_HIP_CHECK(hipMemcpyAsync(lang_probs, m->d_probs, (size_t)B * m->cfg.n_lang * 4, hipMemcpyDeviceToHost, m->st));
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
@@ -717,11 +723,35 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, 
     std::vector<int> tok(B);
     for (int b = 0; b < B; ++b) tok[b] = dec_in[b * T + t];
     WIS_RET(single_row_setup(m, B, tok, t));
-    WIS_RET(dec_forward(m, B, 1, B, true));
+    WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
     for (int b = 0; b < B; ++b)
       WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t) * V, m->logits + (size_t)b * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
     WIS_HIP_CHECK(hipStreamSynchronize(m->st));
   }
+  return WIS_OK;
+}
+
+int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* out) {
+  if (!m || !out) { set_error("wis_debug_phase_cycles: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, B, beam));
+  const int Mrows = B * beam, ctx = m->cfg.n_text_ctx;
+  if (pos < 0 || pos >= ctx) { set_error("bad pos"); return WIS_E_ARG; }
+  std::vector<int> anc((size_t)Mrows * ctx);
+  for (int r = 0; r < Mrows; ++r) for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = r;
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  std::vector<int> tok(Mrows, 100), ps(Mrows, pos), slot(Mrows), ls(Mrows);
+  for (int r = 0; r < Mrows; ++r) { slot[r] = r; ls[r] = r; }
+  WIS_RET(upload_rows(m, tok, ps, slot, ls));
+  WIS_HIP_CHECK(hipMemsetAsync(m->d_prof, 0, 6 * 16 * 8, m->st));
+  WIS_RET(dec_forward(m, Mrows, beam, B, false, beam, 1));   // warm
+  m->prof_on = true;
+  int rc = dec_forward(m, Mrows, beam, B, false, beam, 1);
+  m->prof_on = false;
+  WIS_RET(rc);
+  WIS_HIP_CHECK(hipMemcpyAsync(out, m->d_prof, 6 * 16 * 8, hipMemcpyDeviceToHost, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
   return WIS_OK;
 }
 

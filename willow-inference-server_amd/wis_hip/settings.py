@@ -1,0 +1,66 @@
+"""Same field names and defaults as the reference's `settings.py:6-82` (pydantic-settings `APISettings`, env-overridable,
+case-insensitive, no prefix).  `pydantic_settings` is not installable offline, so this is a plain dataclass that reads the
+environment the same way; an optional `custom_settings.py` on sys.path shadows it, as in reference main.py:68-77.
+Extra fields (not in the reference) are marked."""
+import os
+from dataclasses import dataclass, field, fields
+from functools import lru_cache
+from typing import List
+
+
+@dataclass
+class APISettings:
+    name: str = "Willow Inference Server"
+    description: str = "High Performance Language Inference API"
+    version: str = "1.0"
+    beam_size: int = 1
+    long_beam_size: int = 3
+    long_beam_size_threshold: int = 12000
+    ctranslate2_threads: int = 10
+    language: str = "en"
+    detect_language: bool = False
+    preload_all_models: bool = False
+    preload_whisper_model_tiny: bool = True
+    preload_whisper_model_base: bool = True
+    preload_whisper_model_small: bool = True
+    preload_whisper_model_medium: bool = True
+    preload_whisper_model_large: bool = True
+    sv_memory_threshold: int = 5798205849
+    support_chunking: bool = True
+    chunking_memory_threshold: int = 3798205849
+    concurrent_gpu_chunks: int = 2
+    support_sv: bool = False
+    sv_threshold: float = 0.75
+    whisper_model_default: str = "medium"
+    cors_allowed_origins: List[str] = field(default_factory=list)
+    aiortc_debug: bool = False
+    # --- not in the reference: where the weights come from.  "{size}" is substituted; a directory path selects a
+    # CTranslate2 model dir (models/tovera-wis-whisper-*, utils.sh:99-108), "synthetic:{size}" seeded synthetic weights.
+    whisper_model_path: str = "synthetic:{size}"
+    max_batch: int = 8
+
+    def __post_init__(self):
+        env = {k.lower(): v for k, v in os.environ.items()}
+        for f in fields(self):
+            if f.name in env:
+                raw = env[f.name]
+                cur = getattr(self, f.name)
+                if isinstance(cur, bool):
+                    setattr(self, f.name, raw.strip().lower() in ("1", "true", "yes", "on"))
+                elif isinstance(cur, int):
+                    setattr(self, f.name, int(raw))
+                elif isinstance(cur, float):
+                    setattr(self, f.name, float(raw))
+                elif isinstance(cur, list):
+                    setattr(self, f.name, [s for s in raw.strip("[]").replace('"', "").split(",") if s])
+                else:
+                    setattr(self, f.name, raw)
+
+
+@lru_cache()
+def get_api_settings() -> APISettings:
+    try:
+        from custom_settings import get_api_settings as custom   # reference main.py:68-77
+        return custom()
+    except ImportError:
+        return APISettings()
