@@ -146,7 +146,11 @@ def test_enc_attention(lib, B, T, H):
 
 
 @pytest.mark.parametrize("M,N,K,flags", [(5, 1280, 1280, 8 | 4), (1, 384, 384, 0), (5, 1280, 5120, 2), (17, 512, 2048, 1),
-                                         (40, 1280, 1280, 8 | 1), (5, 51865 // 4 * 4, 384, 8 | 4), (3, 1004, 128, 4), (48, 256, 5120, 2)])
+                                         (40, 1280, 1280, 8 | 1), (5, 51865 // 4 * 4, 384, 8 | 4), (3, 1004, 128, 4), (48, 256, 5120, 2),
+                                         # more workgroups than CUs + several 16-row blocks + fused LN: the shapes that exposed a
+                                         # cross-wave statistics hazard in round 1 (last row wrong in ~0.5 % of workgroups)
+                                         (20, 5120, 640, 8 | 1), (24, 5120, 1280, 8 | 1), (40, 7680, 1280, 8 | 1), (40, 5120, 1280, 8 | 4),
+                                         (8, 5120, 1280, 8 | 4), (5, 1280, 5120, 0), (16, 1280, 4096, 2)])
 def test_gemv(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 31 + N + K)
@@ -170,7 +174,13 @@ def test_gemv(lib, M, N, K, flags):
     dx, dW, dbias, dg, db = DevBuf.from_numpy(x), DevBuf.from_numpy(Wt), DevBuf.from_numpy(bias), DevBuf.from_numpy(g), DevBuf.from_numpy(b)
     dy = DevBuf.from_numpy(y0) if out_f32 else DevBuf(M * N * 2)
     check(lib.wis_op_gemv(0, dx.ptr, dg.ptr, db.ptr, dW.ptr, dbias.ptr, dy.ptr, M, N, K, flags))
-    out = dy.to_numpy(np.float32 if out_f32 else np.float16, (M, N))
-    e = _relerr(out, ref)
-    print(f"gemv M{M} N{N} K{K} flags{flags}: rel err {e:.3e}")
-    assert e < (1e-3 if out_f32 else 2e-3)
+    for rep in range(3):          # repeated: the hazard was timing dependent
+        if rep:
+            check(lib.wis_dev_h2d(0, dy.ptr, y0.ctypes.data_as(__import__("ctypes").c_void_p), y0.nbytes)) if out_f32 else None
+            check(lib.wis_op_gemv(0, dx.ptr, dg.ptr, db.ptr, dW.ptr, dbias.ptr, dy.ptr, M, N, K, flags))
+        out = dy.to_numpy(np.float32 if out_f32 else np.float16, (M, N))
+        e = _relerr(out, ref)
+        worst = float(np.abs(out.astype(np.float64) - ref).max())
+        print(f"gemv M{M} N{N} K{K} flags{flags} rep{rep}: rel err {e:.3e} max abs {worst:.3e}")
+        assert e < (1e-3 if out_f32 else 2e-3)
+        assert worst < 0.05 * (1 + float(np.abs(ref).max()))          # no single corrupted row hiding inside the L2 norm

@@ -25,14 +25,17 @@
 namespace wis {
 
 // =======================================================================================
-__global__ void pack_gemv_kernel(const f16* __restrict__ W, f16* __restrict__ Wp, int N, int Npad, int K, int n_scale, float scale) {
+// packed image: [Npad/rows][K/32][4 k-quarters][rows][8 f16]; rows = 16 is the full MFMA A fragment ([64 lanes][8]),
+// rows = 8 / 4 keep only the first rows of each fragment so that small-N matrices still spread over every CU.
+__global__ void pack_gemv_kernel(const f16* __restrict__ W, f16* __restrict__ Wp, int N, int Npad, int K, int n_scale, float scale, int rows) {
   const int ksteps = K / 32;
-  const size_t total = (size_t)(Npad / 16) * ksteps * 64;
+  const size_t total = (size_t)Npad * ksteps * 4;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    const size_t t = idx >> 6;
+    const int row = (int)(idx % rows);
+    size_t t = idx / rows;
+    const int kq = (int)(t & 3); t >>= 2;
     const int ks = (int)(t % ksteps), nt = (int)(t / ksteps);
-    const int n = 16 * nt + (lane & 15), k = 32 * ks + 8 * (lane >> 4);
+    const int n = rows * nt + row, k = 32 * ks + 8 * kq;
     f16x8 v;
     if (n < N) {
       v = *reinterpret_cast<const f16x8*>(W + (size_t)n * K + k);
@@ -47,11 +50,19 @@ __global__ void pack_gemv_kernel(const f16* __restrict__ W, f16* __restrict__ Wp
     *reinterpret_cast<f16x8*>(Wp + idx * 8) = v;
   }
 }
-int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale) {
-  if (K % 32 || Npad % 16 || Npad < N) { set_error("pack_gemv: bad shape N=%d Npad=%d K=%d", N, Npad, K); return WIS_E_ARG; }
-  const size_t total = (size_t)(Npad / 16) * (K / 32) * 64;
+// tile height of an [N][K] decoder matrix: the full 16-row MFMA fragment unless the matrix is both narrow (fewer than
+// ~200 tiles) and deep (K >= 2048: FFN2), where 4-row tiles spread the long per-tile stream over every CU.  For the
+// narrow d x d matrices the kernel is latency-bound and extra workgroups only add prologue work.
+int gemv_rows_for(int N, int K) {
+  (void)N; (void)K;
+  return 16;   // measured on MI355X (round 1): the K = 5120 stream is already HBM-bound with 80 workgroups (13 MB in ~6k
+               // cycles = 4.5 TB/s); 4-row tiles and a 40-deep prefetch cost ~1.5k cycles of issue per launch and gained nothing
+}
+int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale, int rows) {
+  if (K % 32 || Npad % rows || Npad < N || (rows != 16 && rows != 8 && rows != 4)) { set_error("pack_gemv: bad shape N=%d Npad=%d K=%d rows=%d", N, Npad, K, rows); return WIS_E_ARG; }
+  const size_t total = (size_t)Npad * (K / 32) * 4;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_gemv_kernel, dim3(blocks), dim3(256), 0, st, W, Wp, N, Npad, K, n_scale, scale);
+  hipLaunchKernelGGL(pack_gemv_kernel, dim3(blocks), dim3(256), 0, st, W, Wp, N, Npad, K, n_scale, scale, rows);
   return WIS_OK;
 }
 
@@ -63,11 +74,13 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 // previous kernel) are issued FIRST, then a 16-deep prefetch of this wave's weight fragments (HBM);
 // vmcnt retires in order, so LayerNorm statistics and the f16 staging of x run from registers while
 // the weight stream is in flight, and the MFMAs consume the fragments as they land, refilling the ring.
-constexpr int GV_PF = 16;   // weight fragments in flight per wave (16 KiB)
+// GV_PF (template): weight fragments in flight per wave: 16 (16 KiB) by default, 40 for the K >= 2176 matrices
+// (FFN2) so that their whole per-wave stream is ONE latency round instead of three.
 
 // MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
-template <int MB, int MODE>
+template <int MB, int MODE, int GV_PF>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
+  constexpr int rows = 16;   // full MFMA A fragments (4/8-row tiles were measured: more workgroups only add prologue work)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = p.M, K = p.K;
   const int xstr = KC + 8;
@@ -80,7 +93,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const int ksteps = K / 32;
   const int S = KC / 128;                        // k-steps per wave per chunk
   const int ksl0 = wave * S;                     // first chunk-local k-step of this wave
-  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)nt * ksteps * 64 + lane;
+  // fragment (tile, k-step) = 4*rows 16-byte pieces: piece (kq, row) at kq*rows + row; lanes with row >= rows stay zero
+  const bool wact = (lane & 15) < rows;
+  const int wstep = 4 * rows;                     // pieces per k-step
+  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)nt * ksteps * wstep + (lane >> 4) * rows + (lane & 15);
+  const u32x4 wzero = {0u, 0u, 0u, 0u};
   const int k4n = K >> 2;                        // float4 per row
   const bool ln = p.flags & GV_LN;
   // fast LayerNorm path (host-selected, M <= 8, K <= 2048): the whole M x K activation lives in registers; thread
@@ -120,9 +137,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   // weight prefetch for chunk 0 (independent of x)
   u32x4 wf[GV_PF];
   {
-    const u32x4* wq = wp4 + (size_t)ksl0 * 64;
+    const u32x4* wq = wp4 + (size_t)ksl0 * wstep;
 #pragma unroll
-    for (int u = 0; u < GV_PF; ++u) if (u < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * 64);
+    for (int u = 0; u < GV_PF; ++u) { wf[u] = wzero; if (u < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep); }
   }
 
   stamp(pf, 1);
@@ -150,13 +167,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
     __syncthreads();
     stamp(pf, 2);
+    const float invK = 1.0f / (float)K;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       if (r < M) {
-        const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) / (float)K;
-        const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) / (float)K;
+        const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) * invK;
+        const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) * invK;
         const float mu = cshift[r] + A;
-        const float rs = 1.0f / sqrtf(fmaxf(Bq - A * A, 0.f) + 1e-5f);
+        const float rs = __builtin_amdgcn_rsqf(fmaxf(Bq - A * A, 0.f) + 1e-5f);   // v_rsq_f32 (1 ulp); the result is rounded to f16 anyway
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int k4 = tid + 256 * j;
@@ -204,30 +222,38 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
 
   const int c8n = KC / 8;
   for (int kc0 = 0; kc0 < K; kc0 += KC) {
-    const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * 64;
+    const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * wstep;
     if (kc0 > 0) {
 #pragma unroll
-      for (int u = 0; u < GV_PF; ++u) if (u < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * 64);
+      for (int u = 0; u < GV_PF; ++u) if (u < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep);
     }
     if (!fast && !fastx) {
-      // stage x[:, kc0:kc0+KC] (normalised) as f16
-      for (int idx = tid; idx < M * c8n; idx += 256) {
-        const int r = idx / c8n, c8 = idx - r * c8n, k = kc0 + c8 * 8;
-        f16x8 o;
-        if (ln) {
-          const float* xr = reinterpret_cast<const float*>(p.x) + (size_t)r * K + k;
-          const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
-          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + k), g1 = *reinterpret_cast<const float4*>(p.gamma + k + 4);
-          const float4 b0 = *reinterpret_cast<const float4*>(p.beta + k), b1 = *reinterpret_cast<const float4*>(p.beta + k + 4);
+      // stage x[:, kc0:kc0+KC] as f16
+      if (ln) {
+        // wave w normalises exactly the rows whose statistics it computed (r = w, w+4, ...): the statistics never
+        // cross waves
+        for (int r = wave; r < M; r += 4) {
           const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-          o[0] = (f16)((a.x - mean) * rstd * g0.x + b0.x); o[1] = (f16)((a.y - mean) * rstd * g0.y + b0.y);
-          o[2] = (f16)((a.z - mean) * rstd * g0.z + b0.z); o[3] = (f16)((a.w - mean) * rstd * g0.w + b0.w);
-          o[4] = (f16)((b.x - mean) * rstd * g1.x + b1.x); o[5] = (f16)((b.y - mean) * rstd * g1.y + b1.y);
-          o[6] = (f16)((b.z - mean) * rstd * g1.z + b1.z); o[7] = (f16)((b.w - mean) * rstd * g1.w + b1.w);
-        } else {
-          o = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.x) + (size_t)r * K + k);
+          const float* xr0 = reinterpret_cast<const float*>(p.x) + (size_t)r * K + kc0;
+          for (int c8 = lane; c8 < c8n; c8 += 64) {
+            const int k = kc0 + c8 * 8;
+            const float4 a = *reinterpret_cast<const float4*>(xr0 + c8 * 8), b = *reinterpret_cast<const float4*>(xr0 + c8 * 8 + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + k), g1 = *reinterpret_cast<const float4*>(p.gamma + k + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.beta + k), b1 = *reinterpret_cast<const float4*>(p.beta + k + 4);
+            f16x8 o;
+            o[0] = (f16)((a.x - mean) * rstd * g0.x + b0.x); o[1] = (f16)((a.y - mean) * rstd * g0.y + b0.y);
+            o[2] = (f16)((a.z - mean) * rstd * g0.z + b0.z); o[3] = (f16)((a.w - mean) * rstd * g0.w + b0.w);
+            o[4] = (f16)((b.x - mean) * rstd * g1.x + b1.x); o[5] = (f16)((b.y - mean) * rstd * g1.y + b1.y);
+            o[6] = (f16)((b.z - mean) * rstd * g1.z + b1.z); o[7] = (f16)((b.w - mean) * rstd * g1.w + b1.w);
+            *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) = o;
+          }
         }
-        *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) = o;
+      } else {
+        for (int idx = tid; idx < M * c8n; idx += 256) {
+          const int r = idx / c8n, c8 = idx - r * c8n, k = kc0 + c8 * 8;
+          *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) =
+              *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.x) + (size_t)r * K + k);
+        }
       }
     }
     __syncthreads();
@@ -242,7 +268,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
             const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + base + u) * 32);
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb, acc[mb], 0, 0, 0);
           }
-          if (base + u + GV_PF < S) wf[u] = __builtin_nontemporal_load(wq + (size_t)(base + u + GV_PF) * 64);
+          if (base + u + GV_PF < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)(base + u + GV_PF) * wstep);
         }
       }
     }
@@ -263,8 +289,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + mb) * 64 + ln) * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    const int m = mb * 16 + (ln & 15), n = 16 * nt + 4 * (ln >> 4);
-    if (m < M && n < p.N) {
+    const int m = mb * 16 + (ln & 15), n = rows * nt + 4 * (ln >> 4);
+    if (m < M && n < p.N && 4 * (ln >> 4) < rows) {
       if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
       if (p.flags & GV_QKV) {
         const int d = p.d;
@@ -307,14 +333,18 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
     KC = next;
   }
   const size_t lds = (((size_t)p.M * (KC + 8) * 2 + 15) & ~(size_t)15) + aux;
-  const int npad = cdiv(p.N, 16) * 16;
-  dim3 grid(npad / 16), block(256);
+  const int rows = p.rows ? p.rows : 16;
+  GemvP pp = p; pp.rows = rows;
+  const int npad = cdiv(p.N, rows) * rows;
+  dim3 grid(npad / rows), block(256);
   int mode = 0;
   if (KC == p.K) {
     if ((p.flags & GV_LN) && p.M <= 8 && p.K <= 2048) mode = 1;
     else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
   }
-#define WIS_GV(MBv, MODEv) hipLaunchKernelGGL((gemv_kernel<MBv, MODEv>), grid, block, lds, st, p, KC)
+  const bool deep = false;              // (40-deep variant kept for experiments; see gemv_rows_for)
+#define WIS_GV(MBv, MODEv) do { if (deep && MODEv != 1) hipLaunchKernelGGL((gemv_kernel<MBv, (MODEv == 1 ? 0 : MODEv), 40>), grid, block, lds, st, pp, KC); \
+                                else hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, 16>), grid, block, lds, st, pp, KC); } while (0)
   if (MB == 1) { if (mode == 1) WIS_GV(1, 1); else if (mode == 2) WIS_GV(1, 2); else WIS_GV(1, 0); }
   else if (MB == 2) { if (mode == 2) WIS_GV(2, 2); else WIS_GV(2, 0); }
   else { if (mode == 2) WIS_GV(3, 2); else WIS_GV(3, 0); }
@@ -338,60 +368,96 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 
 // =======================================================================================
 // causal self-attention of one new token per row over its cached history.  grid (M, H), block 64.
-// The logical slot of row m is arithmetic ((m / rpu) * sstride + (m % rpu) * rmul: decode rows own their slot,
-// prefill rows share the utterance's first slot), so the dependent chain is two round trips:
-// {pos, ancestry} -> {K rows (lane = position), V prefetch (lane = dh) for the first 32 positions}.
+// lane = (pl = position slot 0..7, c = 16-byte chunk 0..7 of the 64-wide head): one wave instruction moves 8 cache
+// rows x 128 B; K and V of the first 64 positions are all issued up front (one round trip), the 8-lane dot
+// products and the position reductions are DPP ops, longer histories continue with an online softmax.
+// Logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul (decode rows own their slot, prefill rows share
+// the utterance's first slot).
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
                                                            const int* __restrict__ anc, const int* __restrict__ pos,
                                                            f16* __restrict__ out, int d, int ctx, int rpu, int sstride, int rmul,
                                                            unsigned long long* prof) {
-  __shared__ float sq[64];
-  __shared__ float sp[512];
-  __shared__ int sa[512];
-  const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  __shared__ float red[4][64];
+  const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, pl = lane >> 3, c = lane & 7;
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
   stamp(pf, 0);
   const int ls = (m / rpu) * sstride + (m % rpu) * rmul;
   const int* arow = anc + (size_t)ls * ctx;
   int a0[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const int p = lane + 64 * i; a0[i] = (p < ctx) ? arow[p] : 0; }   // issued before len is known
+  for (int i = 0; i < 8; ++i) a0[i] = arow[8 * i + pl];          // ctx >= 64: always in bounds; issued before len is known
   const int len = pos[m] + 1;
-  sq[lane] = q[(size_t)m * d + h * 64 + lane];
+  const float4 q0 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c);
+  const float4 q1 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c + 4);
+  const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  const int hoff = h * 64 + 8 * c;
+  u32x4 kr[8], vr[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const int p = lane + 64 * i; if (p < len) sa[p] = a0[i]; }
-  __syncthreads();
+  for (int i = 0; i < 8; ++i) { const int p = 8 * i + pl; if (p < len) kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)a0[i] * ctx + p) * d + hoff); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int p = 8 * i + pl; if (p < len) vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)a0[i] * ctx + p) * d + hoff); }
   stamp(pf, 1);
-  // V prefetch: lane = dh, first 32 positions
-  const f16* vbase = vc + h * 64 + lane;
-  f16 vreg[32];
+  float m_run = -INFINITY, l_run = 0.f;
+  float acc[8];
 #pragma unroll
-  for (int pp = 0; pp < 32; ++pp) if (pp < len) vreg[pp] = vbase[((size_t)sa[pp] * ctx + pp) * d];
-  float mx = -INFINITY;
-  for (int p = lane; p < len; p += 64) {
-    const f16* kr = kc + ((size_t)sa[p] * ctx + p) * d + h * 64;
-    f16x8 kv[8];
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int p0 = 0; p0 < len; p0 += 64) {
+    if (p0 > 0) {   // histories beyond 64 positions: next block (not prefetched)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) kv[c] = *reinterpret_cast<const f16x8*>(kr + 8 * c);
-    float dot = 0.f;
+      for (int i = 0; i < 8; ++i) {
+        const int p = p0 + 8 * i + pl;
+        if (p < len) {
+          const int ap = arow[p];
+          kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)ap * ctx + p) * d + hoff);
+          vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)ap * ctx + p) * d + hoff);
+        }
+      }
+    }
+    float sc[8]; float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int i = 0; i < 8; ++i) {
+      const int p = p0 + 8 * i + pl;
+      float dot = 0.f;
+      if (p < len) {
+        const f16x8 kv = *reinterpret_cast<const f16x8*>(&kr[i]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot = fmaf((float)kv[c][j], sq[8 * c + j], dot);
-    sp[p] = dot; mx = fmaxf(mx, dot);
+        for (int j = 0; j < 8; ++j) dot = fmaf((float)kv[j], qv[j], dot);
+      }
+      dot += dpp_f<0xB1>(dot); dot += dpp_f<0x4E>(dot); dot += dpp_f<0x141>(dot);   // sum over the 8 chunk lanes
+      sc[i] = (p < len) ? dot : -INFINITY;
+      mx = fmaxf(mx, sc[i]);
+    }
+    mx = wave_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float pw = __expf(sc[i] - m_new);     // 0 for masked positions
+      lsum += pw;
+      if (p0 + 8 * i + pl < len) {
+        const f16x8 vv = *reinterpret_cast<const f16x8*>(&vr[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, (float)vv[j], acc[j]);
+      }
+    }
+    l_run = l_run * alpha + wave_sum(lsum) * 0.125f;   // every position is replicated on its 8 chunk lanes
+    m_run = m_new;
   }
   stamp(pf, 2);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int p = lane; p < len; p += 64) { const float e = __expf(sp[p] - mx); sp[p] = e; sum += e; }
-  sum = wave_sum(sum);
+  // reduce acc over the 8 position slots: xor 8 inside the 16-lane row by DPP, the four rows through LDS
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] += dpp_f<0x128>(acc[j]);     // row_ror:8
+  if ((lane & 8) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[lane >> 4][8 * c + j] = acc[j];
+  }
   __syncthreads();
   stamp(pf, 3);
-  float acc = 0.f;
-#pragma unroll
-  for (int pp = 0; pp < 32; ++pp) if (pp < len) acc = fmaf(sp[pp], (float)vreg[pp], acc);
-  for (int p = 32; p < len; ++p) acc = fmaf(sp[p], (float)vbase[((size_t)sa[p] * ctx + p) * d], acc);
-  out[(size_t)m * d + h * 64 + lane] = (f16)(acc / sum);
+  const float o = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  out[(size_t)m * d + h * 64 + lane] = (f16)(o / l_run);
   stamp(pf, 4);
 }
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
@@ -402,170 +468,198 @@ int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f1
 }
 
 // =======================================================================================
-// cross-attention of the R query rows of one utterance over a chunk of <= 256 encoder keys.
-// grid (chunks, H, B), block 256.  One memory round trip: every K load (lane = key, 8 coalesced 16-byte
-// dh-groups) and every V load (lane = (key%32 slot, dh-group), 1 KiB per wave instruction) is issued up front;
-// scores / softmax / P.V then run from registers + LDS.  The chunk partials (o[64], max, sum) are published with
-// write-through (sc1) relaxed agent-scope stores and combined by the last-arriving workgroup, which reads them
-// back with sc1 loads: placement independent, no fences (guide §6 G16, "8-B/4-B agent atomics both sides").
-typedef __attribute__((address_space(1))) unsigned gu32;
+// cross-attention of the R (<= 16) query rows of one utterance over a chunk of <= 256 encoder keys, on the
+// matrix cores.  grid (chunks, H, B), block 256 = 4 waves.
+//   scores  S^T[key][r] = K[key][:] . Q[r][:]      v_mfma_f32_16x16x32_f16, A = K (16 keys x 32 dh, 16-byte loads from
+//                                                   the [H][dh/8][T][8] image), B = Q^T (registers); wave w owns key tiles w, w+4, ..
+//   output  O^T[dh][r]  = V^T[dh][:] . P[r][:]      A = V^T (16 dh x 32 keys, 16-byte loads from the [H][64][Tpad] image),
+//                                                   B = P^T (f16 in LDS); wave w owns dh 16w..16w+15
+// Q, then every K and V fragment, are issued up front (one memory round trip; vmcnt retires in order, so the tiny Q load
+// is first).  No cross-lane shuffles: the MFMA output layout puts a query row on a lane column.  Chunk partials
+// (o[64], max, sum) are published with write-through (sc1) relaxed agent-scope stores and combined by the last-arriving
+// workgroup with sc1 loads: placement independent, no fences (guide §6 G16).
 __device__ __forceinline__ void st_sc1(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float ld_sc1(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16-byte aligned, bank-skewed)
 
-template <int R>
-__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vx,
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
-                                                             int H, int d, int T, int C, int CL, unsigned long long* prof) {
-  __shared__ float ssc[R][256];
-  __shared__ float sq[R][64];
-  __shared__ float sred[4][R];
-  __shared__ float so[4][R][64];
-  __shared__ float smx[R], ssum[R];
+                                                             int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof) {
+  __shared__ float ssc[16][257];
+  __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
+  __shared__ float smax[16][16];
+  __shared__ float ssumw[4][16];
+  __shared__ float smx[16], ssum[16];
   __shared__ int s_last;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
   const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int klo = c * CL, khi = (klo + CL < T) ? klo + CL : T, n = khi - klo;   // n <= 256
+  const int klo = c * CL, n = (klo + CL <= T) ? CL : T - klo;   // 1 <= n <= 256, klo % 32 == 0
   unsigned long long* pf = (c == 0 && h == 0 && b == 0 && tid == 0) ? prof : nullptr;
   stamp(pf, 0);
 
-  // ---- all loads first
+  // ---- loads: Q (B operand, lane = (row r, k-quarter)), K fragments, V^T fragments
+  const int rq = l15 < R ? l15 : R - 1;
+  const float* qp = q + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
+  const float4 qa0 = *reinterpret_cast<const float4*>(qp), qa1 = *reinterpret_cast<const float4*>(qp + 4);
+  const float4 qb0 = *reinterpret_cast<const float4*>(qp + 32), qb1 = *reinterpret_cast<const float4*>(qp + 36);
+  const int ntile = (n + 15) >> 4;
   const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
-  u32x4 kr[8];
-  if (tid < n) {
+  u32x4 kf[4][2];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) kr[g] = *reinterpret_cast<const u32x4*>(kb + ((size_t)g * T + klo + tid) * 8);
+  for (int i = 0; i < 4; ++i) {
+    const int t = wave + 4 * i;
+    if (t < ntile) {
+      int key = klo + 16 * t + l15; if (key > T - 1) key = T - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
+    }
   }
-  const int g8 = tid & 7, kq = tid >> 3;
-  const f16* vb = vx + (size_t)(b * H + h) * T * 64 + 8 * g8;
-  u32x4 vr[8];
+  const int nstep = (n + 31) >> 5;
+  const f16* vb = vt + ((size_t)(b * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
+  u32x4 vf[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const int key = klo + kq + 32 * i; if (key < khi) vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)key * 64); }
-  for (int i = tid; i < R * 64; i += 256) sq[i >> 6][i & 63] = q[(size_t)(b * R + (i >> 6)) * d + h * 64 + (i & 63)];
-  __syncthreads();
+  for (int sidx = 0; sidx < 8; ++sidx) if (sidx < nstep) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
   stamp(pf, 1);
 
-  // ---- scores: one key per lane
-  float s[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) s[r] = -INFINITY;
-  if (tid < n) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const f16x8 kv = *reinterpret_cast<const f16x8*>(&kr[g]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float kf = (float)kv[j];
-#pragma unroll
-        for (int r = 0; r < R; ++r) s[r] = fmaf(kf, sq[r][8 * g + j], s[r]);
-      }
-    }
-  }
-  stamp(pf, 2);
-#pragma unroll
-  for (int r = 0; r < R; ++r) { const float v = wave_max(s[r]); if (lane == 0) sred[wave][r] = v; }
-  __syncthreads();
-  if (tid < R) smx[tid] = fmaxf(fmaxf(sred[0][tid], sred[1][tid]), fmaxf(sred[2][tid], sred[3][tid]));
-  __syncthreads();
-  float e[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) { e[r] = (tid < n) ? __expf(s[r] - smx[r]) : 0.f; ssc[r][tid] = e[r]; }
-#pragma unroll
-  for (int r = 0; r < R; ++r) { const float v = wave_sum(e[r]); if (lane == 0) sred[wave][r] = v; }
-  __syncthreads();
-  if (tid < R) ssum[tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
-  stamp(pf, 3);
+  f16x8 qf0, qf1;
+  qf0[0] = (f16)qa0.x; qf0[1] = (f16)qa0.y; qf0[2] = (f16)qa0.z; qf0[3] = (f16)qa0.w; qf0[4] = (f16)qa1.x; qf0[5] = (f16)qa1.y; qf0[6] = (f16)qa1.z; qf0[7] = (f16)qa1.w;
+  qf1[0] = (f16)qb0.x; qf1[1] = (f16)qb0.y; qf1[2] = (f16)qb0.z; qf1[3] = (f16)qb0.w; qf1[4] = (f16)qb1.x; qf1[5] = (f16)qb1.y; qf1[6] = (f16)qb1.z; qf1[7] = (f16)qb1.w;
 
-  // ---- P.V from the prefetched V registers
-  float o[R][8];
+  // ---- scores: D[i = key][j = r]: lane holds r = l15, keys 16t + 4kq + reg
+  float lmax = -INFINITY;
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int i = 0; i < 4; ++i) {
+    const int t = wave + 4 * i;
+    if (t < ntile) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&kf[i][0]), qf0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&kf[i][1]), qf1, acc, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[r][j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int kk = kq + 32 * i;
-    if (kk < n) {
-      const f16x8 vv = *reinterpret_cast<const f16x8*>(&vr[i]);
-      float vf[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vf[j] = (float)vv[j];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float pr = ssc[r][kk];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[r][j] = fmaf(pr, vf[j], o[r][j]);
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int kl = 16 * t + 4 * kq + r4;
+        const float v = (kl < n) ? acc[r4] : -INFINITY;
+        ssc[l15][kl] = v;
+        lmax = fmaxf(lmax, v);
       }
     }
   }
-  stamp(pf, 4);
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = o[r][j];
-      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-      if (lane < 8) so[wave][r][8 * lane + j] = v;
-    }
+  smax[wave * 4 + kq][l15] = lmax;
   __syncthreads();
-  stamp(pf, 5);
+  stamp(pf, 2);
+  if (tid < 16) {
+    float mxv = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mxv = fmaxf(mxv, smax[i][tid]);
+    smx[tid] = mxv;
+  }
+  __syncthreads();
+  // ---- P = exp(S - max) as f16 (thread = key), row sums
+  {
+    const int kl = tid;
+    const bool valid = kl < 16 * ntile;
+    float e[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      e[r] = 0.f;
+      if (r < R) {
+        if (valid) e[r] = __expf(ssc[r][kl] - smx[r]);
+        sp16[r * CA_PSTR + kl] = (f16)e[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (r < R) { const float v = wave_sum(e[r]); if (lane == 0) ssumw[wave][r] = v; }
+  }
+  __syncthreads();
+  stamp(pf, 3);
+  if (tid < 16) ssum[tid] = (ssumw[0][tid] + ssumw[1][tid]) + (ssumw[2][tid] + ssumw[3][tid]);
+
+  // ---- O^T[dh][r]: wave w owns dh 16w .. 16w+15; D[i = dh][j = r]: lane holds r = l15, dh = 16w + 4kq + reg
+  f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx) {
+    if (sidx < nstep) {
+      const f16x8 pb = *reinterpret_cast<const f16x8*>(&sp16[rq * CA_PSTR + 32 * sidx + 8 * kq]);
+      oacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&vf[sidx]), pb, oacc, 0, 0, 0);
+    }
+  }
+  __syncthreads();   // ssum visible
+  stamp(pf, 4);
+  const int dh0 = 16 * wave + 4 * kq;
   if (C == 1) {
-    for (int i = tid; i < R * 64; i += 256) {
-      const int r = i >> 6, dh = i & 63;
-      const float v = (so[0][r][dh] + so[1][r][dh]) + (so[2][r][dh] + so[3][r][dh]);
-      out[(size_t)(b * R + r) * d + h * 64 + dh] = (f16)(v / ssum[r]);
+    if (l15 < R) {
+      const float inv = 1.0f / ssum[l15];
+      const f16x4 o = {(f16)(oacc[0] * inv), (f16)(oacc[1] * inv), (f16)(oacc[2] * inv), (f16)(oacc[3] * inv)};
+      *reinterpret_cast<f16x4*>(out + (size_t)(b * R + l15) * d + h * 64 + dh0) = o;
     }
     return;
   }
   // ---- split-T: publish the partial with write-through stores; the last-arriving workgroup combines
   float* pbase = part + ((size_t)(b * H + h) * C) * R * 66;
-  for (int i = tid; i < R * 64; i += 256) {
-    const int r = i >> 6, dh = i & 63;
-    const float v = (so[0][r][dh] + so[1][r][dh]) + (so[2][r][dh] + so[3][r][dh]);
-    float* pp = pbase + ((size_t)c * R + r) * 66;
-    st_sc1(pp + dh, v);
-    if (dh == 0) { st_sc1(pp + 64, smx[r]); st_sc1(pp + 65, ssum[r]); }
+  if (l15 < R) {
+    float* pp = pbase + ((size_t)c * R + l15) * 66;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) st_sc1(pp + dh0 + r4, oacc[r4]);
+    if (wave == 0 && kq == 0) { st_sc1(pp + 64, smx[l15]); st_sc1(pp + 65, ssum[l15]); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
   __syncthreads();
-  stamp(pf, 6);
+  stamp(pf, 5);
   if (tid == 0) {
     const unsigned prev = __hip_atomic_fetch_add(counters + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (prev == (unsigned)(C - 1));
-    if (last) __hip_atomic_store(counters + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    if (last) {
+      __hip_atomic_store(counters + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          // drop this CU's stale L1 lines
+    }
     s_last = last;
   }
   __syncthreads();
-  stamp(pf, 7);
+  stamp(pf, 6);
   if (!s_last) return;
-  for (int i = tid; i < R * 64; i += 256) {
-    const int r = i >> 6, dh = i & 63;
-    float M_ = -INFINITY;
-    for (int cc = 0; cc < C; ++cc) M_ = fmaxf(M_, ld_sc1(pbase + ((size_t)cc * R + r) * 66 + 64));
-    float L = 0.f, O = 0.f;
-    for (int cc = 0; cc < C; ++cc) {
-      const float* pp = pbase + ((size_t)cc * R + r) * 66;
-      const float w = __expf(ld_sc1(pp + 64) - M_);
-      L = fmaf(ld_sc1(pp + 65), w, L); O = fmaf(ld_sc1(pp + dh), w, O);
+  // one round: thread = (row r, dh pair); plain (pipelined) loads, made safe by the agent-scope acquire that lane 0
+  // executed after winning the ticket (guide §6 G16 consumer form: relaxed ticket -> ONE acquire -> barrier -> plain loads;
+  // 8-byte sc1 buffer loads were measured 4x slower than this on MI355X)
+  if (tid < R * 32) {
+    const int r = tid >> 5, dp = tid & 31;
+    float2 ml[16], ov[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      if (cc < C) {
+        const float* pp = pbase + ((size_t)cc * R + r) * 66;
+        ml[cc] = *reinterpret_cast<const float2*>(pp + 64);
+        ov[cc] = *reinterpret_cast<const float2*>(pp + 2 * dp);
+      }
     }
-    out[(size_t)(b * R + r) * d + h * 64 + dh] = (f16)(O / L);
+    float M_ = -INFINITY;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) if (cc < C) M_ = fmaxf(M_, ml[cc].x);
+    float L = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      if (cc < C) {
+        const float w = __expf(ml[cc].x - M_);
+        L = fmaf(ml[cc].y, w, L); O0 = fmaf(ov[cc].x, w, O0); O1 = fmaf(ov[cc].y, w, O1);
+      }
+    }
+    const float inv = 1.0f / L;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 o2 = {(f16)(O0 * inv), (f16)(O1 * inv)};
+    *reinterpret_cast<f16x2*>(out + (size_t)(b * R + r) * d + h * 64 + 2 * dp) = o2;
   }
+  stamp(pf, 7);
 }
 
-int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vx, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int chunks, unsigned long long* prof) {
-  if (R < 1 || R > MAX_R || chunks < 1) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
-  const int CL = cdiv(T, chunks);
-  if (CL > 256 || chunks > 16) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (<= 16 chunks of <= 256 keys)", chunks, CL); return WIS_E_UNSUPPORTED; }
-  dim3 grid(chunks, H, B), block(256);
-#define WIS_CA(RR) case RR: hipLaunchKernelGGL(dec_cross_attn_kernel<RR>, grid, block, 0, st, q, kx, vx, out, part, counters, H, d, T, chunks, CL, prof); break;
-  switch (R) { WIS_CA(1) WIS_CA(2) WIS_CA(3) WIS_CA(4) WIS_CA(5) WIS_CA(6) WIS_CA(7) WIS_CA(8) }
-#undef WIS_CA
+int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
+                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof) {
+  if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
+  const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
+  if (CL > 256 || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
+  const int used = cdiv(T, CL);                      // chunks that actually hold keys
+  hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof);
   return WIS_OK;
 }
 

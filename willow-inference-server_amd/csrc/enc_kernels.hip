@@ -213,10 +213,10 @@ struct EpiQKV {
   }
 };
 // cross-attention K/V projection of the encoder memory for ONE decoder layer:
-//   K -> Kx f16 [B][H][8][T][8]  (16-byte dh-groups contiguous along T: coalesced lane-per-key reads)
-//   V -> Vx f16 [B][H][T][64]
+//   K -> Kx f16 [B][H][8][T][8]    (16-byte dh-groups contiguous along T = the MFMA A-fragment rows of the decode kernel)
+//   V -> V^T f16 [B][H][64][Tpad]  (keys contiguous, zero padded to Tpad)
 struct EpiCrossKV {
-  const float* bias; f16* kx; f16* vx; int d; int T; int H;
+  const float* bias; f16* kx; f16* vt; int d; int T; int Tpad; int H;
   __device__ void operator()(int m, int n, f32x4 v) const {
     v += ld4(bias + n);
     const int b = m / T, t = m - b * T;
@@ -225,7 +225,9 @@ struct EpiCrossKV {
       st4h(kx + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8 + j), v);
     } else {
       const int nn = n - d, h = nn >> 6, dh = nn & 63;
-      st4h(vx + (((size_t)(b * H + h) * T + t) * 64 + dh), v);
+      f16* o = vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
     }
   }
 };
@@ -246,8 +248,8 @@ int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, 
   EpiQKV e{bias, qk, vt, d, T, Tpad, H};
   return launch_gemm_t(st, p, e);
 }
-int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vx, int d, int T, int H) {
-  EpiCrossKV e{bias, kx, vx, d, T, H};
+int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H) {
+  EpiCrossKV e{bias, kx, vt, d, T, Tpad, H};
   return launch_gemm_t(st, p, e);
 }
 

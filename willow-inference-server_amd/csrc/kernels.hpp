@@ -18,7 +18,7 @@ int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const
 int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C, int T);
 int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
 int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);
-int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vx, int d, int T, int H);
+int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H);
 int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H);
 
 // ---- decoder ---------------------------------------------------------------------------
@@ -45,20 +45,22 @@ struct GemvP {
   // GV_QKV epilogue: n < d -> q (f32 [M][d]); d <= n < 2d -> K cache; n >= 2d -> V cache
   float* q; f16* kc; f16* vc; const int* slot; const int* pos; int d; int ctx;   // cache [slots][ctx][d]
   unsigned long long* prof;      // optional phase stamps (workgroup 0)
+  int rows;                      // weight rows per workgroup tile (16 / 8 / 4; 0 => 16): must match the packing
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
-// pack W [N][K] f16 row-major -> Wp [Npad/16][K/32][64][8]; rows >= N are zero; scale rows
+// pack W [N][K] f16 row-major -> Wp [Npad/rows][K/32][4][rows][8]; matrix rows >= N are zero; scale matrix rows
 // [0, n_scale) by `scale` (folds the 1/sqrt(dh) query scaling into the projection)
-int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale);
+int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale, int rows = 16);
+int gemv_rows_for(int N, int K);     // tile height used for an [N][K] decoder matrix
 
 int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d);
 // logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr);
 // cross attention of R rows per utterance over the utterance's T encoder keys.
-//   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vx f16 [B][H][T][64] -> out f16 [B*R][d]
-int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vx, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int chunks, unsigned long long* prof = nullptr);
+//   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
+int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
+                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr);
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

@@ -171,10 +171,11 @@ int to_f16_mat(wis_model* m, const Loader& L, const std::string& name, int64_t r
 // row-major source -> MFMA-fragment packed (through a temporary f16 image)
 int to_packed(wis_model* m, const Loader& L, const std::string& name, int N, int K, f16** out, f16* tmp, int n_scale = 0, float scale = 1.f, int* npad_out = nullptr) {
   TensorSrc s; WIS_RET(L.get(name, N, K, &s));
-  const int Npad = cdiv(N, 16) * 16;
+  const int rows = gemv_rows_for(N, K);
+  const int Npad = cdiv(N, rows) * rows;
   WIS_RET(dalloc(m, out, (size_t)Npad * K));
   hipLaunchKernelGGL(convert_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, m->st, s.p, s.f16, tmp, 1, (int64_t)N, (int64_t)K, (int64_t)K, (int64_t)0, 1.f);
-  WIS_RET(launch_pack_gemv(m->st, tmp, *out, N, Npad, K, n_scale, scale));
+  WIS_RET(launch_pack_gemv(m->st, tmp, *out, N, Npad, K, n_scale, scale, rows));
   if (npad_out) *npad_out = Npad;
   return WIS_OK;
 }
@@ -297,7 +298,8 @@ int alloc_buffers(wis_model* m) {
   m->kx.resize(L); m->vx.resize(L); m->kc.resize(L); m->vc.resize(L);
   for (int l = 0; l < L; ++l) {
     WIS_RET(dalloc(m, &m->kx[l], (size_t)Bm * H * 8 * T * 8));
-    WIS_RET(dalloc(m, &m->vx[l], (size_t)Bm * H * T * 64));
+    WIS_RET(dalloc(m, &m->vx[l], (size_t)Bm * H * 64 * m->Tpad));
+    WIS_HIP_CHECK(hipMemsetAsync(m->vx[l], 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
     WIS_RET(dalloc(m, &m->kc[l], (size_t)slots * ctx * d));
     WIS_RET(dalloc(m, &m->vc[l], (size_t)slots * ctx * d));
   }
@@ -306,7 +308,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->dao, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dh, (size_t)MAX_ROWS * 4 * d));
   WIS_RET(dalloc(m, &m->logits, (size_t)MAX_ROWS * m->n_vocab_pad));
-  WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * MAX_R * 66));
+  WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * 66));
   WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
   WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bm * H * 4, m->st));
   WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
@@ -384,7 +386,7 @@ int run_cross_kv(wis_model* m, int B) {
   const wis_config_t& c = m->cfg;
   const int d = c.d_model, T = c.n_audio_ctx;
   for (int l = 0; l < c.n_dec_layers; ++l)
-    WIS_RET(launch_gemm_crosskv(m->st, gemm_plain(m->mem, d, m->dec[l].w_ckv, B * T, 2 * d, d), m->dec[l].b_ckv, m->kx[l], m->vx[l], d, T, c.n_heads));
+    WIS_RET(launch_gemm_crosskv(m->st, gemm_plain(m->mem, d, m->dec[l].w_ckv, B * T, 2 * d, d), m->dec[l].b_ckv, m->kx[l], m->vx[l], d, T, m->Tpad, c.n_heads));
   return WIS_OK;
 }
 
@@ -403,30 +405,37 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 48 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 16 : nullptr;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
     // cross-attention block
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
-    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, chunks, pr ? pr + 32 : nullptr));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 32 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
     // FFN
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 64 : nullptr;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
     memset(&g, 0, sizeof(g));
     g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
   }
   if (want_logits) {
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_gemv(st, g));
   }
   return WIS_OK;
@@ -771,12 +780,14 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
         GemvP g; memset(&g, 0, sizeof(g));
         g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.gamma = t.g; g.beta = t.be; g.Wp = t.wp; g.bias = t.b;
         g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
-        WIS_RET(launch_gemv(st, g));
+        g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
+    WIS_RET(launch_gemv(st, g));
         if (count) { ++launches; bytes += (double)t.N * t.K * 2; }
       }
     }
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.rows = gemv_rows_for(m->cfg.n_vocab, g.K);
     WIS_RET(launch_gemv(st, g));
     if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * 2; }
     return WIS_OK;
@@ -829,13 +840,14 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
   hipStream_t st = ctx_stream(c);
   if (flags & GV_QKV) { set_error("wis_op_gemv: flag 16 is internal"); return WIS_E_ARG; }
-  const int Npad = cdiv(N, 16) * 16;
+  const int Npad = cdiv(N, gemv_rows_for(N, K)) * gemv_rows_for(N, K);
   f16* wp = nullptr;
   WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Npad * K * 2));
-  int rc = launch_pack_gemv(st, reinterpret_cast<const f16*>(W), wp, N, Npad, K, 0, 1.f);
+  const int rows = gemv_rows_for(N, K);
+  int rc = launch_pack_gemv(st, reinterpret_cast<const f16*>(W), wp, N, Npad, K, 0, 1.f, rows);
   if (!rc) {
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = x; g.gamma = gamma; g.beta = beta; g.Wp = wp; g.bias = bias; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags;
+    g.x = x; g.gamma = gamma; g.beta = beta; g.Wp = wp; g.bias = bias; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags; g.rows = rows;
     rc = launch_gemv(st, g);
   }
   hipError_t e = hipStreamSynchronize(st);
