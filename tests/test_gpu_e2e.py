@@ -171,3 +171,33 @@ def test_pcm_input_matches_mel_input(tiny, golden_dir, lib):
     r_mel = model.generate(ct2.StorageView.from_array(np.ascontiguousarray(mel)), [PROMPT], beam_size=5, fixed_new_tokens=6)
     r_pcm = model._generate_chunk(model._replicas[0], x, [PROMPT], 4, 5, 224, 1.0, 1.0, True, True, 6, _lib.WIS_IN_PCM_HOST)
     assert r_mel[0].sequences_ids == r_pcm[0].sequences_ids
+
+
+def test_do_whisper_orchestrator(golden_dir):
+    """The do_whisper mirror (reference main.py:554-770): 6-tuple result, per-request model/beam selection, the long-audio
+    beam switch and the > 30 s chunking + LCS merge path (3 windows for 40 s)."""
+    from wis_hip import audio, whisper
+    from wis_hip.settings import APISettings
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.max_batch = 4
+    models = whisper.WhisperModels(settings=s, device_index=[0])
+    clip = os.path.join(golden_dir, "clips", "3sec.flac")
+    res = whisper.do_whisper(clip, "tiny", 5, "transcribe", False, "en", models=models, fixed_new_tokens=6)
+    language, text, infer_ms, translation, speedup, duration = res
+    assert language == "en" and duration == 3840 and translation is None and infer_ms > 0 and speedup == int(3840 // infer_ms)
+    assert len(res.tokens) == 6 and text == " ".join(str(t) for t in res.tokens)
+    again = whisper.do_whisper(open(clip, "rb").read(), "tiny", 5, models=models, fixed_new_tokens=6)       # bytes input, same model handle
+    assert again.tokens == res.tokens
+    g = whisper.do_whisper(clip, "tiny", 1, models=models, fixed_new_tokens=6)                              # per-request beam selection
+    assert len(g.tokens) == 6
+    with pytest.raises(ValueError):
+        whisper.do_whisper(clip, "tiny", 1, force_language="xx", models=models)
+    # 40 s of seeded noise: long mode (beam := long_beam_size) and chunking into 3 windows, merged by LCS
+    rng = np.random.default_rng(0)
+    long_pcm = (0.05 * rng.standard_normal(40 * 16000)).astype(np.float32)
+    assert len(list(audio.chunk_iter(long_pcm))) == 3
+    out = whisper.do_whisper(long_pcm, "tiny", 5, models=models, fixed_new_tokens=5)
+    assert out[5] == 40000 and 1 <= len(out.tokens) <= 15
+    det = whisper.do_whisper(clip, "tiny", 1, detect_language=True, models=models, fixed_new_tokens=4)
+    assert det[0] in __import__("wis_hip.languages", fromlist=["LANGUAGES"]).LANGUAGES

@@ -77,17 +77,21 @@ int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const f
 // =======================================================================================
 // GEMM  C[m][n] = epi( sum_k A(m)[k] * W[n][k] ),  A rows addressed as
 //   A + (m / a_rpb) * a_bs + (m % a_rpb) * a_rs     (implicit im2col for the convs).
-constexpr int BM = 128, BN = 128, BK = 32, LSTR = 40;  // LDS row pitch 40 f16 = 80 B
+constexpr int BN = 128, BK = 32, LSTR = 40;  // LDS row pitch 40 f16 = 80 B
+// BM_ = 128 (default) or 64: the 64-row variant doubles the workgroup count for the N = d GEMMs (out-proj, FFN2), which
+// would otherwise launch only ceil(1500/128) * d/128 = 120 workgroups on 256 CUs.
 
-template <class Epi>
+template <class Epi, int BM_>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
-  __shared__ __attribute__((aligned(16))) f16 sA[2][BM * LSTR];
+  constexpr int MI = BM_ / 64;                 // 32-row MFMA sub-tiles per wave along M
+  constexpr int NA = BM_ / 64;                 // 16-byte A chunks per thread per k-tile
+  __shared__ __attribute__((aligned(16))) f16 sA[2][BM_ * LSTR];
   __shared__ __attribute__((aligned(16))) f16 sW[2][BN * LSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN;
 
-  // loader mapping: thread moves two 16-byte chunks of each tile: chunk c -> row c>>2, k-offset (c&3)*8
+  // loader mapping: 16-byte chunk c -> row c>>2, k-offset (c&3)*8; W tile 512 chunks (2 per thread), A tile BM_*4 chunks
   const int lrow0 = tid >> 2, lrow1 = (tid + 256) >> 2, lkc = (tid & 3) * 8;
   int lm0 = m0 + lrow0; if (lm0 > p.M - 1) lm0 = p.M - 1;
   int lm1 = m0 + lrow1; if (lm1 > p.M - 1) lm1 = p.M - 1;
@@ -99,20 +103,20 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
   uint4 ra0, ra1, rw0, rw1;
 #define WIS_GLOAD(kt)                                                   \
   ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK);               \
-  ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK);               \
+  if (NA == 2) ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK);  \
   rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK);               \
   rw1 = *reinterpret_cast<const uint4*>(gw1 + (kt) * BK);
 #define WIS_SSTORE(buf)                                                 \
   *reinterpret_cast<uint4*>(&sA[buf][soff0]) = ra0;                     \
-  *reinterpret_cast<uint4*>(&sA[buf][soff1]) = ra1;                     \
+  if (NA == 2) *reinterpret_cast<uint4*>(&sA[buf][soff1]) = ra1;        \
   *reinterpret_cast<uint4*>(&sW[buf][soff0]) = rw0;                     \
   *reinterpret_cast<uint4*>(&sW[buf][soff1]) = rw1;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][MI];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < MI; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -124,16 +128,17 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
     if (kt + 1 < nk) { WIS_GLOAD(kt + 1) }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      f16x8 wf[2], af[2];
+      f16x8 wf[2], af[MI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
         wf[i] = *reinterpret_cast<const f16x8*>(&sW[cur][(wn * 64 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
-        af[i] = *reinterpret_cast<const f16x8*>(&sA[cur][(wm * 64 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
-      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const f16x8*>(&sA[cur][(wm * (BM_ / 2) + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
     if (kt + 1 < nk) { WIS_SSTORE(cur ^ 1) }
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (BM_ / 2) + mi * 32 + l31;
       if (m < p.M) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -161,7 +166,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
 template <class Epi>
 static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   if (p.N % BN || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%32)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(gemm_f16_kernel<Epi>, dim3(p.N / BN, cdiv(p.M, BM)), dim3(256), 0, st, p, epi);
+  // fewer than ~1 workgroup per CU with 128-row tiles -> 64-row tiles
+  if ((p.N / BN) * cdiv(p.M, 128) < 200 && p.M > 64)
+    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64>), dim3(p.N / BN, cdiv(p.M, 64)), dim3(256), 0, st, p, epi);
+  else
+    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128>), dim3(p.N / BN, cdiv(p.M, 128)), dim3(256), 0, st, p, epi);
   return WIS_OK;
 }
 
