@@ -169,7 +169,7 @@ int wis_dev_d2h(int device, void* dst, const void* src, size_t bytes);
 int wis_dev_sync(int device);
 
 /* C[M][N] = epilogue(A[M][K](lda) . W[N][K]^T + bias): the encoder MFMA GEMM.
- * flags: 1 = GELU, 2 = add residual (f32, [M][N]) , 4 = output f32 (else f16) */
+ * flags: 1 = GELU, 2 = add residual (f32, [M][N]) , 4 = output f32 (else f16), 8 = split-K x2 variant (with 2|4 only) */
 int wis_op_gemm(int device, const void* A_f16, int lda, const void* W_f16, const float* bias,
                 const float* residual, void* C, int M, int N, int K, int flags);
 /* y f16 [M][d] = LayerNorm(x f32 [M][d]) * gamma + beta, eps 1e-5 */

@@ -55,7 +55,9 @@ def test_logmel_noise_and_batch(golden_dir):
 
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,flags", [(300, 256, 288, 0), (128, 128, 32, 4), (1500, 384, 1152, 1), (257, 1280, 1280, 2 | 4),
-                                         (3000, 512, 5120, 1 | 4), (77, 128, 64, 2 | 4 | 1)])
+                                         (3000, 512, 5120, 1 | 4), (77, 128, 64, 2 | 4 | 1),
+                                         (1500, 1280, 5120, 2 | 4 | 8), (200, 128, 128, 2 | 4 | 8),      # split-K x2 (encoder FFN2)
+                                         (1500, 1280, 1280, 2 | 4), (65, 256, 64, 0)])                  # 64-row tile variant
 def test_gemm(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 7 + N)

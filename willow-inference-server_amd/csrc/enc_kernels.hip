@@ -95,11 +95,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
   const int lrow0 = tid >> 2, lrow1 = (tid + 256) >> 2, lkc = (tid & 3) * 8;
   int lm0 = m0 + lrow0; if (lm0 > p.M - 1) lm0 = p.M - 1;
   int lm1 = m0 + lrow1; if (lm1 > p.M - 1) lm1 = p.M - 1;
-  const f16* ga0 = p.A + (int64_t)(lm0 / p.a_rpb) * p.a_bs + (int64_t)(lm0 % p.a_rpb) * p.a_rs + lkc;
-  const f16* ga1 = p.A + (int64_t)(lm1 / p.a_rpb) * p.a_bs + (int64_t)(lm1 % p.a_rpb) * p.a_rs + lkc;
-  const f16* gw0 = p.W + (int64_t)(n0 + lrow0) * p.K + lkc;
-  const f16* gw1 = p.W + (int64_t)(n0 + lrow1) * p.K + lkc;
+  const f16* ga0_ = p.A + (int64_t)(lm0 / p.a_rpb) * p.a_bs + (int64_t)(lm0 % p.a_rpb) * p.a_rs + lkc;
+  const f16* ga1_ = p.A + (int64_t)(lm1 / p.a_rpb) * p.a_bs + (int64_t)(lm1 % p.a_rpb) * p.a_rs + lkc;
+  const f16* gw0_ = p.W + (int64_t)(n0 + lrow0) * p.K + lkc;
+  const f16* gw1_ = p.W + (int64_t)(n0 + lrow1) * p.K + lkc;
+  const f16 *ga0 = ga0_, *ga1 = ga1_, *gw0 = gw0_, *gw1 = gw1_;
   const int soff0 = lrow0 * LSTR + lkc, soff1 = lrow1 * LSTR + lkc;
+  if (p.klen > 0) { const int kbeg = blockIdx.z * p.klen; ga0 += kbeg; ga1 += kbeg; gw0 += kbeg; gw1 += kbeg; }
   uint4 ra0, ra1, rw0, rw1;
 #define WIS_GLOAD(kt)                                                   \
   ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK);               \
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
   WIS_GLOAD(0) WIS_SSTORE(0)
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -240,6 +242,35 @@ struct EpiCrossKV {
     }
   }
 };
+
+// split-K partial tile: fp32 [blockIdx.z][M][N]
+struct EpiPartial {
+  float* C; int N; int64_t zstride;
+  __device__ void operator()(int m, int n, f32x4 v) const { st4(C + (int64_t)blockIdx.z * zstride + (size_t)m * N + n, v); }
+};
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t zstride, const float* __restrict__ bias,
+                                     const float* resid, float* X, int64_t n4, int N) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int z = 1; z < splits; ++z) { const float4 t = reinterpret_cast<const float4*>(part + z * zstride)[i]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+    const int n = (int)((i * 4) % N);
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    const float4 r = reinterpret_cast<const float4*>(resid)[i];
+    reinterpret_cast<float4*>(X)[i] = make_float4(a.x + b.x + r.x, a.y + b.y + r.y, a.z + b.z + r.z, a.w + b.w + r.w);
+  }
+}
+int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float* scratch, const float* bias, const float* resid, float* X) {
+  GemmP p = p0;
+  if (splits < 2 || p.K % (splits * BK) || p.N % BN) { set_error("splitk: K=%d splits=%d unsupported", p.K, splits); return WIS_E_UNSUPPORTED; }
+  p.klen = p.K / splits;
+  const int64_t zs = (int64_t)p.M * p.N;
+  EpiPartial e{scratch, p.N, zs};
+  hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128>), dim3(p.N / BN, cdiv(p.M, 128), splits), dim3(256), 0, st, p, e);
+  const int64_t n4 = zs / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, scratch, splits, zs, bias, resid, X, n4, p.N);
+  return WIS_OK;
+}
 
 int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const float* resid, void* C, int flags) {
   EpiGeneric e{bias, resid, C, p.N, flags};

@@ -9,12 +9,17 @@ struct GemmP {
   const f16* A; int64_t a_bs; int a_rs; int a_rpb;   // A row m -> A + (m / a_rpb)*a_bs + (m % a_rpb)*a_rs
   const f16* W;                                      // [N][K] row-major
   int M, N, K;
+  int klen;                                          // split-K: K range per blockIdx.z slice (0 = whole K, gridDim.z = 1)
 };
 static inline GemmP gemm_plain(const f16* A, int lda, const f16* W, int M, int N, int K) {
-  GemmP p; p.A = A; p.a_bs = 0; p.a_rs = lda; p.a_rpb = 0x7fffffff; p.W = W; p.M = M; p.N = N; p.K = K; return p;
+  GemmP p; p.A = A; p.a_bs = 0; p.a_rs = lda; p.a_rpb = 0x7fffffff; p.W = W; p.M = M; p.N = N; p.K = K; p.klen = 0; return p;
 }
 int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, f16* y, int M, int d);
 int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const float* resid, void* C, int flags);
+// split-K GEMM for deep-K / narrow-N shapes: `splits` K-slices write fp32 partial tiles to `scratch` ([splits][M][N]), then
+// one elementwise pass adds the slices + bias + residual into X (fp32, may alias resid).  Keeps dense 128x128 tiles and still
+// launches >= 1 workgroup per CU.
+int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p, int splits, float* scratch, const float* bias, const float* resid, float* X);
 int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C, int T);
 int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
 int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);

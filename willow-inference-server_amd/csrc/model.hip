@@ -104,7 +104,7 @@ struct wis_model {
   // activations
   int Tpad;
   f16 *img, *c1, *xn, *qk, *vt, *ao, *hbuf, *mem;
-  float* x;
+  float* x; float* skbuf;
   std::vector<f16*> kx, vx;             // per decoder layer cross K / V
   std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d]
   // decode state
@@ -292,6 +292,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->ao, (size_t)Bm * T * d));
   WIS_RET(dalloc(m, &m->hbuf, (size_t)Bm * T * 4 * d));
   WIS_RET(dalloc(m, &m->mem, (size_t)Bm * T * d));
+  WIS_RET(dalloc(m, &m->skbuf, (size_t)2 * Bm * T * d));
   WIS_HIP_CHECK(hipMemsetAsync(m->img, 0, (size_t)Bm * 3002 * 96 * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->c1, 0, (size_t)Bm * 3002 * d * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->vt, 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
@@ -362,11 +363,11 @@ int run_encoder(wis_model* m, int B) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, M = B * T;
   {  // conv1: implicit im2col over the [3002][96] image, K = 288
-    GemmP p; p.A = m->img; p.a_bs = (int64_t)3002 * 96; p.a_rs = 96; p.a_rpb = 3000; p.W = m->w_conv1; p.M = B * 3000; p.N = d; p.K = 288;
+    GemmP p; p.klen = 0; p.A = m->img; p.a_bs = (int64_t)3002 * 96; p.a_rs = 96; p.a_rpb = 3000; p.W = m->w_conv1; p.M = B * 3000; p.N = d; p.K = 288;
     WIS_RET(launch_gemm_conv1(st, p, m->b_conv1, m->c1, 3000));
   }
   {  // conv2 (stride 2) + GELU + positions -> fp32 residual stream
-    GemmP p; p.A = m->c1; p.a_bs = (int64_t)3002 * d; p.a_rs = 2 * d; p.a_rpb = T; p.W = m->w_conv2; p.M = M; p.N = d; p.K = 3 * d;
+    GemmP p; p.klen = 0; p.A = m->c1; p.a_bs = (int64_t)3002 * d; p.a_rs = 2 * d; p.a_rpb = T; p.W = m->w_conv2; p.M = M; p.N = d; p.K = 3 * d;
     WIS_RET(launch_gemm_conv2(st, p, m->b_conv2, m->enc_pos, m->x, T));
   }
   for (int l = 0; l < c.n_enc_layers; ++l) {
@@ -377,7 +378,10 @@ int run_encoder(wis_model* m, int B) {
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->ao, d, w.w_out, M, d, d), w.b_out, m->x, m->x, 2 | 4));
     WIS_RET(launch_layernorm(st, m->x, w.ln2_g, w.ln2_b, m->xn, M, d));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->xn, d, w.w_f1, M, 4 * d, d), w.b_f1, nullptr, m->hbuf, 1));
-    WIS_RET(launch_gemm_generic(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), w.b_f2, m->x, m->x, 2 | 4));
+    if ((d / 128) * cdiv(M, 128) < 200)   // too few 128x128 tiles for 256 CUs: split K in two, keep the dense tile
+      WIS_RET(launch_gemm_splitk_resid(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), 2, m->skbuf, w.b_f2, m->x, m->x));
+    else
+      WIS_RET(launch_gemm_generic(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), w.b_f2, m->x, m->x, 2 | 4));
   }
   WIS_RET(launch_layernorm(st, m->x, m->enc_ln_g, m->enc_ln_b, m->mem, M, d));
   return WIS_OK;
@@ -817,9 +821,22 @@ int wis_dev_sync(int device) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_H
 
 int wis_op_gemm(int device, const void* A, int lda, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K, int flags) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
-  WIS_RET(launch_gemm_generic(ctx_stream(c), gemm_plain(reinterpret_cast<const f16*>(A), lda, reinterpret_cast<const f16*>(W), M, N, K), bias, residual, C, flags));
+  hipStream_t st = ctx_stream(c);
+  if (flags & 8) {   // split-K = 2 path of the encoder's FFN2: requires bias, residual and fp32 output
+    if (!bias || !residual || (flags & 7) != (2 | 4)) { set_error("wis_op_gemm: split-K needs bias, residual, flags 2|4|8"); return WIS_E_ARG; }
+    float* scratch = nullptr;
+    WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t)2 * M * N * 4));
+    int rc = launch_gemm_splitk_resid(st, gemm_plain(reinterpret_cast<const f16*>(A), lda, reinterpret_cast<const f16*>(W), M, N, K), 2, scratch, bias, residual,
+                                      reinterpret_cast<float*>(C));
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(scratch);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("wis_op_gemm: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+    return WIS_OK;
+  }
+  WIS_RET(launch_gemm_generic(st, gemm_plain(reinterpret_cast<const f16*>(A), lda, reinterpret_cast<const f16*>(W), M, N, K), bias, residual, C, flags));
   WIS_HIP_CHECK(hipGetLastError());
-  WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
+  WIS_HIP_CHECK(hipStreamSynchronize(st));
   return WIS_OK;
 }
 int wis_op_layernorm(int device, const float* x, const float* gamma, const float* beta, void* y, int M, int d) {
