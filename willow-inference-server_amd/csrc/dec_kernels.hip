@@ -74,12 +74,14 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 // previous kernel) are issued FIRST, then a 16-deep prefetch of this wave's weight fragments (HBM);
 // vmcnt retires in order, so LayerNorm statistics and the f16 staging of x run from registers while
 // the weight stream is in flight, and the MFMAs consume the fragments as they land, refilling the ring.
-// GV_PF (template): weight fragments in flight per wave: 16 (16 KiB) by default, 40 for the K >= 2176 matrices
-// (FFN2) so that their whole per-wave stream is ONE latency round instead of three.
+// SC (template): compile-time k-steps per wave (K / 128) for the common single-chunk shapes {3,4,6,8,10} so the prefetch and
+// the MFMA loop are straight-line code (every runtime `u < S` guard would be a scalar branch around one load); SC = 0 is the
+// generic ring of 16 fragments with refill.
 
 // MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
-template <int MB, int MODE, int GV_PF>
+template <int MB, int MODE, int SC, int RM>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
+  constexpr int GV_PF = SC > 0 ? SC : 16;
   constexpr int rows = 16;   // full MFMA A fragments (4/8-row tiles were measured: more workgroups only add prologue work)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = p.M, K = p.K;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = blockIdx.x;
   const int ksteps = K / 32;
-  const int S = KC / 128;                        // k-steps per wave per chunk
+  const int S = SC > 0 ? SC : KC / 128;          // k-steps per wave per chunk
   const int ksl0 = wave * S;                     // first chunk-local k-step of this wave
   // fragment (tile, k-step) = 4*rows 16-byte pieces: piece (kq, row) at kq*rows + row; lanes with row >= rows stay zero
   const bool wact = (lane & 15) < rows;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   // owns float4 columns k4 = tid, tid + 256 of every row (no index arithmetic), statistics are a single shifted pass
   // (c = x[r][0]: var = E[(x-c)^2] - E[x-c]^2) so the block needs ONE reduction + barrier before staging.
   constexpr bool fast = MODE == 1;
-  constexpr int RMAX = fast ? 8 : 1;
+  constexpr int RMAX = fast ? RM : 1;        // RM in {3, 5, 8}: smallest that holds M (rows >= M are clamped duplicates)
   float4 xv[RMAX][2], gv[2], bv[2];
   float cshift[RMAX];
   unsigned long long* pf = (blockIdx.x == 0 && tid == 0) ? p.prof : nullptr;
@@ -119,11 +121,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       if (k4 < k4n) {
         gv[j] = g4[k4]; bv[j] = b4[k4];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) if (r < M) xv[r][j] = x4[(size_t)r * k4n + k4];
+        for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; xv[r][j] = x4[(size_t)rr * k4n + k4]; }   // rows >= M: clamped duplicates
       }
     }
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) cshift[r] = (r < M) ? reinterpret_cast<const float*>(p.x)[(size_t)r * K] : 0.f;
+    for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; cshift[r] = reinterpret_cast<const float*>(p.x)[(size_t)rr * K]; }
   }
   // f16 activations (attention / FFN hidden output of the previous kernel): same idea, up to 13 x 16 B per thread
   constexpr bool fastx = MODE == 2;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   {
     const u32x4* wq = wp4 + (size_t)ksl0 * wstep;
 #pragma unroll
-    for (int u = 0; u < GV_PF; ++u) { wf[u] = wzero; if (u < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep); }
+    for (int u = 0; u < GV_PF; ++u) { wf[u] = wzero; if ((SC > 0 || u < S) && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep); }
   }
 
   stamp(pf, 1);
@@ -148,29 +150,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       sa[r] = 0.f; sb[r] = 0.f;
-      if (r < M) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (tid + 256 * j < k4n) {
-            const float a = xv[r][j].x - cshift[r], b = xv[r][j].y - cshift[r], c = xv[r][j].z - cshift[r], e = xv[r][j].w - cshift[r];
-            sa[r] += (a + b) + (c + e); sb[r] += (a * a + b * b) + (c * c + e * e);
-          }
+      for (int j = 0; j < 2; ++j) {
+        if (tid + 256 * j < k4n) {
+          const float a = xv[r][j].x - cshift[r], b = xv[r][j].y - cshift[r], c = xv[r][j].z - cshift[r], e = xv[r][j].w - cshift[r];
+          sa[r] += (a + b) + (c + e); sb[r] += (a * a + b * b) + (c * c + e * e);
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-      if (r < M) {
-        const float ta = wave_sum(sa[r]), tb = wave_sum(sb[r]);
-        if (lane == 0) { sred[wave * 16 + 2 * r] = ta; sred[wave * 16 + 2 * r + 1] = tb; }
-      }
+      const float ta = wave_sum(sa[r]), tb = wave_sum(sb[r]);
+      if (lane == 0) { sred[wave * 16 + 2 * r] = ta; sred[wave * 16 + 2 * r + 1] = tb; }
     }
     __syncthreads();
     stamp(pf, 2);
     const float invK = 1.0f / (float)K;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-      if (r < M) {
+      {
+        const int rr = r < M ? r : M - 1;       // clamped rows rewrite row M-1 with identical values (benign)
         const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) * invK;
         const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) * invK;
         const float mu = cshift[r] + A;
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
             f16x4 o;
             o[0] = (f16)((xv[r][j].x - mu) * rs * gv[j].x + bv[j].x); o[1] = (f16)((xv[r][j].y - mu) * rs * gv[j].y + bv[j].y);
             o[2] = (f16)((xv[r][j].z - mu) * rs * gv[j].z + bv[j].z); o[3] = (f16)((xv[r][j].w - mu) * rs * gv[j].w + bv[j].w);
-            *reinterpret_cast<f16x4*>(xs + (size_t)r * xstr + k4 * 4) = o;
+            *reinterpret_cast<f16x4*>(xs + (size_t)rr * xstr + k4 * 4) = o;
           }
         }
       }
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * wstep;
     if (kc0 > 0) {
 #pragma unroll
-      for (int u = 0; u < GV_PF; ++u) if (u < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep);
+      for (int u = 0; u < GV_PF; ++u) if ((SC > 0 || u < S) && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep);
     }
     if (!fast && !fastx) {
       // stage x[:, kc0:kc0+KC] as f16
@@ -258,17 +257,29 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
     __syncthreads();
     stamp(pf, 3);
-    for (int base = 0; base < S; base += GV_PF) {
+    if (SC > 0) {
 #pragma unroll
       for (int u = 0; u < GV_PF; ++u) {
-        if (base + u < S) {
-          const f16x8 a = *reinterpret_cast<const f16x8*>(&wf[u]);
+        const f16x8 a = *reinterpret_cast<const f16x8*>(&wf[u]);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + base + u) * 32);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb, acc[mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) {
+          const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + u) * 32);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb, acc[mb], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int base = 0; base < S; base += GV_PF) {
+#pragma unroll
+        for (int u = 0; u < GV_PF; ++u) {
+          if (base + u < S) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(&wf[u]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + base + u) * 32);
+              acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb, acc[mb], 0, 0, 0);
+            }
+            if (base + u + GV_PF < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)(base + u + GV_PF) * wstep);
           }
-          if (base + u + GV_PF < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)(base + u + GV_PF) * wstep);
         }
       }
     }
@@ -342,12 +353,17 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
     if ((p.flags & GV_LN) && p.M <= 8 && p.K <= 2048) mode = 1;
     else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
   }
-  const bool deep = false;              // (40-deep variant kept for experiments; see gemv_rows_for)
-#define WIS_GV(MBv, MODEv) do { if (deep && MODEv != 1) hipLaunchKernelGGL((gemv_kernel<MBv, (MODEv == 1 ? 0 : MODEv), 40>), grid, block, lds, st, pp, KC); \
-                                else hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, 16>), grid, block, lds, st, pp, KC); } while (0)
-  if (MB == 1) { if (mode == 1) WIS_GV(1, 1); else if (mode == 2) WIS_GV(1, 2); else WIS_GV(1, 0); }
-  else if (MB == 2) { if (mode == 2) WIS_GV(2, 2); else WIS_GV(2, 0); }
-  else { if (mode == 2) WIS_GV(3, 2); else WIS_GV(3, 0); }
+  const int sc = (KC == p.K && (p.K / 128 == 3 || p.K / 128 == 4 || p.K / 128 == 6 || p.K / 128 == 8 || p.K / 128 == 10)) ? p.K / 128 : 0;
+#define WIS_GV(MBv, MODEv, SCv, RMv) hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv>), grid, block, lds, st, pp, KC)
+#define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \
+                                                      case 8: WIS_GV(MBv, MODEv, 8, RMv); break; case 10: WIS_GV(MBv, MODEv, 10, RMv); break; default: WIS_GV(MBv, MODEv, 0, RMv); } } while (0)
+  if (MB == 1) {
+    if (mode == 1) { if (p.M <= 3) WIS_GV_SC(1, 1, 3); else if (p.M <= 5) WIS_GV_SC(1, 1, 5); else WIS_GV_SC(1, 1, 8); }
+    else if (mode == 2) WIS_GV_SC(1, 2, 1); else WIS_GV_SC(1, 0, 1);
+  }
+  else if (MB == 2) { if (mode == 2) WIS_GV(2, 2, 0, 1); else WIS_GV(2, 0, 0, 1); }
+  else { if (mode == 2) WIS_GV(3, 2, 0, 1); else WIS_GV(3, 0, 0, 1); }
+#undef WIS_GV_SC
 #undef WIS_GV
   return WIS_OK;
 }
@@ -486,6 +502,9 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 }
 constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16-byte aligned, bank-skewed)
 
+// TPW = key tiles per wave (CL / 64): 2 for 128-key chunks, 4 for 256-key chunks; loads are unconditional with clamped
+// addresses (masked by `kl < n` below), so the issue phase is straight-line code.
+template <int TPW>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
                                                              int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof) {
@@ -506,23 +525,19 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   const float* qp = q + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
   const float4 qa0 = *reinterpret_cast<const float4*>(qp), qa1 = *reinterpret_cast<const float4*>(qp + 4);
   const float4 qb0 = *reinterpret_cast<const float4*>(qp + 32), qb1 = *reinterpret_cast<const float4*>(qp + 36);
-  const int ntile = (n + 15) >> 4;
   const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
-  u32x4 kf[4][2];
+  u32x4 kf[TPW][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int t = wave + 4 * i;
-    if (t < ntile) {
-      int key = klo + 16 * t + l15; if (key > T - 1) key = T - 1;
+  for (int i = 0; i < TPW; ++i) {
+    int key = klo + 16 * (wave + 4 * i) + l15; if (key > T - 1) key = T - 1;      // clamped; masked below
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
-    }
+    for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
   }
-  const int nstep = (n + 31) >> 5;
+  constexpr int NSTEP = 2 * TPW;                      // 32-key P.V steps per chunk; V^T is zero padded up to Tpad >= chunks * CL
   const f16* vb = vt + ((size_t)(b * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
-  u32x4 vf[8];
+  u32x4 vf[NSTEP];
 #pragma unroll
-  for (int sidx = 0; sidx < 8; ++sidx) if (sidx < nstep) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
+  for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
   stamp(pf, 1);
 
   f16x8 qf0, qf1;
@@ -532,9 +547,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // ---- scores: D[i = key][j = r]: lane holds r = l15, keys 16t + 4kq + reg
   float lmax = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TPW; ++i) {
     const int t = wave + 4 * i;
-    if (t < ntile) {
+    {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&kf[i][0]), qf0, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&kf[i][1]), qf1, acc, 0, 0, 0);
@@ -560,7 +575,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // ---- P = exp(S - max) as f16 (thread = key), row sums
   {
     const int kl = tid;
-    const bool valid = kl < 16 * ntile;
+    const bool valid = kl < 64 * TPW;
     float e[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -580,8 +595,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // ---- O^T[dh][r]: wave w owns dh 16w .. 16w+15; D[i = dh][j = r]: lane holds r = l15, dh = 16w + 4kq + reg
   f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int sidx = 0; sidx < 8; ++sidx) {
-    if (sidx < nstep) {
+  for (int sidx = 0; sidx < NSTEP; ++sidx) {
+    {
       const f16x8 pb = *reinterpret_cast<const f16x8*>(&sp16[rq * CA_PSTR + 32 * sidx + 8 * kq]);
       oacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&vf[sidx]), pb, oacc, 0, 0, 0);
     }
@@ -657,9 +672,10 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof) {
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
-  if (CL > 256 || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
+  if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
-  hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof);
+  if (CL <= 128) hipLaunchKernelGGL(dec_cross_attn_kernel<2>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof);
+  else hipLaunchKernelGGL(dec_cross_attn_kernel<4>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof);
   return WIS_OK;
 }
 

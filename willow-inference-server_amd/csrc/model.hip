@@ -399,7 +399,7 @@ int run_cross_kv(wis_model* m, int B) {
 int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
-  int chunks = 256 / (B * H); if (chunks < 6) chunks = 6; if (chunks > 12) chunks = 12;   // <= 256 keys per workgroup
+  const int chunks = (B * H * 12 <= 512) ? 12 : 6;   // 128-key chunks while that gives <= 2 workgroups per CU, else 256-key chunks
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
