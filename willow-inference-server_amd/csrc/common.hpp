@@ -65,6 +65,20 @@ __device__ __forceinline__ float wave_max(float v) {
   const float a = readlane_f(v, 0), b = readlane_f(v, 16), c = readlane_f(v, 32), d = readlane_f(v, 48);
   return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+// wave-wide best of (value descending, index ascending): returns the winning pair on every lane
+__device__ __forceinline__ void wave_argbest(float& v, int& idx) {
+  const float mx = wave_max(v);
+  const int mi = wave_min_i(v == mx ? idx : 0x7fffffff);
+  v = mx; idx = mi;
+}
 // shader-clock stamp for the optional phase profiler (wis_debug_phase_cycles)
 __device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
   if (prof) prof[i] = __builtin_amdgcn_s_memtime();

@@ -686,16 +686,18 @@ __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { ret
 __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restrict__ logits, const float* __restrict__ bias_all,
                                                           const float* __restrict__ bias_begin, const int* __restrict__ step_u,
                                                           float* __restrict__ st_max, float* __restrict__ st_sum,
-                                                          float* __restrict__ st_val, int* __restrict__ st_idx, SampleCfg cfg) {
+                                                          float* __restrict__ st_val, int* __restrict__ st_idx, SampleCfg cfg,
+                                                          int lr_b, int lr_j, int lr_off) {
   constexpr int PT = 16;   // values per thread: supports n_vocab <= 16*256*16
-  __shared__ float sv[4]; __shared__ int si[4];
-  __shared__ float s_bv; __shared__ int s_bi;
+  __shared__ float sv[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, m = blockIdx.y, b = m / cfg.beam;
   const int step = step_u[b];
   const int CHL = cdiv(cfg.n_vocab, STAT_CHUNKS);
   const int lo = c * CHL, hi = (lo + CHL < cfg.n_vocab) ? lo + CHL : cfg.n_vocab;
-  const float* row = logits + (size_t)m * cfg.n_vocab_pad;
+  // logits row of (utterance b, beam j): decode steps b*beam + j; the merged prefill+first step samples every beam from the
+  // utterance's last prompt row (beams > 0 carry cum = -inf there)
+  const float* row = logits + (size_t)(b * lr_b + (m - b * cfg.beam) * lr_j + lr_off) * cfg.n_vocab_pad;
   const bool first = (step == 0) && cfg.suppress_blank;
   const bool mask_eot = cfg.fixed_new > 0 && step < cfg.fixed_new;
   const bool force_eot = cfg.fixed_new > 0 && step >= cfg.fixed_new;
@@ -730,7 +732,9 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
   __syncthreads();
   if (tid == 0) { st_max[m * STAT_CHUNKS + c] = mx; st_sum[m * STAT_CHUNKS + c] = (sv[0] + sv[1]) + (sv[2] + sv[3]); }
 
-  // top-n_cand of the chunk in (value desc, index asc) order: n_cand rounds of block arg-best
+  // top-n_cand of the chunk in (value desc, index asc) order: n_cand rounds of block arg-best (DPP wave reduction,
+  // one barrier per round with a double-buffered 4-entry LDS exchange)
+  __shared__ float xv[2][4]; __shared__ int xi[2][4];
   float pv = INFINITY; int pi = -1;   // previous pick
   for (int rnd = 0; rnd < cfg.n_cand; ++rnd) {
     float bv = -INFINITY; int bi = 0x7fffffff;
@@ -743,30 +747,25 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
         if (better(pv, pi, v, nidx) && better(v, nidx, bv, bi)) { bv = v; bi = nidx; }
       }
     }
+    wave_argbest(bv, bi);
+    const int pb = rnd & 1;
+    if (lane == 0) { xv[pb][wave] = bv; xi[pb][wave] = bi; }
+    __syncthreads();
+    float fv = xv[pb][0]; int fi = xi[pb][0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-    }
-    __syncthreads();
-    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
-    __syncthreads();
+    for (int w = 1; w < 4; ++w) if (better(xv[pb][w], xi[pb][w], fv, fi)) { fv = xv[pb][w]; fi = xi[pb][w]; }
     if (tid == 0) {
-      float fv = sv[0]; int fi = si[0];
-      for (int w = 1; w < 4; ++w) if (better(sv[w], si[w], fv, fi)) { fv = sv[w]; fi = si[w]; }
-      s_bv = fv; s_bi = fi;
       st_val[((size_t)m * STAT_CHUNKS + c) * cfg.n_cand + rnd] = fv;
       st_idx[((size_t)m * STAT_CHUNKS + c) * cfg.n_cand + rnd] = fi;
     }
-    __syncthreads();
-    pv = s_bv; pi = s_bi;
+    pv = fv; pi = fi;
   }
 }
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
-                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg) {
+                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg, int lr_b, int lr_j, int lr_off) {
   if (cdiv(cfg.n_vocab, STAT_CHUNKS) > 16 * 256) { set_error("logit_stats: vocab too large"); return WIS_E_UNSUPPORTED; }
   hipLaunchKernelGGL(logit_stats_kernel, dim3(STAT_CHUNKS, B * cfg.beam), dim3(256), 0, st, logits, bias_all, bias_begin, step_u,
-                     st_max, st_sum, st_val, st_idx, cfg);
+                     st_max, st_sum, st_val, st_idx, cfg, lr_b, lr_j, lr_off);
   return WIS_OK;
 }
 
@@ -823,11 +822,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
       const float v = pool_v[i]; const int id = pool_id[i];
       if (better(pv, pi, v, id) && better(v, id, bv, bi)) { bv = v; bi = id; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-    }
+    wave_argbest(bv, bi);
     if (lane == 0) { cand_v[rnd] = bv; cand_word[rnd] = bi % V; cand_org[rnd] = bi / V; }
     pv = bv; pi = bi;
   }
@@ -911,6 +906,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
       bs.cum[r0 + j] = nb_cum[j];
       rm.tok[r0 + j] = nb_tok[j];
       rm.pos[r0 + j] = npos;
+      rm.slot[r0 + j] = r0 + j;                    // decode rows own their KV slot (the merged first step ran on prompt rows)
     }
   }
   if (lane == 0) bs.step_u[b] = step + 1;

@@ -74,7 +74,8 @@ struct SampleCfg {
 };
 constexpr int STAT_CHUNKS = 16;
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
-                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg);
+                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg,
+                       int lr_b, int lr_j, int lr_off);   // logits row of (b, j) = b*lr_b + j*lr_j + lr_off
 struct BeamState {
   int* step_u;      // [B] generated-token count so far
   int* done;        // [B]

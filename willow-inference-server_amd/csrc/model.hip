@@ -546,7 +546,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   const wis_config_t& c = m->cfg;
   const int beam = o->beam_size < 1 ? 1 : o->beam_size;
   WIS_RET(check_batch(m, B, beam));
-  if (P < 1 || P - 1 > MAX_R || B * (P - 1) > MAX_ROWS) { set_error("prompt length %d unsupported (1..%d)", P, MAX_R + 1); return WIS_E_UNSUPPORTED; }
+  if (P < 1 || P > 16 || B * P > MAX_ROWS) { set_error("prompt length %d unsupported (1..16, B*P <= %d)", P, MAX_ROWS); return WIS_E_UNSUPPORTED; }
   int max_new = o->max_new_tokens > 0 ? o->max_new_tokens : std::min(c.n_text_ctx / 2, c.n_text_ctx - P);
   if (max_new > 256) max_new = 256;
   if (P - 1 + max_new > c.n_text_ctx) max_new = c.n_text_ctx - (P - 1);
@@ -566,9 +566,10 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   // ---- decode state
   const int Mrows = B * beam;
   {
+    // ancestry: every prompt position (0..P-1) of every beam lives in the utterance's first slot; later positions are own
     std::vector<int> anc((size_t)Mrows * ctx);
     for (int r = 0; r < Mrows; ++r)
-      for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = (p < P - 1) ? (r / beam) * beam : r;
+      for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = (p < P) ? (r / beam) * beam : r;
     std::vector<float> cum(Mrows);
     for (int r = 0; r < Mrows; ++r) cum[r] = (r % beam == 0) ? 0.f : -INFINITY;   // CT2 GPU path: beams tiled up front, scores [0, -inf, ...]
     WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, st));
@@ -580,20 +581,6 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     WIS_HIP_CHECK(hipMemsetAsync(m->bs.out_len, 0, (size_t)B * 4, st));
     WIS_HIP_CHECK(hipStreamSynchronize(st));   // host vectors go out of scope
   }
-  // ---- prefill: prompt[:-1] through the decoder, one pass, rows (b, i)
-  if (P > 1) {
-    const int R = P - 1;
-    std::vector<int> tok(B * R), pos(B * R), slot(B * R), ls(B * R);
-    for (int b = 0; b < B; ++b) for (int i = 0; i < R; ++i) { tok[b * R + i] = prompt[b * P + i]; pos[b * R + i] = i; slot[b * R + i] = b * beam; ls[b * R + i] = b * beam; }
-    WIS_RET(upload_rows(m, tok, pos, slot, ls));
-    WIS_RET(dec_forward(m, B * R, R, B, false, beam, 0));
-  }
-  WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
-  {
-    std::vector<int> tok(Mrows), pos(Mrows), slot(Mrows), ls(Mrows);
-    for (int r = 0; r < Mrows; ++r) { tok[r] = prompt[(r / beam) * P + P - 1]; pos[r] = P - 1; slot[r] = r; ls[r] = r; }
-    WIS_RET(upload_rows(m, tok, pos, slot, ls));
-  }
   SampleCfg sc; memset(&sc, 0, sizeof(sc));
   sc.n_vocab = c.n_vocab; sc.n_vocab_pad = m->n_vocab_pad; sc.eot = c.eot; sc.beam = beam; sc.n_cand = 2 * beam; sc.max_new = max_new;
   sc.fixed_new = o->fixed_new_tokens; sc.suppress_blank = o->suppress_blank; sc.greedy = beam == 1;
@@ -603,11 +590,24 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   if (sc.max_candidates > sc.max_hyp - beam) sc.max_candidates = sc.max_hyp - beam > 0 ? sc.max_hyp - beam : 1;
   // CT2: allow_early_exit = patience == 1 && length_penalty == 0 && coverage_penalty == 0
   sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
+  const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
+
+  // ---- prefill + FIRST decode step in one pass: all P prompt tokens of an utterance are rows (b, i) at positions i in the
+  // utterance's first KV slot (causal by position); the logits of the last prompt row seed the beams (CT2 forwards
+  // prompt[:-1] and then feeds prompt[-1] as the first decoder input — the same arithmetic, one weight pass instead of two)
+  {
+    std::vector<int> tok(B * P), pos(B * P), slot(B * P), ls(B * P);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) { tok[b * P + i] = prompt[b * P + i]; pos[b * P + i] = i; slot[b * P + i] = b * beam; ls[b * P + i] = b * beam; }
+    WIS_RET(upload_rows(m, tok, pos, slot, ls));
+    WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
+    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1));
+    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc));
+  }
+  WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
 
   auto one_step = [&]() -> int {
     WIS_RET(dec_forward(m, Mrows, beam, B, true, beam, 1));
-    WIS_RET(launch_logit_stats(st, m->logits, o->suppress_default ? m->bias_all : nullptr, m->bias_begin, m->bs.step_u,
-                               m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc));
+    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, beam, 1, 0));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc));
     return WIS_OK;
   };
@@ -632,21 +632,23 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     }
   }
   int sync_every = o->sync_every > 0 ? o->sync_every : 4;
-  int steps = 0;
+  int steps = 1;            // the first step ran with the prefill pass
   int* h_done = m->h_pin;   // pinned
   *h_done = 0;
   // with the measurement convention the step count is known: fixed_new tokens + the forced EOT
   const int known = (sc.fixed_new > 0) ? std::min(max_new, sc.fixed_new + 1) : 0;
-  while (steps < max_new) {
-    int burst = known ? known - steps : std::min(sync_every, max_new - steps);
-    if (burst <= 0) break;
-    for (int i = 0; i < burst; ++i) {
-      if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
+  const int limit = known ? known : max_new;
+  for (;;) {
+    if (steps < limit) {
+      const int burst = known ? limit - steps : std::min(sync_every, limit - steps);
+      for (int i = 0; i < burst; ++i) {
+        if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
+      }
+      steps += burst;
     }
-    steps += burst;
     WIS_HIP_CHECK(hipMemcpyAsync(h_done, m->bs.all_done, 4, hipMemcpyDeviceToHost, st));
     WIS_HIP_CHECK(hipStreamSynchronize(st));
-    if (*h_done >= B) break;
+    if (*h_done >= B || steps >= limit) break;
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
   if (*h_done < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, *h_done, B); return WIS_E_STATE; }
