@@ -54,10 +54,10 @@ def test_logmel_noise_and_batch(golden_dir):
 
 
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 288, 0), (128, 128, 32, 4), (1500, 384, 1152, 1), (257, 1280, 1280, 2 | 4),
+@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 320, 0), (128, 128, 64, 4), (1500, 384, 1152, 1), (257, 1280, 1280, 2 | 4),
                                          (3000, 512, 5120, 1 | 4), (77, 128, 64, 2 | 4 | 1),
                                          (1500, 1280, 5120, 2 | 4 | 8), (200, 128, 128, 2 | 4 | 8),      # split-K x2 (encoder FFN2)
-                                         (1500, 1280, 1280, 2 | 4), (65, 256, 64, 0)])                  # 64-row tile variant
+                                         (1500, 1280, 1280, 2 | 4), (65, 256, 64, 0), (1500, 3840, 1280, 0), (3000, 1280, 320, 1)])   # 64-row tiles; QKV / conv1 shapes
 def test_gemm(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 7 + N)
@@ -84,26 +84,28 @@ def test_gemm(lib, M, N, K, flags):
 
 def test_gemm_implicit_im2col_conv(lib):
     """conv1d(k=3, pad=1, stride s) as a GEMM over overlapping rows of the zero-padded time-major image
-    is what the encoder does; checked here through wis_op_gemm's lda (row pitch C*s, K = 3C)."""
+    is what the encoder does; checked here through wis_op_gemm's lda (row pitch C*s, K = 3C rounded up to the 64-deep
+    k-tile with zero weight columns, exactly like the engine's conv1: 288 -> 320)."""
     import torch
     import torch.nn.functional as F
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(5)
-    Cin, Cout, T = 96, 128, 300
-    for stride in (1, 2):
-        x = (rng.standard_normal((Cin, T)) * 0.5).astype(np.float16)
-        w = (rng.standard_normal((Cout, Cin, 3)) * 0.1).astype(np.float16)
-        ref = F.conv1d(torch.from_numpy(x.astype(np.float32))[None], torch.from_numpy(w.astype(np.float32)), stride=stride, padding=1)[0].numpy().T
-        img = np.zeros((T + 2, Cin), np.float16); img[1:T + 1] = x.T
-        wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(Cout, 3 * Cin))     # [out][k*C + c]
-        Tout = ref.shape[0]
-        dA, dW = DevBuf.from_numpy(img), DevBuf.from_numpy(wp)
-        dC = DevBuf(Tout * Cout * 4)
-        check(lib.wis_op_gemm(0, dA.ptr, Cin * stride, dW.ptr, None, None, dC.ptr, Tout, Cout, 3 * Cin, 4))
-        out = dC.to_numpy(np.float32, (Tout, Cout))
-        e = _relerr(out, ref)
-        print(f"conv-as-gemm stride {stride}: rel err {e:.3e}")
-        assert e < 1e-4
+    for Cin, Cout, T in ((96, 128, 300), (128, 256, 130)):
+        Kp = ((3 * Cin + 63) // 64) * 64
+        for stride in (1, 2):
+            x = (rng.standard_normal((Cin, T)) * 0.5).astype(np.float16)
+            w = (rng.standard_normal((Cout, Cin, 3)) * 0.1).astype(np.float16)
+            ref = F.conv1d(torch.from_numpy(x.astype(np.float32))[None], torch.from_numpy(w.astype(np.float32)), stride=stride, padding=1)[0].numpy().T
+            img = np.zeros((T + 2) * Cin + 64, np.float16); img[Cin:(T + 1) * Cin] = x.T.reshape(-1)     # + tail for the zero-weighted over-read
+            wp = np.zeros((Cout, Kp), np.float16); wp[:, :3 * Cin] = w.transpose(0, 2, 1).reshape(Cout, 3 * Cin)     # [out][k*C + c]
+            Tout = ref.shape[0]
+            dA, dW = DevBuf.from_numpy(img), DevBuf.from_numpy(wp)
+            dC = DevBuf(Tout * Cout * 4)
+            check(lib.wis_op_gemm(0, dA.ptr, Cin * stride, dW.ptr, None, None, dC.ptr, Tout, Cout, Kp, 4))
+            out = dC.to_numpy(np.float32, (Tout, Cout))
+            e = _relerr(out, ref)
+            print(f"conv-as-gemm C{Cin} stride {stride}: rel err {e:.3e}")
+            assert e < 1e-4
 
 
 @pytest.mark.parametrize("M,d", [(5, 384), (1500, 1280), (33, 512)])

@@ -77,42 +77,54 @@ int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const f
 // =======================================================================================
 // GEMM  C[m][n] = epi( sum_k A(m)[k] * W[n][k] ),  A rows addressed as
 //   A + (m / a_rpb) * a_bs + (m % a_rpb) * a_rs     (implicit im2col for the convs).
-constexpr int BN = 128, BK = 32, LSTR = 40;  // LDS row pitch 40 f16 = 80 B
-// BM_ = 128 (default) or 64: the 64-row variant doubles the workgroup count for the N = d GEMMs (out-proj, FFN2), which
+constexpr int BN = 128, BK = 64, LSTR = 72;  // 64-deep k-tiles; LDS row pitch 72 f16 = 144 B (conflict-free ds_read_b128)
+// BM_ = 128 (default) or 64: the 64-row variant doubles the workgroup count for the N = d GEMMs (out-proj, conv2), which
 // would otherwise launch only ceil(1500/128) * d/128 = 120 workgroups on 256 CUs.
+// Tile order: the grid is 1-D; workgroup ids are first regrouped so that the ids an XCD receives (id % 8, observed dispatch
+// order — a speed assumption only) form one contiguous range, then mapped m-fastest, so an XCD works on a few W column
+// panels (<= ~2 MB, L2-resident) against all of A.
 
 template <class Epi, int BM_>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
   constexpr int MI = BM_ / 64;                 // 32-row MFMA sub-tiles per wave along M
-  constexpr int NA = BM_ / 64;                 // 16-byte A chunks per thread per k-tile
+  constexpr int NA = BM_ / 32;                 // 16-byte A chunks per thread per k-tile (W: always 4)
   __shared__ __attribute__((aligned(16))) f16 sA[2][BM_ * LSTR];
   __shared__ __attribute__((aligned(16))) f16 sW[2][BN * LSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-  const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN;
+  // XCD-aware, bijective regrouping of the linear workgroup id (guide T1), then m-fastest tile coordinates
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN);
+  int wg;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN;
 
-  // loader mapping: 16-byte chunk c -> row c>>2, k-offset (c&3)*8; W tile 512 chunks (2 per thread), A tile BM_*4 chunks
-  const int lrow0 = tid >> 2, lrow1 = (tid + 256) >> 2, lkc = (tid & 3) * 8;
-  int lm0 = m0 + lrow0; if (lm0 > p.M - 1) lm0 = p.M - 1;
-  int lm1 = m0 + lrow1; if (lm1 > p.M - 1) lm1 = p.M - 1;
-  const f16* ga0_ = p.A + (int64_t)(lm0 / p.a_rpb) * p.a_bs + (int64_t)(lm0 % p.a_rpb) * p.a_rs + lkc;
-  const f16* ga1_ = p.A + (int64_t)(lm1 / p.a_rpb) * p.a_bs + (int64_t)(lm1 % p.a_rpb) * p.a_rs + lkc;
-  const f16* gw0_ = p.W + (int64_t)(n0 + lrow0) * p.K + lkc;
-  const f16* gw1_ = p.W + (int64_t)(n0 + lrow1) * p.K + lkc;
-  const f16 *ga0 = ga0_, *ga1 = ga1_, *gw0 = gw0_, *gw1 = gw1_;
-  const int soff0 = lrow0 * LSTR + lkc, soff1 = lrow1 * LSTR + lkc;
-  if (p.klen > 0) { const int kbeg = blockIdx.z * p.klen; ga0 += kbeg; ga1 += kbeg; gw0 += kbeg; gw1 += kbeg; }
-  uint4 ra0, ra1, rw0, rw1;
-#define WIS_GLOAD(kt)                                                   \
-  ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK);               \
-  if (NA == 2) ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK);  \
-  rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK);               \
-  rw1 = *reinterpret_cast<const uint4*>(gw1 + (kt) * BK);
-#define WIS_SSTORE(buf)                                                 \
-  *reinterpret_cast<uint4*>(&sA[buf][soff0]) = ra0;                     \
-  if (NA == 2) *reinterpret_cast<uint4*>(&sA[buf][soff1]) = ra1;        \
-  *reinterpret_cast<uint4*>(&sW[buf][soff0]) = rw0;                     \
-  *reinterpret_cast<uint4*>(&sW[buf][soff1]) = rw1;
+  // loader mapping: 16-byte chunk c -> row c>>3, k-offset (c&7)*8; rows lrow + 32*i (explicitly named registers: arrays
+  // here get demoted to scratch / LDS by the compiler)
+  const int lrow = tid >> 3, lkc = (tid & 7) * 8;
+  auto arow = [&](int i) -> const f16* {
+    int lm = m0 + lrow + 32 * i; if (lm > p.M - 1) lm = p.M - 1;
+    return p.A + (int64_t)(lm / p.a_rpb) * p.a_bs + (int64_t)(lm % p.a_rpb) * p.a_rs + lkc;
+  };
+  const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
+  const f16* ga0 = arow(0) + kbeg; const f16* ga1 = arow(1) + kbeg;
+  const f16* ga2 = arow(NA > 2 ? 2 : 0) + kbeg; const f16* ga3 = arow(NA > 2 ? 3 : 0) + kbeg;
+  const f16* gw0 = p.W + (int64_t)(n0 + lrow) * p.K + lkc + kbeg;
+  const f16* gw1 = gw0 + (int64_t)32 * p.K; const f16* gw2 = gw0 + (int64_t)64 * p.K; const f16* gw3 = gw0 + (int64_t)96 * p.K;
+  const int soff = lrow * LSTR + lkc;
+  uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define WIS_GLOAD(kt)                                                                         \
+  ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK); ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK);   \
+  if (NA > 2) { ra2 = *reinterpret_cast<const uint4*>(ga2 + (kt) * BK); ra3 = *reinterpret_cast<const uint4*>(ga3 + (kt) * BK); } \
+  rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK); rw1 = *reinterpret_cast<const uint4*>(gw1 + (kt) * BK);   \
+  rw2 = *reinterpret_cast<const uint4*>(gw2 + (kt) * BK); rw3 = *reinterpret_cast<const uint4*>(gw3 + (kt) * BK);
+#define WIS_SSTORE(buf)                                                                       \
+  *reinterpret_cast<uint4*>(&sA[buf][soff]) = ra0; *reinterpret_cast<uint4*>(&sA[buf][soff + 32 * LSTR]) = ra1;     \
+  if (NA > 2) { *reinterpret_cast<uint4*>(&sA[buf][soff + 64 * LSTR]) = ra2; *reinterpret_cast<uint4*>(&sA[buf][soff + 96 * LSTR]) = ra3; } \
+  *reinterpret_cast<uint4*>(&sW[buf][soff]) = rw0; *reinterpret_cast<uint4*>(&sW[buf][soff + 32 * LSTR]) = rw1;     \
+  *reinterpret_cast<uint4*>(&sW[buf][soff + 64 * LSTR]) = rw2; *reinterpret_cast<uint4*>(&sW[buf][soff + 96 * LSTR]) = rw3;
 
   f32x16 acc[2][MI];
 #pragma unroll
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
     const int cur = kt & 1;
     if (kt + 1 < nk) { WIS_GLOAD(kt + 1) }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 16; ++kk) {
       f16x8 wf[2], af[MI];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -167,12 +179,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
 
 template <class Epi>
 static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
-  if (p.N % BN || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%32)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
+  if (p.N % BN || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
   // fewer than ~1 workgroup per CU with 128-row tiles -> 64-row tiles
   if ((p.N / BN) * cdiv(p.M, 128) < 200 && p.M > 64)
-    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64>), dim3(p.N / BN, cdiv(p.M, 64)), dim3(256), 0, st, p, epi);
+    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64>), dim3((p.N / BN) * cdiv(p.M, 64)), dim3(256), 0, st, p, epi);
   else
-    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128>), dim3(p.N / BN, cdiv(p.M, 128)), dim3(256), 0, st, p, epi);
+    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128>), dim3((p.N / BN) * cdiv(p.M, 128)), dim3(256), 0, st, p, epi);
   return WIS_OK;
 }
 
@@ -265,7 +277,7 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
-  hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128>), dim3(p.N / BN, cdiv(p.M, 128), splits), dim3(256), 0, st, p, e);
+  hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128>), dim3((p.N / BN) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
   const int64_t n4 = zs / 4;
   int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, scratch, splits, zs, bias, resid, X, n4, p.N);

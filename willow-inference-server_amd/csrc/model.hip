@@ -37,13 +37,14 @@ __global__ void convert_kernel(const void* __restrict__ src, int src_f16, void* 
     if (dst_f16) reinterpret_cast<f16*>(dst)[r * dst_ld + c] = (f16)v; else reinterpret_cast<float*>(dst)[r * dst_ld + c] = v;
   }
 }
-// conv weight [out][in][3] -> f16 [out][3*cpad], element (o, k*cpad + c) = W[o][c][k]; padding zero
-__global__ void conv_pack_kernel(const void* __restrict__ src, int src_f16, f16* __restrict__ dst, int out, int in, int cpad) {
-  const int64_t total = (int64_t)out * 3 * cpad;
+// conv weight [out][in][3] -> f16 [out][row_len], element (o, k*cpad + c) = W[o][c][k]; channel padding and the row tail
+// [3*cpad, row_len) are zero (row_len = K rounded up to the GEMM's 64-deep k-tile)
+__global__ void conv_pack_kernel(const void* __restrict__ src, int src_f16, f16* __restrict__ dst, int out, int in, int cpad, int row_len) {
+  const int64_t total = (int64_t)out * row_len;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int o = (int)(i / (3 * cpad)), rem = (int)(i - (int64_t)o * 3 * cpad), k = rem / cpad, c = rem - k * cpad;
+    const int o = (int)(i / row_len), rem = (int)(i - (int64_t)o * row_len), k = rem / cpad, c = rem - k * cpad;
     float v = 0.f;
-    if (c < in) {
+    if (k < 3 && c < in) {
       const int64_t s = ((int64_t)o * in + c) * 3 + k;
       v = src_f16 ? (float)reinterpret_cast<const f16*>(src)[s] : reinterpret_cast<const float*>(src)[s];
     }
@@ -195,11 +196,11 @@ int load_weights(wis_model* m, const Loader& L) {
     {
       TensorSrc s;
       if ((rc = L.get("encoder/conv1/weight", d, (int64_t)c.n_mels * 3, &s))) break;
-      if ((rc = dalloc(m, &m->w_conv1, (size_t)d * 3 * 96))) break;
-      hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks_for((int64_t)d * 288)), dim3(256), 0, m->st, s.p, s.f16, m->w_conv1, d, c.n_mels, 96);
+      if ((rc = dalloc(m, &m->w_conv1, (size_t)d * 320))) break;     // K = 3*96 = 288 padded to 320 = 5 x 64
+      hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks_for((int64_t)d * 320)), dim3(256), 0, m->st, s.p, s.f16, m->w_conv1, d, c.n_mels, 96, 320);
       if ((rc = L.get("encoder/conv2/weight", d, (int64_t)d * 3, &s))) break;
       if ((rc = dalloc(m, &m->w_conv2, (size_t)d * 3 * d))) break;
-      hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks_for((int64_t)d * 3 * d)), dim3(256), 0, m->st, s.p, s.f16, m->w_conv2, d, d, d);
+      hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks_for((int64_t)d * 3 * d)), dim3(256), 0, m->st, s.p, s.f16, m->w_conv2, d, d, d, 3 * d);
     }
     if ((rc = to_f32(m, L, "encoder/conv1/bias", d, &m->b_conv1))) break;
     if ((rc = to_f32(m, L, "encoder/conv2/bias", d, &m->b_conv2))) break;
@@ -283,7 +284,7 @@ int alloc_buffers(wis_model* m) {
   const int d = c.d_model, H = c.n_heads, Bm = c.max_batch, T = c.n_audio_ctx, L = c.n_dec_layers;
   const int slots = Bm * c.max_beam, ctx = c.n_text_ctx;
   m->Tpad = cdiv(T, 64) * 64;
-  WIS_RET(dalloc(m, &m->img, (size_t)Bm * 3002 * 96));
+  WIS_RET(dalloc(m, &m->img, (size_t)Bm * 3002 * 96 + 64));     // +64: the last window's zero-weighted over-read
   WIS_RET(dalloc(m, &m->c1, (size_t)Bm * 3002 * d));
   WIS_RET(dalloc(m, &m->x, (size_t)Bm * T * d));
   WIS_RET(dalloc(m, &m->xn, (size_t)Bm * T * d));
@@ -293,7 +294,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->hbuf, (size_t)Bm * T * 4 * d));
   WIS_RET(dalloc(m, &m->mem, (size_t)Bm * T * d));
   WIS_RET(dalloc(m, &m->skbuf, (size_t)2 * Bm * T * d));
-  WIS_HIP_CHECK(hipMemsetAsync(m->img, 0, (size_t)Bm * 3002 * 96 * 2, m->st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->img, 0, ((size_t)Bm * 3002 * 96 + 64) * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->c1, 0, (size_t)Bm * 3002 * d * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->vt, 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
   m->kx.resize(L); m->vx.resize(L); m->kc.resize(L); m->vc.resize(L);
@@ -362,8 +363,8 @@ int stage_input(wis_model* m, const float* input, int kind, int B) {
 int run_encoder(wis_model* m, int B) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, M = B * T;
-  {  // conv1: implicit im2col over the [3002][96] image, K = 288
-    GemmP p; p.klen = 0; p.A = m->img; p.a_bs = (int64_t)3002 * 96; p.a_rs = 96; p.a_rpb = 3000; p.W = m->w_conv1; p.M = B * 3000; p.N = d; p.K = 288;
+  {  // conv1: implicit im2col over the [3002][96] image, K = 288 (+32 zero-weighted columns that read into the next row)
+    GemmP p; p.klen = 0; p.A = m->img; p.a_bs = (int64_t)3002 * 96; p.a_rs = 96; p.a_rpb = 3000; p.W = m->w_conv1; p.M = B * 3000; p.N = d; p.K = 320;
     WIS_RET(launch_gemm_conv1(st, p, m->b_conv1, m->c1, 3000));
   }
   {  // conv2 (stride 2) + GELU + positions -> fp32 residual stream
