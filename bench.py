@@ -86,13 +86,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    # One HIP runtime per process: torch bundles its own libamdhip64; when torch.cuda is needed (distributed branch) torch must
+    # be imported BEFORE libwis_hip.so so that the library's libamdhip64.so.7 dependency resolves to the runtime torch loaded.
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
+        import torch  # noqa: F401
     from wis_hip import _lib, audio, ctranslate2 as ct2, weights as W
     lib = _lib.load()
     _lib.require_gpu()
-    dev = local_rank if world > 1 else 0
+    dev = local_rank
 
+    # launched by torch.distributed.run (RANK set) -> always take the distributed branch, even with one rank, so that the
+    # RCCL init / weight broadcast / device-arena hand-off is the same code at every N
     dist = torch = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(dev)
@@ -101,7 +108,7 @@ def main():
     a = W.arch(args.model)
     t0 = time.perf_counter()
     weights = None
-    if world == 1:
+    if not use_dist:
         weights = W.synthetic_weights(args.model, seed=1234)
         arena, index = W.build_arena(weights)
         handle = ct2.create_handle(a, arena, index, dev, max_batch=max(args.batch, 1), max_beam=max(args.beam, 1))
@@ -142,7 +149,7 @@ def main():
                                     scores.ctypes.data_as(C.POINTER(C.c_float))))
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         _lib.check(lib.wis_dev_sync(dev))
@@ -161,7 +168,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     timing = _lib.Timing(); _lib.check(lib.wis_last_timing(handle, C.byref(timing)))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,6 +195,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if weights is None:
+            weights = W.synthetic_weights(args.model, seed=1234)
         try:
             cpu = cpu_baseline(args.model, weights, pcm, args.beam, fixed_new, audio_ms)
         except Exception as e:   # the baseline leg must never take the measurement down
@@ -211,7 +220,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     lib.wis_model_destroy(handle)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -11,6 +11,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libwis_hip.so: one HIP runtime per process)
 
 pytestmark = pytest.mark.gpu
 MARGIN = 0.02
@@ -201,3 +202,27 @@ def test_do_whisper_orchestrator(golden_dir):
     assert out[5] == 40000 and 1 <= len(out.tokens) <= 15
     det = whisper.do_whisper(clip, "tiny", 1, detect_language=True, models=models, fixed_new_tokens=4)
     assert det[0] in __import__("wis_hip.languages", fromlist=["LANGUAGES"]).LANGUAGES
+
+
+def test_model_from_device_resident_arena(mels):
+    """Multi-GPU load path: the weight arena arrives in DEVICE memory (the buffer an RCCL broadcast filled, here a torch CUDA
+    tensor) and is handed to wis_model_create(arena_on_device=1) by raw pointer; results must equal the host-arena model."""
+    import torch
+    from wis_hip import _lib, ctranslate2 as ct2, weights as W
+    w = W.synthetic_weights("tiny", seed=1234, emb_std=0.06, ln_jitter=0.1)
+    a = W.arch("tiny")
+    arena, index = W.build_arena(w)
+    buf = torch.from_numpy(arena).to("cuda:0")
+    torch.cuda.synchronize()
+    h = ct2.create_handle(a, None, index, 0, max_batch=2, max_beam=5, arena_device_ptr=(buf.data_ptr(), arena.nbytes))
+    del buf
+    torch.cuda.empty_cache()
+    host = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5)
+    dev = ct2.Whisper.__new__(ct2.Whisper)
+    dev._replicas, dev.max_batch, dev.max_beam, dev.arch = [ct2._Replica(h, 0)], 2, 5, a
+    import threading
+    dev._pick = threading.Lock()
+    f = ct2.StorageView.from_array(mels)
+    r_host = host.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)
+    r_dev = dev.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)
+    assert [r.sequences_ids for r in r_host] == [r.sequences_ids for r in r_dev]

@@ -19,6 +19,8 @@
 //    (softmax max/sum are in-lane + one half-swap), P feeds the PV MFMA straight from the
 //    accumulator registers (the key order inside a 16-key MFMA step is permuted identically for
 //    P and V^T), V arrives pre-transposed ([dh][T]) from the QKV epilogue.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -177,14 +179,125 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-DMA variant (opt-in, WIS_GEMM_GLDS=1): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4, no VGPR round trip and no ds_write
+// (the register-staged kernel above is LDS-write bound: 32 KiB of ds_write_b128 per k-tile at ~79 B/clk vs 512 cycles of MFMA).
+// The DMA writes lane l at base + 16*l, i.e. one wave instruction fills 8 rows x 128 B of a LINEAR [rows][64] f16 image, so the
+// bank-conflict swizzle lives on the SOURCE address: LDS slot (row, c) holds global 16-byte chunk c ^ (row & 7) of that row, and
+// fragment reads apply the same XOR (guide rule 21 / T2).  Two LDS buffers; tile k+1 is in flight while tile k is multiplied.
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+__device__ __forceinline__ void glds16(const f16* src, f16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)lds_wave_base, 16, 0, 0);   // generic -> global / LDS address spaces
+}
+
+template <class Epi, int BM_>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p, Epi epi) {
+  constexpr int MI = BM_ / 64;                 // 32-row MFMA sub-tiles per wave along M
+  constexpr int AI = BM_ / 32;                 // DMA instructions per wave per k-tile for the A tile (8 rows each); W: 4
+  __shared__ __attribute__((aligned(1024))) f16 sA[2][BM_ * 64];
+  __shared__ __attribute__((aligned(1024))) f16 sW[2][BN * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN);
+  int wg;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN;
+  const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
+
+  // DMA source pointers: instruction i of this wave covers tile rows (BM_/4 or 32)*wave + 8*i + (lane>>3); the lane fetches
+  // global chunk (lane&7) ^ (row&7) so that the linear LDS image is XOR-swizzled
+  const int lr = lane >> 3, lc = lane & 7;
+  auto asrc = [&](int i) -> const f16* {
+    const int row = (BM_ / 4) * wave + 8 * i + lr;
+    int lm = m0 + row; if (lm > p.M - 1) lm = p.M - 1;
+    return p.A + (int64_t)(lm / p.a_rpb) * p.a_bs + (int64_t)(lm % p.a_rpb) * p.a_rs + ((lc ^ (row & 7)) * 8) + kbeg;
+  };
+  auto wsrc = [&](int i) -> const f16* {
+    const int row = 32 * wave + 8 * i + lr;
+    return p.W + (int64_t)(n0 + row) * p.K + ((lc ^ (row & 7)) * 8) + kbeg;
+  };
+  const f16* ga0 = asrc(0); const f16* ga1 = asrc(1);
+  const f16* ga2 = asrc(AI > 2 ? 2 : 0); const f16* ga3 = asrc(AI > 2 ? 3 : 0);
+  const f16* gw0 = wsrc(0); const f16* gw1 = wsrc(1); const f16* gw2 = wsrc(2); const f16* gw3 = wsrc(3);
+  const int la = (BM_ / 4) * wave * 64, lw = 32 * wave * 64;      // wave-uniform LDS element offsets of this wave's rows
+#define WIS_DMA(buf, kt)                                                                  \
+  glds16(ga0 + (kt) * BK, &sA[buf][la]); glds16(ga1 + (kt) * BK, &sA[buf][la + 8 * 64]);  \
+  if (AI > 2) { glds16(ga2 + (kt) * BK, &sA[buf][la + 16 * 64]); glds16(ga3 + (kt) * BK, &sA[buf][la + 24 * 64]); } \
+  glds16(gw0 + (kt) * BK, &sW[buf][lw]); glds16(gw1 + (kt) * BK, &sW[buf][lw + 8 * 64]); \
+  glds16(gw2 + (kt) * BK, &sW[buf][lw + 16 * 64]); glds16(gw3 + (kt) * BK, &sW[buf][lw + 24 * 64]);
+
+  f32x16 acc[2][MI];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment read offsets (elements): row r, chunk c = 2*kk + hi  ->  r*64 + ((c ^ (r & 7)) * 8)
+  const int rw0 = wn * 64 + l31, rw1 = rw0 + 32, ra0 = wm * (BM_ / 2) + l31, ra1 = ra0 + 32;
+
+  const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
+  WIS_DMA(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { WIS_DMA(cur ^ 1, kt + 1) }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int c = 2 * kk + hi;
+      const f16x8 wf0 = *reinterpret_cast<const f16x8*>(&sW[cur][rw0 * 64 + ((c ^ (rw0 & 7)) * 8)]);
+      const f16x8 wf1 = *reinterpret_cast<const f16x8*>(&sW[cur][rw1 * 64 + ((c ^ (rw1 & 7)) * 8)]);
+      const f16x8 af0 = *reinterpret_cast<const f16x8*>(&sA[cur][ra0 * 64 + ((c ^ (ra0 & 7)) * 8)]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, af0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, af0, acc[1][0], 0, 0, 0);
+      if (MI > 1) {
+        const f16x8 af1 = *reinterpret_cast<const f16x8*>(&sA[cur][ra1 * 64 + ((c ^ (ra1 & 7)) * 8)]);
+        acc[0][MI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, af1, acc[0][MI - 1], 0, 0, 0);
+        acc[1][MI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, af1, acc[1][MI - 1], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile k+1 have landed
+    __syncthreads();                                     // ... and everyone's; nobody still reads buffer `cur`
+  }
+#undef WIS_DMA
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (BM_ / 2) + mi * 32 + l31;
+      if (m < p.M) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * r4 + 4 * hi;
+          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
+          epi(m, n, v);
+        }
+      }
+    }
+}
+
+// measured on MI355X round 1 (large-v2 encoder, 2 workgroups/CU): register-staged 6.5 ms vs LDS-DMA 7.3 ms -> DMA variant is opt-in
+static bool use_glds() { static const bool v = getenv("WIS_GEMM_GLDS") != nullptr; return v; }
+
 template <class Epi>
 static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   if (p.N % BN || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
   // fewer than ~1 workgroup per CU with 128-row tiles -> 64-row tiles
-  if ((p.N / BN) * cdiv(p.M, 128) < 200 && p.M > 64)
-    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64>), dim3((p.N / BN) * cdiv(p.M, 64)), dim3(256), 0, st, p, epi);
-  else
-    hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128>), dim3((p.N / BN) * cdiv(p.M, 128)), dim3(256), 0, st, p, epi);
+  const bool small = (p.N / BN) * cdiv(p.M, 128) < 200 && p.M > 64;
+  const dim3 grid((p.N / BN) * cdiv(p.M, small ? 64 : 128));
+  if (use_glds()) {
+    if (small) hipLaunchKernelGGL((gemm_glds_kernel<Epi, 64>), grid, dim3(256), 0, st, p, epi);
+    else hipLaunchKernelGGL((gemm_glds_kernel<Epi, 128>), grid, dim3(256), 0, st, p, epi);
+  } else {
+    if (small) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64>), grid, dim3(256), 0, st, p, epi);
+    else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128>), grid, dim3(256), 0, st, p, epi);
+  }
   return WIS_OK;
 }
 
@@ -277,7 +390,8 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
-  hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128>), dim3((p.N / BN) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
+  if (use_glds()) hipLaunchKernelGGL((gemm_glds_kernel<EpiPartial, 128>), dim3((p.N / BN) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
+  else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128>), dim3((p.N / BN) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
   const int64_t n4 = zs / 4;
   int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, scratch, splits, zs, bias, resid, X, n4, p.N);
