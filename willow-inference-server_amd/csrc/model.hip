@@ -109,7 +109,7 @@ struct wis_model {
   std::vector<f16*> kx, vx;             // per decoder layer cross K / V
   std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d]
   // decode state
-  float *dx, *dq, *logits, *part; f16 *dao, *dh; unsigned* counters;
+  float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
@@ -309,6 +309,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->dq, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dao, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dh, (size_t)MAX_ROWS * 4 * d));
+  WIS_RET(dalloc(m, &m->dln, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->logits, (size_t)MAX_ROWS * m->n_vocab_pad));
   WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * 66));
   WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
@@ -395,6 +396,17 @@ int run_cross_kv(wis_model* m, int B) {
   return WIS_OK;
 }
 
+// LayerNorm + skinny GEMM.  Up to 8 rows the LayerNorm is fused into the GEMM prologue (register resident); with more rows
+// (batched decode: B*beam up to 48) every workgroup re-normalising all rows costs more than one extra launch, so the rows are
+// normalised once by layernorm_kernel into an f16 buffer and the GEMM takes its f16-activation path.
+static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
+  if (g.M > 8 && (g.flags & GV_LN)) {
+    WIS_RET(launch_layernorm(st, reinterpret_cast<const float*>(g.x), g.gamma, g.beta, m->dln, g.M, g.K));
+    g.x = m->dln; g.gamma = nullptr; g.beta = nullptr; g.flags &= ~GV_LN;
+  }
+  return launch_gemv(st, g);
+}
+
 // ---- one decoder forward over the current row metadata ---------------------------------
 // sstride / rmul: logical-slot mapping of the rows (decode rows: beam, 1; prefill rows: beam, 0; single rows: 1, 0)
 int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul) {
@@ -411,37 +423,37 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 48 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 16 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
     // cross-attention block
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 32 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 64 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
     g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
   }
   if (want_logits) {
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
   }
   return WIS_OK;
 }
