@@ -22,7 +22,7 @@ C_SOURCES = ["audio_io.c"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join(ROOT, "include", "wis_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off"]
+             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
 C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
 
 
