@@ -1,0 +1,111 @@
+"""-m gpu: the re-hosted REST endpoints over the HIP path and the dynamic micro-batcher under concurrent load
+(load shape of client/jmeter-asr.jmx:53-90 - N clients POSTing 3sec.flac with model=…&beam_size=5)."""
+import asyncio
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before libwis_hip.so)
+
+pytestmark = pytest.mark.gpu
+PROMPT = [50258, 50259, 50359, 50363]
+
+
+def _multipart(data):
+    b = "wisBoundary7"
+    body = (f"--{b}\r\nContent-Disposition: form-data; name=\"audio_file\"; filename=\"3sec.flac\"\r\nContent-Type: audio/flac\r\n\r\n").encode() \
+        + data + f"\r\n--{b}--\r\n".encode()
+    return body, {"content-type": f"multipart/form-data; boundary={b}"}
+
+
+@pytest.fixture(scope="module")
+def served():
+    from wis_hip.server import create_app
+    from wis_hip.settings import APISettings
+    from wis_hip.whisper import WhisperModels
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.max_batch = 8
+    models = WhisperModels(s, device_index=[0])
+    return create_app(models=models), models
+
+
+def test_concurrent_generate_calls_batch_and_match_serial_results(golden_dir):
+    """16 threads call generate() at once: the micro-batcher must form multi-utterance device batches and every caller must
+    get what a lone call gets (up to the batch-composition rounding documented in test_gpu_fullsize: equal scores, ids
+    equal unless a near-tie flips)."""
+    from wis_hip import ctranslate2 as ct2
+    model = ct2.Whisper("synthetic:base", max_batch=8, max_beam=5)
+    m3 = np.load(os.path.join(golden_dir, "logmel_3sec.npz"))["mel"].astype(np.float32)
+    m10 = np.load(os.path.join(golden_dir, "logmel_10sec.npz"))["mel"].astype(np.float32)
+    feats = {0: np.ascontiguousarray(m3[None]), 1: np.ascontiguousarray(m10[None])}
+    kw = dict(beam_size=5, fixed_new_tokens=10)
+    lone = {k: model.generate(ct2.StorageView.from_array(v), [PROMPT], **kw)[0] for k, v in feats.items()}
+    n0 = len(model._batcher.batches)
+    out, start = {}, threading.Barrier(16)
+
+    def client(i):
+        start.wait()
+        beam = 5 if i % 4 else 1                      # a different batch key mixed in: must never share a device batch
+        out[i] = (beam, model.generate(ct2.StorageView.from_array(feats[i % 2]), [PROMPT], beam_size=beam, fixed_new_tokens=10)[0])
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    sizes = [n for _, n in model._batcher.batches[n0:]]
+    print("device batches formed:", sizes)
+    assert sum(sizes) == 16 and max(sizes) > 1 and max(sizes) <= 8
+    flips = 0
+    for i, (beam, r) in out.items():
+        if beam != 5:
+            continue
+        ref = lone[i % 2]
+        assert abs(r.scores[0] - ref.scores[0]) <= 2e-3
+        flips += r.sequences_ids != ref.sequences_ids
+    assert flips <= 2
+    model.close()
+
+
+def test_asr_and_willow_endpoints(served, golden_dir):
+    import httpx
+    from wis_hip import audio
+    from wis_hip.whisper import do_whisper
+    app, models = served
+    clip = os.path.join(golden_dir, "clips", "3sec.flac")
+    flac = open(clip, "rb").read()
+    direct = do_whisper(clip, "tiny", 5, "transcribe", False, None, models=models)
+    pcm, _ = audio.load_audio(clip)
+    s16 = np.round(pcm * 32768.0).astype("<i2").tobytes()
+
+    async def go():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis", timeout=120) as c:
+            body, hdr = _multipart(flac)
+            r = await c.post("/api/asr?model=tiny&beam_size=5&detect_language=False", content=body, headers=hdr)
+            assert r.status_code == 200, r.text
+            j = r.json()
+            assert set(j) == {"infer_time", "infer_speedup", "audio_duration", "language", "text"}
+            assert j["audio_duration"] == 3840 and j["language"] == "en" and j["text"] == direct[1]
+            assert j["infer_speedup"] == int(3840 // j["infer_time"])
+            # Willow device path: raw 16-bit PCM + x-audio-* headers; same samples -> same transcript
+            hw = {"x-audio-sample-rate": "16000", "x-audio-bits": "16", "x-audio-channel": "1", "x-audio-codec": "pcm", "x-willow-id": "test"}
+            r = await c.post("/api/willow?model=tiny&beam_size=5", content=s16, headers=hw)
+            assert r.status_code == 200 and r.json() == {"language": "en", "text": direct[1]}
+            r = await c.post("/api/willow?model=tiny&beam_size=5&stats=true", content=flac, headers={"x-audio-codec": "flac"})
+            assert r.status_code == 200 and r.json()["text"] == direct[1] and "infer_time" in r.json()
+            r = await c.post("/api/willow?model=tiny&beam_size=5&detect_language=true", content=s16, headers=hw)
+            assert r.status_code == 200 and len(r.json()["language"]) in (2, 3)
+            # jmeter-asr.jmx shape: concurrent identical POSTs; all answers equal, device batches > 1 formed
+            mdl = models.get("tiny")
+            n0 = len(mdl._batcher.batches)
+            rs = await asyncio.gather(*[c.post("/api/asr?model=tiny&beam_size=5&detect_language=False", content=body, headers=hdr) for _ in range(24)])
+            assert all(x.status_code == 200 for x in rs)
+            texts = [x.json()["text"] for x in rs]
+            sizes = [n for _, n in mdl._batcher.batches[n0:]]
+            print("REST load: device batches", sizes)
+            assert sum(sizes) == 24 and max(sizes) > 1
+            assert sum(t != direct[1] for t in texts) <= 2       # near-tie flips only (batch composition changes rounding)
+
+    asyncio.run(go())

@@ -1,0 +1,94 @@
+"""not gpu: real-weight loaders.  A Hugging Face Whisper checkpoint written by transformers' own
+`save_pretrained` (safetensors) is read by wis_hip.weights.load_hf_dir, converted to the CTranslate2 directory layout WIS
+ships (model.bin + config.json), read back, and the oracle built from the loaded weights must reproduce the HF model's own
+forward pass - so the name mapping (fused QKV / fused cross KV / absent k bias / tied projection) is pinned on HF itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.whisper_ref import WhisperRef
+
+
+def hf_checkpoint(tmp, d=128, L=2, H=2, V=2000, seed=0, dtype=torch.float32, sharded=False):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    torch.manual_seed(seed)
+    cfg = WhisperConfig(vocab_size=V, d_model=d, encoder_layers=L, decoder_layers=L, encoder_attention_heads=H,
+                        decoder_attention_heads=H, encoder_ffn_dim=4 * d, decoder_ffn_dim=4 * d, num_mel_bins=80,
+                        max_source_positions=1500, max_target_positions=448, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=1, suppress_tokens=None, begin_suppress_tokens=None, init_std=0.05)
+    m = WhisperForConditionalGeneration(cfg).eval()
+    with torch.no_grad():    # make LayerNorm / biases non-trivial so a swapped gamma/beta or dropped bias cannot hide
+        for n, p in m.named_parameters():
+            if "layer_norm" in n or n.endswith(".bias"):
+                p.add_(0.1 * torch.randn_like(p))
+    m = m.to(dtype)
+    m.save_pretrained(tmp, safe_serialization=True, max_shard_size="1MB" if sharded else "10GB")
+    with open(os.path.join(tmp, "generation_config.json"), "w") as f:
+        json.dump({"suppress_tokens": [1, 7, 9], "begin_suppress_tokens": [220, 2]}, f)
+    return m.float()
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_hf_safetensors_loader_matches_hf_forward(tmp_path, sharded):
+    from wis_hip import weights as W
+    d, L, H, V = 128, 2, 2, 2000
+    hf = hf_checkpoint(str(tmp_path), d, L, H, V, sharded=sharded)
+    if sharded:
+        assert os.path.exists(tmp_path / "model.safetensors.index.json")
+    w, a, cfg = W.load_hf_dir(str(tmp_path))
+    assert (a["d_model"], a["n_layers"], a["n_heads"], a["n_vocab"]) == (d, L, H, V)
+    assert cfg["suppress_ids_begin"] == [220, 2] and set(cfg["suppress_ids"]) == {1, 7, 9, W.TRANSLATE, W.TRANSCRIBE}
+    assert set(w) == set(W.tensor_shapes(d, L, V, 448))
+    for name, (shape, kind) in W.tensor_shapes(d, L, V, 448).items():
+        assert tuple(w[name].shape) == tuple(shape), name
+        assert w[name].dtype == (np.float32 if kind == "pos" else np.float16), name
+    # rebuild the HF model from the f16-rounded weights so both sides see the same numbers, then compare forwards
+    w32 = {k: np.asarray(v, np.float32) for k, v in w.items()}
+    ref = WhisperRef(w, d, L, H, n_vocab=V, eot=2, sot=1)
+    from tests.test_oracle_whisper import to_hf
+    hf16 = to_hf(w32, d, L, H, V)
+    rng = np.random.default_rng(3)
+    mel = rng.standard_normal((1, 80, 3000)).astype(np.float32) * 0.5
+    ids = np.array([[1, 5, 17, 900, 33]])
+    with torch.no_grad():
+        enc_hf = hf16.model.encoder(torch.from_numpy(mel)).last_hidden_state.numpy()
+        lg_hf = hf16(input_features=torch.from_numpy(mel), decoder_input_ids=torch.from_numpy(ids)).logits.numpy()
+        lg_orig = hf(input_features=torch.from_numpy(mel), decoder_input_ids=torch.from_numpy(ids)).logits.numpy()
+    enc = ref.encode(torch.from_numpy(mel)).numpy()
+    lg = ref.decode_logits(ids, torch.from_numpy(enc)).numpy()
+    assert np.abs(enc - enc_hf).max() < 2e-4
+    assert np.abs(lg - lg_hf).max() < 2e-3
+    # and against the ORIGINAL fp32 checkpoint: only the f16 rounding of the stored weights separates them
+    assert np.abs(lg - lg_orig).max() < 5e-2, np.abs(lg - lg_orig).max()
+
+
+def test_convert_to_ct2_dir_roundtrip(tmp_path):
+    from wis_hip import weights as W
+    hf_dir, ct2_dir = tmp_path / "hf", tmp_path / "ct2"
+    os.makedirs(hf_dir)
+    hf_checkpoint(str(hf_dir), dtype=torch.float16)
+    w_hf, a_hf, cfg_hf = W.load_hf_dir(str(hf_dir))
+    W.convert_hf_to_ct2_dir(str(hf_dir), str(ct2_dir))
+    assert os.path.exists(ct2_dir / "model.bin") and os.path.exists(ct2_dir / "config.json")
+    w, a, cfg = W.load_model_dir(str(ct2_dir))
+    assert a == a_hf
+    assert cfg["suppress_ids"] == cfg_hf["suppress_ids"] and cfg["suppress_ids_begin"] == [220, 2] and cfg["lang_ids"] == W.LANG_IDS
+    assert set(w) == set(w_hf)
+    for k in w:
+        assert w[k].dtype == w_hf[k].dtype and np.array_equal(w[k], w_hf[k]), k
+    # the arena both loaders feed to wis_model_create is byte-identical
+    a1, i1 = W.build_arena(w_hf)
+    a2, i2 = W.build_arena({k: w[k] for k in w_hf})
+    assert i1 == i2 and np.array_equal(a1, a2)
+
+
+def test_loader_rejects_unsupported_geometry(tmp_path):
+    from wis_hip import weights as W
+    hf_checkpoint(str(tmp_path), d=96, L=1, H=2, V=300)       # head_dim 48
+    with pytest.raises(ValueError, match="head_dim 64"):
+        W.load_hf_dir(str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        W.load_model_dir(str(tmp_path / "nope"))

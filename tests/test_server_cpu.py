@@ -1,0 +1,162 @@
+"""not gpu: the micro-batcher and the REST re-host's request handling - everything that does not need the
+GPU: batch formation / routing / error propagation with a fake device, multipart + x-audio-* parsing, the reference's 400s."""
+import asyncio
+import io
+import threading
+import time
+import wave
+
+import numpy as np
+import pytest
+
+
+def test_microbatcher_coalesces_equal_keys_and_routes_results():
+    from wis_hip.batching import MicroBatcher
+    seen = []
+
+    def run(ctx, key, payloads):
+        seen.append((ctx, key, list(payloads)))
+        time.sleep(0.03)                       # the "GPU" is busy: later submissions queue up meanwhile
+        return [(key, p * 10) for p in payloads]
+
+    mb = MicroBatcher(["gpu0"], run, lambda key: 4 if key == "a" else 2)
+    out = {}
+
+    def client(i):
+        key = "a" if i % 3 else "b"
+        out[i] = mb.submit(key, [i, i + 100])
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(12)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    mb.close()
+    for i in range(12):
+        key = "a" if i % 3 else "b"
+        assert out[i] == [(key, i * 10), (key, (i + 100) * 10)]             # right caller, payload order kept
+    assert all(len({k for _, k, _ in [b]}) == 1 for b in seen)
+    for ctx, key, payloads in seen:
+        assert len(payloads) <= (4 if key == "a" else 2)                      # capacity respected per key
+    assert max(len(p) for _, _, p in seen) > 1                                # batching happened
+    assert sum(len(p) for _, _, p in seen) == 24
+    assert sum(n for _, n in mb.batches) == 24
+
+
+def test_microbatcher_two_workers_and_error_propagation():
+    from wis_hip.batching import MicroBatcher
+
+    def run(ctx, key, payloads):
+        time.sleep(0.02)
+        if key == "boom":
+            raise RuntimeError("device fault")
+        return [f"{ctx}:{p}" for p in payloads]
+
+    mb = MicroBatcher(["g0", "g1"], run, lambda key: 2)
+    res, errs = {}, []
+
+    def client(i):
+        try:
+            res[i] = mb.submit("boom" if i == 5 else "k", [i])
+        except RuntimeError as e:
+            errs.append((i, str(e)))
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(10)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errs == [(5, "device fault")]
+    assert sorted(res) == [0, 1, 2, 3, 4, 6, 7, 8, 9] and all(v[0].endswith(f":{i}") for i, v in res.items())
+    assert {v[0].split(":")[0] for v in res.values()} == {"g0", "g1"}         # both replicas were fed
+    mb.close()
+    with pytest.raises(RuntimeError):
+        mb.submit("k", [1])
+
+
+def test_lone_request_is_not_delayed():
+    from wis_hip.batching import MicroBatcher
+    mb = MicroBatcher(["g"], lambda c, k, p: list(p), lambda k: 8)
+    t0 = time.perf_counter()
+    for i in range(50):
+        assert mb.submit("k", [i]) == [i]
+    assert (time.perf_counter() - t0) / 50 < 5e-3        # no batching timer on the latency path
+    mb.close()
+
+
+class _FakeModels:
+    """Stands in for WhisperModels so request handling can be exercised without a GPU; reaching the model is an error here."""
+
+    def __init__(self):
+        from wis_hip.settings import APISettings
+        from wis_hip.whisper import _Tokenizer
+        self.settings = APISettings()
+        self.tokenizer = _Tokenizer(None)
+
+    def get(self, size):
+        if size not in ("tiny", "base", "small", "medium", "large"):
+            raise ValueError(f"unknown model {size!r}")
+        return object()
+
+
+def _client(app):
+    import httpx
+    return httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis")
+
+
+def _multipart(data, field="audio_file"):
+    b = "xYzBoundary123"
+    body = (f"--{b}\r\nContent-Disposition: form-data; name=\"{field}\"; filename=\"a.flac\"\r\nContent-Type: application/octet-stream\r\n\r\n").encode() \
+        + data + f"\r\n--{b}--\r\n".encode()
+    return body, {"content-type": f"multipart/form-data; boundary={b}"}
+
+
+def test_multipart_parser_roundtrip():
+    from wis_hip.server import parse_multipart
+    payload = bytes(range(256)) * 40 + b"\r\n--not-the-boundary\r\n"
+    body, hdr = _multipart(payload)
+    assert parse_multipart(body, hdr["content-type"]) == payload
+    with pytest.raises(ValueError):
+        parse_multipart(body, "application/json")
+    with pytest.raises(ValueError):
+        parse_multipart(_multipart(payload, field="other")[0], hdr["content-type"])
+
+
+def test_write_stream_wav_is_a_wav_our_decoder_reads():
+    from wis_hip import audio
+    from wis_hip.server import write_stream_wav
+    pcm = (np.sin(np.arange(1600) * 0.05) * 12000).astype("<i2")
+    f = write_stream_wav(pcm.tobytes(), 16000, 16, 1)
+    with wave.open(io.BytesIO(f.getvalue())) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 1600)
+    x, sr = audio.load_audio(f)                          # host C decoder inside libwis_hip.so: no GPU needed
+    assert sr == 16000 and np.array_equal(x, pcm.astype(np.float32) / 32768.0)
+
+
+def test_endpoints_reference_error_behaviour():
+    from wis_hip.server import create_app
+    app = create_app(models=_FakeModels())
+
+    async def go():
+        async with _client(app) as c:
+            r = await c.get("/api/ping")
+            assert r.status_code == 200 and r.json() == {"message": "pong"}
+            body, hdr = _multipart(b"this is not audio")
+            r = await c.post("/api/asr?model=tiny&force_language=klingon", content=body, headers=hdr)
+            assert r.status_code == 400 and r.json() == {"error": "Invalid force_language"}
+            r = await c.post("/api/asr?model=tiny", content=body, headers=hdr)
+            assert r.status_code == 400 and r.json() == {"error": "Invalid audio"}
+            r = await c.post("/api/asr?model=huge", content=body, headers=hdr)
+            assert r.status_code == 400 and "unknown model" in r.json()["error"]
+            r = await c.post("/api/willow?model=tiny&force_language=xx", content=b"\0" * 64, headers={"x-audio-codec": "pcm"})
+            assert r.status_code == 400 and r.json() == {"error": "Invalid force_language"}
+            r = await c.post("/api/willow?model=tiny", content=b"\0" * 64, headers={"x-audio-codec": "opus", "x-audio-sample-rate": "16000"})
+            assert r.status_code == 400 and r.json() == {"error": "Invalid audio"}
+            r = await c.post("/api/willow?model=tiny", content=b"\0" * 64, headers={"x-audio-codec": "pcm"})   # missing rate/bits/channel headers
+            assert r.status_code == 400 and r.json() == {"error": "Invalid audio"}
+            r = await c.post("/api/willow?model=tiny", content=b"RIFFjunk", headers={"x-audio-codec": "wav"})
+            assert r.status_code == 400 and r.json() == {"error": "Invalid audio"}
+            r = await c.post("/api/willow?model=tiny&voice_auth=true", content=b"", headers={"x-audio-codec": "pcm"})
+            assert r.status_code == 400
+
+    asyncio.run(go())

@@ -20,6 +20,7 @@ import threading
 import numpy as np
 
 from . import _lib, weights as W
+from .batching import MicroBatcher
 from .languages import LANGUAGE_CODES
 
 
@@ -113,6 +114,34 @@ def create_handle(a, arena, index, device, max_batch=8, max_beam=5, arena_device
     return h
 
 
+def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
+    B = mel.shape[0]
+    o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
+    pr = np.ascontiguousarray(np.asarray(prompts, np.int32).reshape(B, P))
+    ids = np.zeros((B, max_new), np.int32)
+    lens = np.zeros(B, np.int32)
+    scores = np.zeros(B, np.float32)
+    _lib.check(_lib.load().wis_generate(r.handle, _lib.ptr(mel), B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
+                                        ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        scores.ctypes.data_as(C.POINTER(C.c_float))))
+    return [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
+
+
+
+def _capacity(max_batch, key):
+    """Utterances per device batch: the decoder handles <= 48 rows per pass (rows = utterances x beam while decoding,
+    utterances x (prompt - 1) in the prefill)."""
+    P, beam = key[0], key[1]
+    return max(1, min(max_batch, 48 // max(beam, 1), 48 // max(P - 1, 1)))
+
+
+def _run_batch(replica, key, rows):
+    P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind = key
+    mel = np.ascontiguousarray(np.stack([m for m, _ in rows]))
+    with replica.lock:
+        return _generate_chunk(replica, mel, [p for _, p in rows], P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind)
+
+
 class Whisper:
     """One replica per entry of `device_index` (reference: `device_index=[*range(cuda_num_devices)]`, main.py:295)."""
 
@@ -124,35 +153,40 @@ class Whisper:
             raise ValueError(f"wis_hip runs on MI355X GPUs only (device={device!r}); there is no CPU path")
         _lib.require_gpu()
         self.compute_type = "float16"
+        cfg = {}
         if weights is None:
-            weights, arch = self._load(model_path)
-        self.arch = arch
+            weights, arch, cfg = self._load(model_path)
+        self.arch, self.decode_config = arch, cfg
         devs = list(device_index) if isinstance(device_index, (list, tuple)) else [int(device_index)]
         arena, index = W.build_arena(weights)
-        self._replicas = [_Replica(create_handle(arch, arena, index, d, max_batch, max_beam), d) for d in devs]
+        kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"))
+        self._replicas = [_Replica(create_handle(arch, arena, index, d, max_batch, max_beam, **kw), d) for d in devs]
         self.max_batch, self.max_beam = max_batch, max_beam
         self._pick = threading.Lock()
+        # concurrent generate() calls coalesce into device batches, one worker per GPU replica (wis_hip/batching.py)
+        self._batcher = MicroBatcher(self._replicas, _run_batch, lambda key: _capacity(max_batch, key))
 
     @staticmethod
     def _load(model_path):
+        """'synthetic:<size>[:seed]' (no checkpoint offline), a CTranslate2 model directory (what WIS ships) or a
+        Hugging Face safetensors checkpoint directory."""
         if isinstance(model_path, str) and model_path.startswith("synthetic:"):
             parts = model_path.split(":")
             size = parts[1]
             seed = int(parts[2]) if len(parts) > 2 else 1234
-            return W.synthetic_weights(size, seed=seed), W.arch(size)
+            return W.synthetic_weights(size, seed=seed), W.arch(size), {}
         if not os.path.isdir(model_path):
-            raise FileNotFoundError(f"{model_path}: not a CTranslate2 model directory (or use 'synthetic:<size>')")
-        w, _cfg = W.load_model_dir(model_path)
-        d = w["decoder/embeddings/weight"].shape[1]
-        for name, (dd, L, H) in W.ARCH.items():
-            if dd == d:
-                a = W.arch(name)
-                a["n_vocab"] = w["decoder/embeddings/weight"].shape[0]
-                return w, a
-        raise ValueError(f"unsupported d_model {d}")
+            raise FileNotFoundError(f"{model_path}: not a model directory (CTranslate2 or Hugging Face; or use 'synthetic:<size>')")
+        return W.load_model_dir(model_path)
+
+    def close(self):
+        b = self.__dict__.pop("_batcher", None)
+        if b is not None:
+            b.close()
 
     def __del__(self):
         try:
+            self.close()
             for r in getattr(self, "_replicas", []):
                 if r.handle:
                     _lib.load().wis_model_destroy(r.handle)
@@ -194,31 +228,14 @@ class Whisper:
         if any(len(p) != P for p in prompts):
             raise ValueError("all prompts must have the same length")
         max_new = min(max_length // 2, max_length - P)
-        per_call = max(1, min(self.max_batch, 48 // max(beam_size, 1), 48 // max(P - 1, 1)))
-        results = []
-        r = self._acquire()
-        try:
-            with r.lock:
-                for s in range(0, B, per_call):
-                    e = min(B, s + per_call)
-                    results.extend(self._generate_chunk(r, mel[s:e], prompts[s:e], P, beam_size, max_new, float(length_penalty),
-                                                        float(patience), suppress_blank, list(suppress_tokens) == [-1],
-                                                        fixed_new_tokens, input_kind))
-        finally:
-            self._release(r)
-        return results
+        key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), list(suppress_tokens) == [-1],
+               int(fixed_new_tokens), int(input_kind))
+        rows = [(np.ascontiguousarray(mel[b]), [int(t) for t in prompts[b]]) for b in range(B)]
+        return self._batcher.submit(key, rows)
 
     def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
-        B = mel.shape[0]
-        o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
-        pr = np.ascontiguousarray(np.asarray(prompts, np.int32).reshape(B, P))
-        ids = np.zeros((B, max_new), np.int32)
-        lens = np.zeros(B, np.int32)
-        scores = np.zeros(B, np.float32)
-        _lib.check(_lib.load().wis_generate(r.handle, _lib.ptr(mel), B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
-                                            ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
-                                            scores.ctypes.data_as(C.POINTER(C.c_float))))
-        return [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
+        """One `wis_generate` call on replica r (the caller serialises access to r)."""
+        return _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind)
 
     def detect_language(self, features):
         mel = self._features(features)

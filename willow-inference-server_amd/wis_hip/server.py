@@ -1,0 +1,178 @@
+"""Thin re-host of the reference's REST ASR endpoints over the HIP path:
+
+    GET  /api/ping      (main.py:1129-1137)
+    POST /api/asr       multipart upload `audio_file`             (main.py:1168-1234)
+    POST /api/willow    raw body + x-audio-* headers              (main.py:1237-1377)
+
+Same query parameters, same JSON fields, same 400 behaviour (`{"error": "Invalid force_language"}`, `{"error": "Invalid
+audio"}`).  Differences, all deliberate:
+  * inference runs OFF the event loop (a thread pool calls `do_whisper`; ctypes releases the GIL), so concurrent requests
+    reach the model together and the micro-batcher (wis_hip/batching.py) turns them into device batches - the reference blocks
+    its single worker inside `do_whisper` (main.py:1205, 1338);
+  * audio containers: WAV, FLAC and raw PCM are decoded natively (csrc/audio_io.c); other codecs need PyAV, which the
+    reference uses (`audio_to_wav`, main.py:108-120) and this image does not have -> HTTP 400 "Invalid audio";
+  * speaker verification (`voice_auth`) is a different model family and out of scope -> HTTP 400.
+WebRTC (`/api/rtc/asr`), TTS, nginx auth and the static sites are not re-hosted (out of scope).
+
+    uvicorn --factory wis_hip.server:create_app --host 0.0.0.0 --port 19000
+"""
+import asyncio
+import io
+import logging
+import os
+import wave
+from concurrent.futures import ThreadPoolExecutor
+from contextlib import asynccontextmanager
+from email.parser import BytesParser
+from email.policy import HTTP
+
+from fastapi import FastAPI, Request
+from fastapi.middleware.cors import CORSMiddleware
+from fastapi.responses import JSONResponse
+
+from .settings import get_api_settings
+from .whisper import InvalidAudio, WhisperModels, check_language, do_whisper
+
+logger = logging.getLogger("infer")
+
+
+def write_stream_wav(data, rate, bits, ch):
+    """Raw PCM from a Willow device -> in-memory WAV (main.py:98-105)."""
+    f = io.BytesIO()
+    w = wave.open(f, "wb")
+    w.setparams((ch, bits // 8, rate, 0, "NONE", "NONE"))
+    w.writeframesraw(bytes(data))
+    w.close()
+    f.seek(0)
+    return f
+
+
+def parse_multipart(body, content_type, field="audio_file"):
+    """The one multipart field /api/asr needs (python-multipart is not installed, so FastAPI's UploadFile is unavailable)."""
+    if "multipart/form-data" not in (content_type or ""):
+        raise ValueError("expected multipart/form-data")
+    msg = BytesParser(policy=HTTP).parsebytes(b"Content-Type: " + content_type.encode() + b"\r\nMIME-Version: 1.0\r\n\r\n" + body)
+    for part in msg.iter_parts():
+        if part.get_param("name", header="content-disposition") == field:
+            return part.get_payload(decode=True)
+    raise ValueError(f"multipart field {field!r} missing")
+
+
+def _as_bool(v, default):
+    if v is None:
+        return default
+    return str(v).strip().lower() in ("1", "true", "yes", "on")
+
+
+def create_app(models=None, settings=None, max_workers=None):
+    s = settings or (models.settings if models is not None else get_api_settings())
+    state = {"models": models}
+    # enough threads that a full device batch per GPU replica can be waiting in the micro-batcher at once
+    pool = ThreadPoolExecutor(max_workers=max_workers or 8 * max(1, s.max_batch), thread_name_prefix="wis-req")
+
+    def get_models():
+        if state["models"] is None:
+            state["models"] = WhisperModels(s)
+        return state["models"]
+
+    @asynccontextmanager
+    async def lifespan(_app):       # main.py:1097-1101: load, then warm on the reference clip when one is configured
+        if os.environ.get("WIS_PRELOAD", "0") == "1":
+            m = get_models()
+            m.preload()
+            clip = os.environ.get("WIS_WARM_CLIP")
+            if clip and os.path.exists(clip):
+                m.warm(clip)
+        yield
+        pool.shutdown(wait=False, cancel_futures=True)
+
+    app = FastAPI(title=s.name, description=s.description, version=s.version, openapi_url="/api/openapi.json", docs_url="/api/docs",
+                  redoc_url="/api/redoc", lifespan=lifespan)
+    if s.cors_allowed_origins:
+        app.add_middleware(CORSMiddleware, allow_origins=s.cors_allowed_origins, allow_credentials=True, allow_methods=["*"], allow_headers=["*"])
+
+    def params(request):
+        q = request.query_params
+        model = q.get("model", s.whisper_model_default)
+        beam = q.get("beam_size")
+        return dict(model=model, beam_size=int(beam) if beam not in (None, "") else s.beam_size,
+                    detect_language=_as_bool(q.get("detect_language"), s.detect_language), force_language=q.get("force_language") or None,
+                    translate=_as_bool(q.get("translate"), False))
+
+    async def run_whisper(audio_file, p):
+        loop = asyncio.get_running_loop()
+        return await loop.run_in_executor(pool, lambda: do_whisper(audio_file, p["model"], p["beam_size"], "transcribe", p["detect_language"],
+                                                                   p["force_language"], p["translate"], models=get_models()))
+
+    def bad(msg):
+        return JSONResponse(content={"error": msg}, status_code=400)
+
+    @app.get("/api/ping")
+    async def ping():
+        return JSONResponse(content={"message": "pong"})
+
+    @app.post("/api/asr")
+    async def asr(request: Request):
+        p = params(request)
+        if p["force_language"] and not check_language(p["force_language"]):
+            return bad("Invalid force_language")
+        try:
+            data = parse_multipart(await request.body(), request.headers.get("content-type"))
+            res = await run_whisper(io.BytesIO(data), p)
+        except InvalidAudio as e:
+            logger.debug("ASR: %s - returning HTTP 400", e)
+            return bad("Invalid audio")
+        except ValueError as e:        # malformed upload / unknown model (the reference lets these surface as 500s)
+            return bad(str(e))
+        language, text, infer_time, translation, infer_speedup, audio_duration = res
+        out = {"infer_time": infer_time, "infer_speedup": infer_speedup, "audio_duration": audio_duration, "language": language, "text": text}
+        if translation:
+            out["translation"] = translation
+        return JSONResponse(content=out)
+
+    @app.post("/api/willow")
+    async def willow(request: Request):
+        p = params(request)
+        q = request.query_params
+        save_audio, stats, voice_auth = _as_bool(q.get("save_audio"), False), _as_bool(q.get("stats"), False), _as_bool(q.get("voice_auth"), False)
+        if p["force_language"] and not check_language(p["force_language"]):
+            return bad("Invalid force_language")
+        if voice_auth:
+            return bad("voice_auth (speaker verification) is not part of this build")
+        h = request.headers
+        sample_rate, bits, channel = h.get("x-audio-sample-rate", "").lower(), h.get("x-audio-bits", "").lower(), h.get("x-audio-channel", "").lower()
+        codec = h.get("x-audio-codec", "").lower()
+        chunks = []
+        async for chunk in request.stream():
+            chunks.append(chunk)
+        body = b"".join(chunks)
+        try:
+            if codec == "pcm":
+                audio_file = write_stream_wav(body, int(sample_rate), int(bits), int(channel))
+            elif codec in ("wav", "flac"):
+                audio_file = io.BytesIO(body)
+            else:
+                raise InvalidAudio(f"codec {codec!r} needs PyAV")
+            if save_audio:
+                path = os.environ.get("WIS_SAVE_AUDIO_PATH", "nginx/static/audio/willow.wav")
+                os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+                with open(path, "wb") as f:
+                    f.write(audio_file.getbuffer())
+            res = await run_whisper(audio_file, p)
+        except InvalidAudio as e:
+            logger.debug("WILLOW: %s - returning HTTP 400", e)
+            return bad("Invalid audio")
+        except ValueError as e:        # bad x-audio-* header values / unknown model
+            return bad("Invalid audio" if "invalid literal" in str(e) else str(e))
+        language, text, infer_time, translation, infer_speedup, audio_duration = res
+        if stats:
+            out = {"infer_time": infer_time, "infer_speedup": infer_speedup, "audio_duration": audio_duration, "language": language, "text": text}
+        else:
+            out = {"language": language, "text": text}
+        if translation:
+            out["translation"] = translation
+        return JSONResponse(content=out)
+
+    app.state.wis = state
+    app.state.pool = pool
+    return app

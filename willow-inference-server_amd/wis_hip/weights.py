@@ -201,12 +201,168 @@ def read_ct2_model_bin(path):
     return out
 
 
-def load_model_dir(path):
-    """A CTranslate2 Whisper model directory -> (weights dict, config dict with suppress_ids / lang_ids)."""
-    w = read_ct2_model_bin(os.path.join(path, "model.bin"))
+def write_ct2_model_bin(path, weights, spec="WhisperSpec", revision=3, aliases=None):
+    """Writer for the same layout (used to convert HF checkpoints to a WIS model directory and by the tests)."""
+    ids = {np.dtype(np.float32): 0, np.dtype(np.int8): 1, np.dtype(np.int16): 2, np.dtype(np.int32): 3, np.dtype(np.float16): 4}
+
+    def wstr(f, x):
+        b = x.encode() + b"\0"
+        f.write(struct.pack("<H", len(b)) + b)
+
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 6))
+        wstr(f, spec)
+        f.write(struct.pack("<II", revision, len(weights)))
+        for name, v in weights.items():
+            v = np.ascontiguousarray(v)
+            wstr(f, name)
+            f.write(struct.pack("<B", v.ndim) + struct.pack("<" + "I" * v.ndim, *v.shape))
+            f.write(struct.pack("<BI", ids[v.dtype], v.nbytes))
+            f.write(v.tobytes())
+        aliases = aliases or {}
+        f.write(struct.pack("<I", len(aliases)))
+        for al, tgt in aliases.items():
+            wstr(f, al)
+            wstr(f, tgt)
+
+
+# ---- Hugging Face checkpoints (SURVEY §8(f)1; HF names per transformers modeling_whisper.py, SURVEY Appendix B) ----------------
+def from_hf_state_dict(sd, dtype=np.float16):
+    """HF `WhisperForConditionalGeneration` state dict (name -> ndarray) -> CTranslate2 WhisperSpec names.
+    q/k/v are fused into linear_0 ([3d, d]; the absent k_proj bias becomes zeros), the cross-attention k/v into
+    attention/linear_1 ([2d, d]); Q scaling stays OUT of the weights (CT2 applies it at run time; this engine folds it in
+    when it packs the decoder weights, csrc/model.hip)."""
+    g = lambda n: np.asarray(sd[n])
+    out = {}
+
+    def cast(v):
+        return np.ascontiguousarray(np.asarray(v, np.float32).astype(dtype))
+
+    pre = "model." if any(k.startswith("model.") for k in sd) else ""
+    d = g(pre + "encoder.conv1.weight").shape[0]
+    out["encoder/conv1/weight"], out["encoder/conv1/bias"] = cast(g(pre + "encoder.conv1.weight")), cast(g(pre + "encoder.conv1.bias"))
+    out["encoder/conv2/weight"], out["encoder/conv2/bias"] = cast(g(pre + "encoder.conv2.weight")), cast(g(pre + "encoder.conv2.bias"))
+    key = pre + "encoder.embed_positions.weight"
+    out["encoder/position_encodings/encodings"] = (np.ascontiguousarray(np.asarray(sd[key], np.float32)) if key in sd
+                                                   else sinusoids(N_AUDIO_CTX, d))
+    zeros = np.zeros(d, np.float32)
+    for side in ("encoder", "decoder"):
+        L = 1 + max(int(k.split(".")[len(pre.split(".")) + 1]) for k in sd if k.startswith(f"{pre}{side}.layers."))
+        for l in range(L):
+            p, q = f"{side}/layer_{l}/", f"{pre}{side}.layers.{l}."
+            out[p + "self_attention/layer_norm/gamma"], out[p + "self_attention/layer_norm/beta"] = cast(g(q + "self_attn_layer_norm.weight")), cast(g(q + "self_attn_layer_norm.bias"))
+            out[p + "self_attention/linear_0/weight"] = cast(np.concatenate([g(q + "self_attn.q_proj.weight"), g(q + "self_attn.k_proj.weight"), g(q + "self_attn.v_proj.weight")]))
+            out[p + "self_attention/linear_0/bias"] = cast(np.concatenate([np.asarray(g(q + "self_attn.q_proj.bias"), np.float32), zeros, np.asarray(g(q + "self_attn.v_proj.bias"), np.float32)]))
+            out[p + "self_attention/linear_1/weight"], out[p + "self_attention/linear_1/bias"] = cast(g(q + "self_attn.out_proj.weight")), cast(g(q + "self_attn.out_proj.bias"))
+            if side == "decoder":
+                out[p + "attention/layer_norm/gamma"], out[p + "attention/layer_norm/beta"] = cast(g(q + "encoder_attn_layer_norm.weight")), cast(g(q + "encoder_attn_layer_norm.bias"))
+                out[p + "attention/linear_0/weight"], out[p + "attention/linear_0/bias"] = cast(g(q + "encoder_attn.q_proj.weight")), cast(g(q + "encoder_attn.q_proj.bias"))
+                out[p + "attention/linear_1/weight"] = cast(np.concatenate([g(q + "encoder_attn.k_proj.weight"), g(q + "encoder_attn.v_proj.weight")]))
+                out[p + "attention/linear_1/bias"] = cast(np.concatenate([zeros, np.asarray(g(q + "encoder_attn.v_proj.bias"), np.float32)]))
+                out[p + "attention/linear_2/weight"], out[p + "attention/linear_2/bias"] = cast(g(q + "encoder_attn.out_proj.weight")), cast(g(q + "encoder_attn.out_proj.bias"))
+            out[p + "ffn/layer_norm/gamma"], out[p + "ffn/layer_norm/beta"] = cast(g(q + "final_layer_norm.weight")), cast(g(q + "final_layer_norm.bias"))
+            out[p + "ffn/linear_0/weight"], out[p + "ffn/linear_0/bias"] = cast(g(q + "fc1.weight")), cast(g(q + "fc1.bias"))
+            out[p + "ffn/linear_1/weight"], out[p + "ffn/linear_1/bias"] = cast(g(q + "fc2.weight")), cast(g(q + "fc2.bias"))
+        out[f"{side}/layer_norm/gamma"], out[f"{side}/layer_norm/beta"] = cast(g(f"{pre}{side}.layer_norm.weight")), cast(g(f"{pre}{side}.layer_norm.bias"))
+    out["decoder/embeddings/weight"] = cast(g(pre + "decoder.embed_tokens.weight"))
+    out["decoder/position_encodings/encodings"] = cast(g(pre + "decoder.embed_positions.weight"))
+    return out
+
+
+def _read_safetensors(path):
+    from safetensors import safe_open
+    out = {}
+    with safe_open(path, framework="np") as f:
+        for k in f.keys():
+            out[k] = f.get_tensor(k)
+    return out
+
+
+def load_hf_dir(path):
+    """A Hugging Face Whisper checkpoint directory (`config.json` + `model.safetensors` or its sharded index
+    [+ `generation_config.json`]) -> (CT2-named weights, arch dict, decode config)."""
+    with open(os.path.join(path, "config.json")) as f:
+        hc = json.load(f)
+    idx = os.path.join(path, "model.safetensors.index.json")
+    if os.path.exists(idx):
+        with open(idx) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+    else:
+        files = ["model.safetensors"]
+    sd = {}
+    for fn in files:
+        sd.update(_read_safetensors(os.path.join(path, fn)))
+    w = from_hf_state_dict(sd)
+    gen = {}
+    gj = os.path.join(path, "generation_config.json")
+    if os.path.exists(gj):
+        with open(gj) as f:
+            gen = json.load(f)
     cfg = {}
-    cj = os.path.join(path, "config.json")
-    if os.path.exists(cj):
-        with open(cj) as f:
-            cfg = json.load(f)
-    return w, cfg
+    sup = gen.get("suppress_tokens", hc.get("suppress_tokens"))
+    if sup:
+        # CT2's converter adds <|translate|>, <|transcribe|> handling through the prompt; the released WIS models carry
+        # them in suppress_ids (SURVEY row a11) - keep whatever the checkpoint says and add the two task tokens
+        cfg["suppress_ids"] = sorted(set(int(t) for t in sup) | {TRANSLATE, TRANSCRIBE})
+    beg = gen.get("begin_suppress_tokens", hc.get("begin_suppress_tokens"))
+    if beg:
+        cfg["suppress_ids_begin"] = [int(t) for t in beg]
+    if "lang_to_id" in gen:
+        cfg["lang_ids"] = sorted(int(v) for v in gen["lang_to_id"].values())
+    return w, arch_from_weights(w, hc.get("decoder_attention_heads")), cfg
+
+
+def arch_from_weights(w, n_heads=None):
+    d = w["decoder/embeddings/weight"].shape[1]
+    L = 1 + max(int(k.split("/")[1][len("layer_"):]) for k in w if k.startswith("decoder/layer_") and k.split("/")[1][len("layer_"):].isdigit())
+    H = n_heads or d // 64
+    if d % 64 or H * 64 != d:
+        raise ValueError(f"unsupported Whisper geometry d_model={d}, heads={H}: the engine is built for head_dim 64")
+    if w["encoder/conv1/weight"].shape[1] != N_MELS:
+        raise ValueError(f"{w['encoder/conv1/weight'].shape[1]} mel bins: only the 80-bin models WIS serves are supported")
+    size = next((k for k, v in ARCH.items() if v == (d, L, H)), f"custom-{d}x{L}")
+    return dict(size=size, d_model=d, n_layers=L, n_heads=H, n_vocab=int(w["decoder/embeddings/weight"].shape[0]),
+                n_audio_ctx=int(w["encoder/position_encodings/encodings"].shape[0]),
+                n_text_ctx=int(w["decoder/position_encodings/encodings"].shape[0]), n_mels=N_MELS)
+
+
+def load_model_dir(path):
+    """A Whisper model directory -> (weights, arch, decode config).  Accepted layouts: the CTranslate2 one WIS ships
+    (`model.bin` + `config.json` with suppress_ids / suppress_ids_begin / lang_ids; utils.sh:99-108, main.py:341-444) and a
+    Hugging Face checkpoint (`model.safetensors`)."""
+    if os.path.exists(os.path.join(path, "model.bin")):
+        w = read_ct2_model_bin(os.path.join(path, "model.bin"))
+        if "encoder/position_encodings/encodings" not in w:
+            w["encoder/position_encodings/encodings"] = sinusoids(N_AUDIO_CTX, w["decoder/embeddings/weight"].shape[1])
+        w["encoder/position_encodings/encodings"] = np.ascontiguousarray(w["encoder/position_encodings/encodings"], np.float32)
+        w.pop("decoder/projection/weight", None)       # alias of the embeddings (tied)
+        w = {k: (v if k == "encoder/position_encodings/encodings" else np.ascontiguousarray(v.astype(np.float16)))
+             for k, v in w.items() if not k.endswith("weight_scale")}
+        cfg = {}
+        cj = os.path.join(path, "config.json")
+        if os.path.exists(cj):
+            with open(cj) as f:
+                cj = json.load(f)
+            cfg = {k: cj[k] for k in ("suppress_ids", "suppress_ids_begin", "lang_ids") if k in cj}
+        return w, arch_from_weights(w), cfg
+    if os.path.exists(os.path.join(path, "model.safetensors")) or os.path.exists(os.path.join(path, "model.safetensors.index.json")):
+        return load_hf_dir(path)
+    raise FileNotFoundError(f"{path}: neither a CTranslate2 (model.bin) nor a Hugging Face (model.safetensors) Whisper directory")
+
+
+def convert_hf_to_ct2_dir(hf_dir, out_dir):
+    """`ct2-transformers-converter --quantization float16` equivalent for Whisper (utils.sh:104-105): writes model.bin +
+    config.json and copies the tokenizer files so `WhisperProcessor.from_pretrained(out_dir)` keeps working (main.py:331-333)."""
+    import shutil
+    w, a, cfg = load_hf_dir(hf_dir)
+    os.makedirs(out_dir, exist_ok=True)
+    write_ct2_model_bin(os.path.join(out_dir, "model.bin"), w, aliases={"decoder/projection/weight": "decoder/embeddings/weight"})
+    full = dict(suppress_ids=cfg.get("suppress_ids", SUPPRESS_IDS), suppress_ids_begin=cfg.get("suppress_ids_begin", SUPPRESS_IDS_BEGIN),
+                lang_ids=cfg.get("lang_ids", LANG_IDS), alignment_heads=[])
+    with open(os.path.join(out_dir, "config.json"), "w") as f:
+        json.dump(full, f)
+    for fn in ("tokenizer.json", "tokenizer_config.json", "preprocessor_config.json", "vocab.json", "merges.txt", "added_tokens.json",
+               "special_tokens_map.json", "normalizer.json"):
+        if os.path.exists(os.path.join(hf_dir, fn)):
+            shutil.copy(os.path.join(hf_dir, fn), os.path.join(out_dir, fn))
+    return a

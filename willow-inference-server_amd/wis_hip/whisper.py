@@ -101,6 +101,10 @@ def default_models():
     return _default_models
 
 
+class InvalidAudio(ValueError):
+    """The container could not be decoded (the REST layer answers HTTP 400 "Invalid audio", main.py:1311-1314)."""
+
+
 def check_language(language):
     return language in LANGUAGES
 
@@ -119,7 +123,15 @@ def do_whisper(audio_file, model, beam_size=None, task="transcribe", detect_lang
     first_time_start = time.perf_counter()
 
     # STEP 1 — load audio and extract features
-    pcm, sr = audio.load_audio(audio_file) if not isinstance(audio_file, np.ndarray) else (audio_file.astype(np.float32), 16000)
+    if isinstance(audio_file, np.ndarray):
+        pcm, sr = audio_file.astype(np.float32), 16000
+    else:
+        try:
+            pcm, sr = audio.load_audio(audio_file)
+        except Exception as e:
+            raise InvalidAudio(str(e)) from e
+    if pcm.shape[0] == 0:
+        raise InvalidAudio("empty audio")
     audio_duration = int(pcm.shape[0] / sr * 1000)
     if audio_duration >= s.long_beam_size_threshold:
         beam_size = s.long_beam_size
