@@ -152,6 +152,12 @@ int wis_last_timing(const wis_model_t* m, wis_timing_t* t);
  * text position `pos` (out: [6][16] uint64: QKV gemv, out-proj gemv, cross-attn, self-attn, FFN1 gemv, FFN2 gemv) */
 int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* out);
 
+/* ---- tuning tap: device timeline of one decode forward (B x beam rows at text position `pos`): for each of the
+ * n_dec_layers * 8 layer kernels (QKV, self-attn, out-proj, cross-Q, cross-attn, cross-out, FFN1, FFN2) the 100 MHz
+ * constant-clock time of its first workgroup start and last workgroup end -> out[k][2].  use_graph = 1 replays the
+ * forward as a HIP graph (what wis_generate does), 0 launches it eagerly. */
+int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, uint64_t* out, int n_out);
+
 /* ---- roofline tap (bench.py): launch the decoder's weight-streaming skinny-GEMM kernel once over
  * EVERY decoder weight matrix of the model (6 per layer + the vocabulary projection = the weight
  * stream of one decode step, >> the 256 MiB Infinity Cache for the large sizes), `passes` times,

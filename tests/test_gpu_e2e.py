@@ -218,10 +218,7 @@ def test_model_from_device_resident_arena(mels):
     del buf
     torch.cuda.empty_cache()
     host = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5)
-    dev = ct2.Whisper.__new__(ct2.Whisper)
-    dev._replicas, dev.max_batch, dev.max_beam, dev.arch = [ct2._Replica(h, 0)], 2, 5, a
-    import threading
-    dev._pick = threading.Lock()
+    dev = ct2.Whisper.from_handles([(h, 0)], a, max_batch=2, max_beam=5)
     f = ct2.StorageView.from_array(mels)
     r_host = host.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)
     r_dev = dev.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)

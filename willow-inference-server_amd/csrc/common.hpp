@@ -83,6 +83,14 @@ __device__ __forceinline__ void wave_argbest(float& v, int& idx) {
 __device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
   if (prof) prof[i] = __builtin_amdgcn_s_memtime();
 }
+// whole-kernel span for the step timeline (wis_debug_timeline): thread 0 of EVERY workgroup folds the 100 MHz constant
+// clock into slot 14 (min = first workgroup start) / slot 15 (max = last workgroup end) of the kernel's stamp row
+__device__ __forceinline__ void tl_begin(unsigned long long* prof) {
+  if (prof) atomicMin(prof + 14, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void tl_end(unsigned long long* prof) {
+  if (prof) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
 // exact (erf) GELU, as torch.nn.functional.gelu default / CT2 GELU
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   float4 xv[RMAX][2], gv[2], bv[2];
   float cshift[RMAX];
   unsigned long long* pf = (blockIdx.x == 0 && tid == 0) ? p.prof : nullptr;
+  if (tid == 0) tl_begin(p.prof);
   stamp(pf, 0);
   if (fast) {
     const float4* x4 = reinterpret_cast<const float4*>(p.x);
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
   }
   stamp(pf, 6);
+  if (tid == 0) tl_end(p.prof);
 }
 
 int launch_gemv(hipStream_t st, const GemvP& p) {
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   __shared__ float red[4][64];
   const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, pl = lane >> 3, c = lane & 7;
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
+  if (lane == 0) tl_begin(prof);
   stamp(pf, 0);
   const int ls = (m / rpu) * sstride + (m % rpu) * rmul;
   const int* arow = anc + (size_t)ls * ctx;
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   const float o = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
   out[(size_t)m * d + h * 64 + lane] = (f16)(o / l_run);
   stamp(pf, 4);
+  if (lane == 0) tl_end(prof);
 }
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof) {
@@ -518,6 +522,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int klo = c * CL, n = (klo + CL <= T) ? CL : T - klo;   // 1 <= n <= 256, klo % 32 == 0
   unsigned long long* pf = (c == 0 && h == 0 && b == 0 && tid == 0) ? prof : nullptr;
+  if (tid == 0) tl_begin(prof);
   stamp(pf, 0);
 
   // ---- loads: Q (B operand, lane = (row r, k-quarter)), K fragments, V^T fragments
@@ -634,6 +639,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   }
   __syncthreads();
   stamp(pf, 6);
+  if (tid == 0) tl_end(prof);
   if (!s_last) return;
   // one round: thread = (row r, dh pair); plain (pipelined) loads, made safe by the agent-scope acquire that lane 0
   // executed after winning the ticket (guide §6 G16 consumer form: relaxed ticket -> ONE acquire -> barrier -> plain loads;
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     *reinterpret_cast<f16x2*>(out + (size_t)(b * R + r) * d + h * 64 + 2 * dp) = o2;
   }
   stamp(pf, 7);
+  if (tid == 0) tl_end(prof);
 }
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,

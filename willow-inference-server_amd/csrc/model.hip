@@ -93,7 +93,8 @@ struct wis_model {
   int device;
   DeviceCtx* ctx;
   hipStream_t st;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;    // slabs (hipMalloc'ed), carved by dalloc()
+  char* slab_cur = nullptr; size_t slab_left = 0;
   size_t bytes = 0;
   // weights
   f16 *w_conv1, *w_conv2; float *b_conv1, *b_conv2, *enc_pos, *enc_ln_g, *enc_ln_b;
@@ -118,19 +119,32 @@ struct wis_model {
   wis_timing_t timing;
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph;
-  unsigned long long* d_prof;   // [6][16] phase stamps of layer 0 (wis_debug_phase_cycles)
-  bool prof_on;
+  unsigned long long* d_prof;   // [L*8][16] stamp rows, one per layer kernel (wis_debug_phase_cycles / wis_debug_timeline)
+  bool prof_on; bool prof_all;
 };
 
 namespace {
 
+// Bump allocator over large slabs: the ~700 tensors and buffers of a replica come from a handful of hipMalloc calls, so the
+// small per-layer parameters (biases, LayerNorm vectors: 2.5-10 KB) sit next to their matrices inside the same large-page
+// fragments instead of each owning a 4 KB page - every decode kernel touches 3-5 of them on its critical path, and a
+// translation miss there costs more than the kernel's whole weight stream.
+constexpr size_t SLAB_BYTES = (size_t)1 << 30;
 template <class T>
 int dalloc(wis_model* m, T** p, size_t n_elems) {
-  void* q = nullptr;
   size_t b = n_elems * sizeof(T); if (b == 0) b = 16;
-  hipError_t e = hipMalloc(&q, b);
-  if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", b, hipGetErrorString(e)); return WIS_E_NOMEM; }
-  m->allocs.push_back(q); m->bytes += b; *p = reinterpret_cast<T*>(q);
+  const size_t align = b >= ((size_t)1 << 20) ? ((size_t)1 << 16) : 256;
+  size_t pad = (align - (reinterpret_cast<uintptr_t>(m->slab_cur) & (align - 1))) & (align - 1);
+  if (!m->slab_cur || pad + b > m->slab_left) {
+    const size_t sb = b > SLAB_BYTES ? ((b + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1)) : SLAB_BYTES;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, sb);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", sb, hipGetErrorString(e)); return WIS_E_NOMEM; }
+    m->allocs.push_back(q); m->slab_cur = static_cast<char*>(q); m->slab_left = sb; pad = 0;
+  }
+  m->slab_cur += pad; m->slab_left -= pad;
+  *p = reinterpret_cast<T*>(m->slab_cur);
+  m->slab_cur += b; m->slab_left -= b; m->bytes += b + pad;
   return WIS_OK;
 }
 inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
@@ -330,7 +344,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->d_in, (size_t)Bm * WIS_N_SAMPLES));
   WIS_RET(dalloc(m, &m->d_nsamp, Bm));
   WIS_RET(dalloc(m, &m->d_probs, (size_t)Bm * (c.n_lang > 0 ? c.n_lang : 1)));
-  WIS_RET(dalloc(m, &m->d_prof, (size_t)6 * 16));
+  WIS_RET(dalloc(m, &m->d_prof, (size_t)c.n_dec_layers * 8 * 16));
   WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 65536, hipHostMallocDefault));
   for (int i = 0; i < 8; ++i) WIS_HIP_CHECK(hipEventCreate(&m->ev[i]));
   return WIS_OK;
@@ -416,7 +430,8 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
-    unsigned long long* pr = (m->prof_on && l == 0) ? m->d_prof : nullptr;
+    // stamp rows of this layer's 8 kernels: QKV, self-attn, out, cross-Q, cross-attn, cross-out, FFN1, FFN2
+    unsigned long long* pr = (m->prof_on && (l == 0 || m->prof_all)) ? m->d_prof + (size_t)l * 8 * 16 : nullptr;
     GemvP g; memset(&g, 0, sizeof(g));
     // self-attention block
     g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
@@ -424,28 +439,29 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.prof = pr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 48 : nullptr));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
     memset(&g, 0, sizeof(g));
-    g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 16 : nullptr;
+    g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // cross-attention block
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_ln_gemv(m, st, g));
-    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 32 : nullptr));
+    static const bool exp_skip_cq = getenv("WIS_EXP_SKIP_CQ") != nullptr;
+    if (!exp_skip_cq) WIS_RET(launch_ln_gemv(m, st, g));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
     memset(&g, 0, sizeof(g));
-    g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID;
+    g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 64 : nullptr;
+    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
-    g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
+    g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 112 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
@@ -772,14 +788,60 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
   std::vector<int> tok(Mrows, 100), ps(Mrows, pos), slot(Mrows), ls(Mrows);
   for (int r = 0; r < Mrows; ++r) { slot[r] = r; ls[r] = r; }
   WIS_RET(upload_rows(m, tok, ps, slot, ls));
-  WIS_HIP_CHECK(hipMemsetAsync(m->d_prof, 0, 6 * 16 * 8, m->st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->d_prof, 0, 8 * 16 * 8, m->st));
   WIS_RET(dec_forward(m, Mrows, beam, B, false, beam, 1));   // warm
   m->prof_on = true;
   int rc = dec_forward(m, Mrows, beam, B, false, beam, 1);
   m->prof_on = false;
   WIS_RET(rc);
-  WIS_HIP_CHECK(hipMemcpyAsync(out, m->d_prof, 6 * 16 * 8, hipMemcpyDeviceToHost, m->st));
+  // API order: QKV gemv, out-proj gemv, cross-attn, self-attn, FFN1 gemv, FFN2 gemv  <-  rows 0, 2, 4, 1, 6, 7
+  static const int rows[6] = {0, 2, 4, 1, 6, 7};
+  for (int i = 0; i < 6; ++i)
+    WIS_HIP_CHECK(hipMemcpyAsync(out + i * 16, m->d_prof + rows[i] * 16, 16 * 8, hipMemcpyDeviceToHost, m->st));
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  return WIS_OK;
+}
+
+int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, uint64_t* out, int n_out) {
+  if (!m || !out) { set_error("wis_debug_timeline: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, B, beam));
+  const int Mrows = B * beam, ctx = m->cfg.n_text_ctx, nk = m->cfg.n_dec_layers * 8;
+  if (pos < 0 || pos >= ctx || n_out < nk) { set_error("wis_debug_timeline: bad pos / out size (need %d rows)", nk); return WIS_E_ARG; }
+  std::vector<int> anc((size_t)Mrows * ctx);
+  for (int r = 0; r < Mrows; ++r) for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = r;
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  std::vector<int> tok(Mrows, 100), ps(Mrows, pos), slot(Mrows), ls(Mrows);
+  for (int r = 0; r < Mrows; ++r) { slot[r] = r; ls[r] = r; }
+  WIS_RET(upload_rows(m, tok, ps, slot, ls));
+  std::vector<unsigned long long> init((size_t)nk * 16, 0ull);
+  for (int k = 0; k < nk; ++k) init[(size_t)k * 16 + 14] = ~0ull;
+  m->prof_on = true; m->prof_all = true;
+  int rc = WIS_OK;
+  hipGraph_t g = nullptr; hipGraphExec_t gx = nullptr;
+  do {
+    if (use_graph) {
+      if (hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { set_error("capture failed"); rc = WIS_E_HIP; break; }
+      rc = dec_forward(m, Mrows, beam, B, true, beam, 1);
+      if (hipStreamEndCapture(m->st, &g) != hipSuccess || rc) { if (!rc) { set_error("end capture failed"); rc = WIS_E_HIP; } break; }
+      if (hipGraphInstantiate(&gx, g, nullptr, nullptr, 0) != hipSuccess) { set_error("instantiate failed"); rc = WIS_E_HIP; break; }
+    }
+    for (int it = 0; it < 3 && !rc; ++it) {   // the last iteration is the one reported
+      if (hipMemcpyAsync(m->d_prof, init.data(), init.size() * 8, hipMemcpyHostToDevice, m->st) != hipSuccess) { rc = WIS_E_HIP; break; }
+      hipStreamSynchronize(m->st);
+      if (use_graph) { if (hipGraphLaunch(gx, m->st) != hipSuccess) { set_error("graph launch failed"); rc = WIS_E_HIP; } }
+      else rc = dec_forward(m, Mrows, beam, B, true, beam, 1);
+      hipStreamSynchronize(m->st);
+    }
+  } while (0);
+  m->prof_on = false; m->prof_all = false;
+  if (gx) hipGraphExecDestroy(gx);
+  if (g) hipGraphDestroy(g);
+  WIS_RET(rc);
+  std::vector<unsigned long long> h((size_t)nk * 16);
+  WIS_HIP_CHECK(hipMemcpy(h.data(), m->d_prof, h.size() * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < nk; ++k) { out[2 * k] = h[(size_t)k * 16 + 14]; out[2 * k + 1] = h[(size_t)k * 16 + 15]; }
   return WIS_OK;
 }
 

@@ -166,6 +166,19 @@ class Whisper:
         # concurrent generate() calls coalesce into device batches, one worker per GPU replica (wis_hip/batching.py)
         self._batcher = MicroBatcher(self._replicas, _run_batch, lambda key: _capacity(max_batch, key))
 
+    @classmethod
+    def from_handles(cls, handles, arch, max_batch=8, max_beam=5, decode_config=None):
+        """Wrap replicas that already exist: [(wis_model handle, device), ...] - e.g. models created from a weight arena an
+        RCCL broadcast delivered straight into device memory (`create_handle(arena_device_ptr=...)`, wis_hip/dist.py)."""
+        self = cls.__new__(cls)
+        self.compute_type = "float16"
+        self.arch, self.decode_config = arch, decode_config or {}
+        self._replicas = [_Replica(h, d) for h, d in handles]
+        self.max_batch, self.max_beam = max_batch, max_beam
+        self._pick = threading.Lock()
+        self._batcher = MicroBatcher(self._replicas, _run_batch, lambda key: _capacity(max_batch, key))
+        return self
+
     @staticmethod
     def _load(model_path):
         """'synthetic:<size>[:seed]' (no checkpoint offline), a CTranslate2 model directory (what WIS ships) or a
