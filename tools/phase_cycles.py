@@ -10,16 +10,17 @@ sys.path.insert(0, os.path.join(ROOT, "willow-inference-server_amd"))
 from wis_hip import _lib, ctranslate2 as ct2, weights as W
 
 size = sys.argv[1] if len(sys.argv) > 1 else "large"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 lib = _lib.load()
 a = W.arch(size)
 w = W.synthetic_weights(size)
 arena, index = W.build_arena(w)
-h = ct2.create_handle(a, arena, index, 0, max_batch=1, max_beam=5)
+h = ct2.create_handle(a, arena, index, 0, max_batch=B, max_beam=5)
 out = np.zeros((6, 16), np.uint64)
 names = ["gemv QKV (LN)", "gemv out-proj", "cross-attn", "self-attn", "gemv FFN1 (LN)", "gemv FFN2"]
 for pos in (10,):
-    _lib.check(lib.wis_debug_phase_cycles(h, 1, 5, pos, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    _lib.check(lib.wis_debug_phase_cycles(h, B, 5, pos, out.ctypes.data_as(C.POINTER(C.c_uint64))))
     for i, n in enumerate(names):
-        st = [int(v) for v in out[i] if v]
+        st = [int(v) for v in out[i][:14] if v]
         if st:
             print(f"{n:16s} pos {pos}: total {st[-1] - st[0]:6d} cyc; phases {[st[j + 1] - st[j] for j in range(len(st) - 1)]}")

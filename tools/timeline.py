@@ -12,13 +12,14 @@ from wis_hip import _lib, ctranslate2 as ct2  # noqa: E402
 size = sys.argv[1] if len(sys.argv) > 1 else "large"
 beam = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 pos = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-model = ct2.Whisper(f"synthetic:{size}", max_batch=1, max_beam=5)
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+model = ct2.Whisper(f"synthetic:{size}", max_batch=B, max_beam=5)
 L = model.arch["n_layers"]
 names = ["QKV", "self-attn", "out", "cross-Q", "cross-attn", "cross-out", "FFN1", "FFN2"]
 lib = _lib.load()
-for graph in (0, 1):
+for graph in (1,):
     out = np.zeros((L * 8, 2), np.uint64)
-    _lib.check(lib.wis_debug_timeline(model._replicas[0].handle, 1, beam, pos, graph, out.ctypes.data_as(C.POINTER(C.c_uint64)), L * 8))
+    _lib.check(lib.wis_debug_timeline(model._replicas[0].handle, B, beam, pos, graph, out.ctypes.data_as(C.POINTER(C.c_uint64)), L * 8))
     t = out.astype(np.int64) * 10           # ns (100 MHz clock)
     dur = (t[:, 1] - t[:, 0]).reshape(L, 8)
     gap = np.zeros(L * 8, np.int64)

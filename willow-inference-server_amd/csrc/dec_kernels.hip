@@ -129,13 +129,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; cshift[r] = reinterpret_cast<const float*>(p.x)[(size_t)rr * K]; }
   }
   // f16 activations (attention / FFN hidden output of the previous kernel): same idea, up to 13 x 16 B per thread
+  // (MB >= 2: up to 48 rows x 1280 columns per chunk = 30 x 16 B per thread; K larger than the chunk is walked chunk by
+  // chunk, the next chunk's activations are fetched into registers while the matrix cores work on the current one)
   constexpr bool fastx = MODE == 2;
-  constexpr int NXH = fastx ? 13 : 1;
+  constexpr int NXH = fastx ? (MB == 1 ? 13 : 30) : 1;
   u32x4 xh[NXH];
+  const int c8 = KC >> 3, k8n = K >> 3, nx = M * c8;     // 16-byte pieces per chunk row / per full row / per chunk
   if (fastx) {
     const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
+    if (KC == K) {
 #pragma unroll
-    for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < M * (K >> 3)) xh[i] = x8[idx]; }
+      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) xh[i] = x8[idx]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = idx / c8; xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
+    }
   }
   // weight prefetch for chunk 0 (independent of x)
   u32x4 wf[GV_PF];
@@ -188,11 +196,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       }
     }
   } else if (fastx) {
-    const int c8 = K >> 3;
 #pragma unroll
     for (int i = 0; i < NXH; ++i) {
       const int idx = tid + 256 * i;
-      if (idx < M * c8) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
+      if (idx < nx) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
     }
   } else if (ln) {
     const float* xf = reinterpret_cast<const float*>(p.x);
@@ -223,9 +230,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const int c8n = KC / 8;
   for (int kc0 = 0; kc0 < K; kc0 += KC) {
     const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * wstep;
-    if (kc0 > 0) {
+    const bool more = kc0 + KC < K;
+    if (kc0 > 0 && SC == 0) {
 #pragma unroll
-      for (int u = 0; u < GV_PF; ++u) if ((SC > 0 || u < S) && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep);
+      for (int u = 0; u < GV_PF; ++u) if (u < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep);
+    }
+    if (fastx && more) {   // next chunk's activations: in flight during this chunk's MFMAs
+      const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x) + ((kc0 + KC) >> 3);
+#pragma unroll
+      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = idx / c8; xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
     }
     if (!fast && !fastx) {
       // stage x[:, kc0:kc0+KC] as f16
@@ -267,6 +280,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
           const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + u) * 32);
           acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb, acc[mb], 0, 0, 0);
         }
+        if (more && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)(KC / 32 + u) * wstep);   // same slot, next chunk
       }
     } else {
       for (int base = 0; base < S; base += GV_PF) {
@@ -285,6 +299,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       }
     }
     __syncthreads();
+    if (fastx && more) {
+#pragma unroll
+      for (int i = 0; i < NXH; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < nx) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
+      }
+    }
   }
   stamp(pf, 4);
   // cross-wave reduction; D[i = n][j = m]: lane holds m = lane&15, n = 4*(lane>>4) + r
@@ -336,10 +357,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
 int launch_gemv(hipStream_t st, const GemvP& p) {
   if (p.M < 1 || p.M > MAX_ROWS || p.K % 128 || p.N % 4) { set_error("gemv: M=%d N=%d K=%d unsupported", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
   const int MB = cdiv(p.M, 16);
-  // largest K-chunk (multiple of 128 dividing K) whose f16 image of M rows fits 64 KiB
+  // largest K-chunk (multiple of 128 dividing K) whose f16 image of M rows fits the LDS: 64 KiB for <= 16 rows (several
+  // workgroups per CU), the whole 160 KiB CU array (minus slack) for the batched-decode row counts
+  static size_t lds_dev_max = 0;
+  if (!lds_dev_max) {
+    int dev = 0, v = 0; hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v < 65536) v = 65536;
+    lds_dev_max = (size_t)v;
+  }
+  // (two half-size chunks so that two workgroups fit a CU were measured slower for N = 4d: 24.3 vs 19.0 us at 40 rows)
+  const size_t lds_cap = MB == 1 ? 65536 : (lds_dev_max > 155648 ? 155648 : lds_dev_max);
   int KC = p.K;
   const size_t aux = (size_t)4 * MB * 64 * 16 + MAX_ROWS * 8 + 4 * 16 * 4 + 16;   // red + stats + sred (+ alignment)
-  while ((size_t)p.M * (KC + 8) * 2 + aux > 65536) {
+  while ((size_t)p.M * (KC + 8) * 2 + aux > lds_cap) {
     int next = 0;
     for (int c = KC - 128; c >= 128; c -= 128) if (p.K % c == 0) { next = c; break; }
     if (!next) { set_error("gemv: cannot chunk K=%d for M=%d", p.K, p.M); return WIS_E_UNSUPPORTED; }
@@ -351,20 +381,27 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int npad = cdiv(p.N, rows) * rows;
   dim3 grid(npad / rows), block(256);
   int mode = 0;
-  if (KC == p.K) {
-    if ((p.flags & GV_LN) && p.M <= 8 && p.K <= 2048) mode = 1;
-    else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
-  }
-  const int sc = (KC == p.K && (p.K / 128 == 3 || p.K / 128 == 4 || p.K / 128 == 6 || p.K / 128 == 8 || p.K / 128 == 10)) ? p.K / 128 : 0;
-#define WIS_GV(MBv, MODEv, SCv, RMv) hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv>), grid, block, lds, st, pp, KC)
+  if (MB == 1) {
+    if (KC == p.K) {
+      if ((p.flags & GV_LN) && p.M <= 8 && p.K <= 2048) mode = 1;
+      else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
+    }
+  } else if (!(p.flags & GV_LN) && p.M * (KC / 8) <= 30 * 256) mode = 2;       // register-staged f16 chunks (single or multi chunk)
+  const int sck = KC / 128;
+  const int sc = ((KC == p.K || mode == 2) && (sck == 3 || sck == 4 || sck == 6 || sck == 8 || sck == 10)) ? sck : 0;
+#define WIS_GV(MBv, MODEv, SCv, RMv) do { \
+    if (lds > 65536) { static bool big_ok = false; \
+      if (!big_ok) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
+                       set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } big_ok = true; } } \
+    hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv>), grid, block, lds, st, pp, KC); } while (0)
 #define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \
                                                       case 8: WIS_GV(MBv, MODEv, 8, RMv); break; case 10: WIS_GV(MBv, MODEv, 10, RMv); break; default: WIS_GV(MBv, MODEv, 0, RMv); } } while (0)
   if (MB == 1) {
     if (mode == 1) { if (p.M <= 3) WIS_GV_SC(1, 1, 3); else if (p.M <= 5) WIS_GV_SC(1, 1, 5); else WIS_GV_SC(1, 1, 8); }
     else if (mode == 2) WIS_GV_SC(1, 2, 1); else WIS_GV_SC(1, 0, 1);
   }
-  else if (MB == 2) { if (mode == 2) WIS_GV(2, 2, 0, 1); else WIS_GV(2, 0, 0, 1); }
-  else { if (mode == 2) WIS_GV(3, 2, 0, 1); else WIS_GV(3, 0, 0, 1); }
+  else if (MB == 2) { if (mode == 2) WIS_GV_SC(2, 2, 1); else WIS_GV(2, 0, 0, 1); }
+  else { if (mode == 2) WIS_GV_SC(3, 2, 1); else WIS_GV(3, 0, 0, 1); }
 #undef WIS_GV_SC
 #undef WIS_GV
   return WIS_OK;

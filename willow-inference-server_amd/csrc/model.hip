@@ -426,7 +426,9 @@ static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
 int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
-  const int chunks = (B * H * 12 <= 512) ? 12 : 6;   // 128-key chunks while that gives <= 2 workgroups per CU, else 256-key chunks
+  static const int env_chunks = getenv("WIS_CROSS_CHUNKS") ? atoi(getenv("WIS_CROSS_CHUNKS")) : 0;
+  // 256-key chunks (6 per utterance-head): measured faster than 128-key chunks at every batch size (fewer partials to publish and combine)
+  const int chunks = env_chunks ? env_chunks : 6;
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
@@ -448,8 +450,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    static const bool exp_skip_cq = getenv("WIS_EXP_SKIP_CQ") != nullptr;
-    if (!exp_skip_cq) WIS_RET(launch_ln_gemv(m, st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
