@@ -1,4 +1,5 @@
-"""Tuning aid: print the phase stamps (shader clock cycles) of decoder layer 0's kernels for large-v2, beam 5."""
+"""Tuning aid: print the phase stamps (shader clock cycles) of decoder layer 0 kernels (needs a tap build:
+WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1 python willow-inference-server_amd/build.py)."""
 import ctypes as C
 import os
 import sys

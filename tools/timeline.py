@@ -1,5 +1,5 @@
 """Device timeline of one decode step (wis_debug_timeline): per layer-kernel duration and the idle gap before it.
-usage: python tools/timeline.py [size] [beam] [pos]"""
+usage: python tools/timeline.py [size] [beam] [pos] [batch]   (needs a tap build: WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1 python willow-inference-server_amd/build.py)"""
 import ctypes as C
 import os
 import sys

@@ -79,17 +79,28 @@ __device__ __forceinline__ void wave_argbest(float& v, int& idx) {
   const int mi = wave_min_i(v == mx ? idx : 0x7fffffff);
   v = mx; idx = mi;
 }
-// shader-clock stamp for the optional phase profiler (wis_debug_phase_cycles)
+// Tuning taps (wis_debug_phase_cycles / wis_debug_timeline): compiled in only with -DWIS_TAPS=1
+// (WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1 python willow-inference-server_amd/build.py); the product build carries no tap code.
+#ifndef WIS_TAPS
+#define WIS_TAPS 0
+#endif
+// shader-clock stamp of workgroup 0 for the phase profiler
 __device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
+#if WIS_TAPS
   if (prof) prof[i] = __builtin_amdgcn_s_memtime();
+#endif
 }
-// whole-kernel span for the step timeline (wis_debug_timeline): thread 0 of EVERY workgroup folds the 100 MHz constant
-// clock into slot 14 (min = first workgroup start) / slot 15 (max = last workgroup end) of the kernel's stamp row
+// whole-kernel span for the step timeline: thread 0 of EVERY workgroup folds the 100 MHz constant clock into slot 14
+// (min = first workgroup start) / slot 15 (max = last workgroup end) of the kernel's stamp row
 __device__ __forceinline__ void tl_begin(unsigned long long* prof) {
+#if WIS_TAPS
   if (prof) atomicMin(prof + 14, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 __device__ __forceinline__ void tl_end(unsigned long long* prof) {
+#if WIS_TAPS
   if (prof) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 // exact (erf) GELU, as torch.nn.functional.gelu default / CT2 GELU
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

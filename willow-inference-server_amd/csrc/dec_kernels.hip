@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const int c8 = KC >> 3, k8n = K >> 3, nx = M * c8;     // 16-byte pieces per chunk row / per full row / per chunk
   if (fastx) {
     const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
-    if (KC == K) {
+    if (MB == 1 || KC == K) {   // MB == 1: the launcher only selects this mode for a single chunk
 #pragma unroll
       for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) xh[i] = x8[idx]; }
     } else {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const int c8n = KC / 8;
   for (int kc0 = 0; kc0 < K; kc0 += KC) {
     const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * wstep;
-    const bool more = kc0 + KC < K;
+    const bool more = MB > 1 && kc0 + KC < K;     // multi-chunk register staging exists for the batched row counts only
     if (kc0 > 0 && SC == 0) {
 #pragma unroll
       for (int u = 0; u < GV_PF; ++u) if (u < S && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep);

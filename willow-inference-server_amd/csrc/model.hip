@@ -778,6 +778,7 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, 
 
 int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* out) {
   if (!m || !out) { set_error("wis_debug_phase_cycles: bad argument"); return WIS_E_ARG; }
+  if (!WIS_TAPS) { set_error("tuning taps are not compiled in (rebuild with WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1)"); return WIS_E_UNSUPPORTED; }
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, beam));
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx;
@@ -805,6 +806,7 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
 
 int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, uint64_t* out, int n_out) {
   if (!m || !out) { set_error("wis_debug_timeline: bad argument"); return WIS_E_ARG; }
+  if (!WIS_TAPS) { set_error("tuning taps are not compiled in (rebuild with WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1)"); return WIS_E_UNSUPPORTED; }
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, beam));
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx, nk = m->cfg.n_dec_layers * 8;
