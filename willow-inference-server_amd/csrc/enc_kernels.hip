@@ -79,58 +79,74 @@ int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const f
 // =======================================================================================
 // GEMM  C[m][n] = epi( sum_k A(m)[k] * W[n][k] ),  A rows addressed as
 //   A + (m / a_rpb) * a_bs + (m % a_rpb) * a_rs     (implicit im2col for the convs).
-constexpr int BN = 128, BK = 64, LSTR = 72;  // 64-deep k-tiles; LDS row pitch 72 f16 = 144 B (conflict-free ds_read_b128)
+constexpr int BK = 64, LSTR = 72;  // 64-deep k-tiles; LDS row pitch 72 f16 = 144 B (conflict-free ds_read_b128)
 // BM_ = 128 (default) or 64: the 64-row variant doubles the workgroup count for the N = d GEMMs (out-proj, conv2), which
 // would otherwise launch only ceil(1500/128) * d/128 = 120 workgroups on 256 CUs.
 // Tile order: the grid is 1-D; workgroup ids are first regrouped so that the ids an XCD receives (id % 8, observed dispatch
 // order — a speed assumption only) form one contiguous range, then mapped m-fastest, so an XCD works on a few W column
 // panels (<= ~2 MB, L2-resident) against all of A.
 
-template <class Epi, int BM_>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
-  constexpr int MI = BM_ / 64;                 // 32-row MFMA sub-tiles per wave along M
-  constexpr int NA = BM_ / 32;                 // 16-byte A chunks per thread per k-tile (W: always 4)
+// Tile shapes (BM_ x BN_, WM_ x WN_ waves, wave tile (BM_/WM_) x (BN_/WN_)):
+//   128x128, 2x2 waves   the B = 1 encoder shapes with >= 240 tiles (two workgroups co-reside per CU)
+//    64x128, 2x2 waves   N = d GEMMs at B = 1 (out-proj, conv2): 240 instead of 120 workgroups
+//   256x256, 2x4 waves   batched encoders (M = B * 1500): 128 FLOP per operand byte fetched instead of 64
+// Measured on MI355X (tools/gemm_tiles.sh; per-GEMM us at M = 1500 | M = 12000):
+//   QKV (N = 3d)   128x128 30.3 | 189     64x128 43.1     128x192 34.6     128x256 39.8     256x128 32.6 | 200     256x256 48.9 | 162
+//   FFN1 (N = 4d)  128x128 37.9 | 281     64x128 50.1                      128x256 50.3     256x128 39.0 | 298     256x256 61.0 | 258
+// and, for the 128x128 tile at M = 1500, three different operand pipelines - register staging one k-tile ahead (this kernel),
+// a 2-stage LDS-DMA double buffer, and a 4-stage LDS-DMA ring with counted vmcnt waits, a raw s_barrier and inline-asm
+// fragment reads (three stages in flight) - all land on the same 6.4 ms encoder: the loop is not latency-bound; with two
+// workgroups per CU the CUs ingest operands at ~30 GB/s each (~7.6 TB/s aggregate L2 -> CU), which is what 64 FLOP per
+// fetched byte turns into ~490 TFLOP/s.  torch.matmul (hipBLASLt) on the same shapes: 21.7 / 23.9 us (tools/mm_bench.py).
+template <class Epi, int BM_, int BN_, int WM_, int WN_>
+__global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi epi) {
+  constexpr int T = 64 * WM_ * WN_;            // threads
+  constexpr int TM = BM_ / WM_, TN = BN_ / WN_;   // wave tile
+  constexpr int MI = TM / 32, NI = TN / 32;    // 32x32 MFMA sub-tiles per wave
+  constexpr int RP = T / 8;                    // tile rows covered by one 16-byte-per-thread pass
+  constexpr int NA = BM_ / RP, NW = BN_ / RP;  // passes per k-tile (A, W): 2 or 4
+  static_assert((NA == 2 || NA == 4) && (NW == 2 || NW == 4), "loader passes");
   __shared__ __attribute__((aligned(16))) f16 sA[2][BM_ * LSTR];
-  __shared__ __attribute__((aligned(16))) f16 sW[2][BN * LSTR];
+  __shared__ __attribute__((aligned(16))) f16 sW[2][BN_ * LSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN_, wn = wave % WN_, l31 = lane & 31, hi = lane >> 5;
   // XCD-aware, bijective regrouping of the linear workgroup id (guide T1), then m-fastest tile coordinates
-  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN);
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
   int wg;
   {
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN;
+  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN_;
 
-  // loader mapping: 16-byte chunk c -> row c>>3, k-offset (c&7)*8; rows lrow + 32*i (explicitly named registers: arrays
+  // loader mapping: 16-byte chunk c -> row c>>3, k-offset (c&7)*8; rows lrow + RP*i (explicitly named registers: arrays
   // here get demoted to scratch / LDS by the compiler)
   const int lrow = tid >> 3, lkc = (tid & 7) * 8;
   auto arow = [&](int i) -> const f16* {
-    int lm = m0 + lrow + 32 * i; if (lm > p.M - 1) lm = p.M - 1;
+    int lm = m0 + lrow + RP * i; if (lm > p.M - 1) lm = p.M - 1;
     return p.A + (int64_t)(lm / p.a_rpb) * p.a_bs + (int64_t)(lm % p.a_rpb) * p.a_rs + lkc;
   };
   const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
   const f16* ga0 = arow(0) + kbeg; const f16* ga1 = arow(1) + kbeg;
   const f16* ga2 = arow(NA > 2 ? 2 : 0) + kbeg; const f16* ga3 = arow(NA > 2 ? 3 : 0) + kbeg;
   const f16* gw0 = p.W + (int64_t)(n0 + lrow) * p.K + lkc + kbeg;
-  const f16* gw1 = gw0 + (int64_t)32 * p.K; const f16* gw2 = gw0 + (int64_t)64 * p.K; const f16* gw3 = gw0 + (int64_t)96 * p.K;
+  const int64_t wrp = (int64_t)RP * p.K;
   const int soff = lrow * LSTR + lkc;
   uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
 #define WIS_GLOAD(kt)                                                                         \
   ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK); ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK);   \
   if (NA > 2) { ra2 = *reinterpret_cast<const uint4*>(ga2 + (kt) * BK); ra3 = *reinterpret_cast<const uint4*>(ga3 + (kt) * BK); } \
-  rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK); rw1 = *reinterpret_cast<const uint4*>(gw1 + (kt) * BK);   \
-  rw2 = *reinterpret_cast<const uint4*>(gw2 + (kt) * BK); rw3 = *reinterpret_cast<const uint4*>(gw3 + (kt) * BK);
+  rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK); rw1 = *reinterpret_cast<const uint4*>(gw0 + wrp + (kt) * BK);   \
+  if (NW > 2) { rw2 = *reinterpret_cast<const uint4*>(gw0 + 2 * wrp + (kt) * BK); rw3 = *reinterpret_cast<const uint4*>(gw0 + 3 * wrp + (kt) * BK); }
 #define WIS_SSTORE(buf)                                                                       \
-  *reinterpret_cast<uint4*>(&sA[buf][soff]) = ra0; *reinterpret_cast<uint4*>(&sA[buf][soff + 32 * LSTR]) = ra1;     \
-  if (NA > 2) { *reinterpret_cast<uint4*>(&sA[buf][soff + 64 * LSTR]) = ra2; *reinterpret_cast<uint4*>(&sA[buf][soff + 96 * LSTR]) = ra3; } \
-  *reinterpret_cast<uint4*>(&sW[buf][soff]) = rw0; *reinterpret_cast<uint4*>(&sW[buf][soff + 32 * LSTR]) = rw1;     \
-  *reinterpret_cast<uint4*>(&sW[buf][soff + 64 * LSTR]) = rw2; *reinterpret_cast<uint4*>(&sW[buf][soff + 96 * LSTR]) = rw3;
+  *reinterpret_cast<uint4*>(&sA[buf][soff]) = ra0; *reinterpret_cast<uint4*>(&sA[buf][soff + RP * LSTR]) = ra1;     \
+  if (NA > 2) { *reinterpret_cast<uint4*>(&sA[buf][soff + 2 * RP * LSTR]) = ra2; *reinterpret_cast<uint4*>(&sA[buf][soff + 3 * RP * LSTR]) = ra3; } \
+  *reinterpret_cast<uint4*>(&sW[buf][soff]) = rw0; *reinterpret_cast<uint4*>(&sW[buf][soff + RP * LSTR]) = rw1;     \
+  if (NW > 2) { *reinterpret_cast<uint4*>(&sW[buf][soff + 2 * RP * LSTR]) = rw2; *reinterpret_cast<uint4*>(&sW[buf][soff + 3 * RP * LSTR]) = rw3; }
 
-  f32x16 acc[2][MI];
+  f32x16 acc[NI][MI];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
     for (int b = 0; b < MI; ++b)
 #pragma unroll
@@ -144,15 +160,15 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
     if (kt + 1 < nk) { WIS_GLOAD(kt + 1) }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      f16x8 wf[2], af[MI];
+      f16x8 wf[NI], af[MI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        wf[i] = *reinterpret_cast<const f16x8*>(&sW[cur][(wn * 64 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
+      for (int i = 0; i < NI; ++i)
+        wf[i] = *reinterpret_cast<const f16x8*>(&sW[cur][(wn * TN + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const f16x8*>(&sA[cur][(wm * (BM_ / 2) + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
+        af[i] = *reinterpret_cast<const f16x8*>(&sA[cur][(wm * TM + i * 32 + l31) * LSTR + kk * 16 + hi * 8]);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
@@ -164,14 +180,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
 #undef WIS_SSTORE
   // D[i = n][j = m]: lane holds m = l31, n = (r&3) + 8*(r>>2) + 4*hi
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * (BM_ / 2) + mi * 32 + l31;
+      const int m = m0 + wm * TM + mi * 32 + l31;
       if (m < p.M) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const int n = n0 + wn * 64 + ni * 32 + 8 * r4 + 4 * hi;
+          const int n = n0 + wn * TN + ni * 32 + 8 * r4 + 4 * hi;
           f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
           epi(m, n, v);
         }
@@ -179,125 +195,24 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmP p, Epi epi) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// LDS-DMA variant (opt-in, WIS_GEMM_GLDS=1): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4, no VGPR round trip and no ds_write
-// (the register-staged kernel above is LDS-write bound: 32 KiB of ds_write_b128 per k-tile at ~79 B/clk vs 512 cycles of MFMA).
-// The DMA writes lane l at base + 16*l, i.e. one wave instruction fills 8 rows x 128 B of a LINEAR [rows][64] f16 image, so the
-// bank-conflict swizzle lives on the SOURCE address: LDS slot (row, c) holds global 16-byte chunk c ^ (row & 7) of that row, and
-// fragment reads apply the same XOR (guide rule 21 / T2).  Two LDS buffers; tile k+1 is in flight while tile k is multiplied.
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-__device__ __forceinline__ void glds16(const f16* src, f16* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)lds_wave_base, 16, 0, 0);   // generic -> global / LDS address spaces
+// Tile choice (WIS_GEMM_TILE=BMxBN overrides with one of the instantiated shapes, tuning only).
+static void gemm_pick_tile(const GemmP& p, int* bm, int* bn) {
+  static int ebm = -1, ebn = -1;
+  if (ebm < 0) { ebm = 0; ebn = 0; if (const char* e = getenv("WIS_GEMM_TILE")) sscanf(e, "%dx%d", &ebm, &ebn); }
+  if (ebm && ebn && p.N % ebn == 0) { *bm = ebm; *bn = ebn; return; }
+  if (p.N % 256 == 0 && (p.N / 256) * cdiv(p.M, 256) >= 200) { *bm = 256; *bn = 256; return; }     // batched encoder
+  const bool small = (p.N / 128) * cdiv(p.M, 128) < 200 && p.M > 64;
+  *bm = small ? 64 : 128; *bn = 128;
 }
-
-template <class Epi, int BM_>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p, Epi epi) {
-  constexpr int MI = BM_ / 64;                 // 32-row MFMA sub-tiles per wave along M
-  constexpr int AI = BM_ / 32;                 // DMA instructions per wave per k-tile for the A tile (8 rows each); W: 4
-  __shared__ __attribute__((aligned(1024))) f16 sA[2][BM_ * 64];
-  __shared__ __attribute__((aligned(1024))) f16 sW[2][BN * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN);
-  int wg;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN;
-  const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
-
-  // DMA source pointers: instruction i of this wave covers tile rows (BM_/4 or 32)*wave + 8*i + (lane>>3); the lane fetches
-  // global chunk (lane&7) ^ (row&7) so that the linear LDS image is XOR-swizzled
-  const int lr = lane >> 3, lc = lane & 7;
-  auto asrc = [&](int i) -> const f16* {
-    const int row = (BM_ / 4) * wave + 8 * i + lr;
-    int lm = m0 + row; if (lm > p.M - 1) lm = p.M - 1;
-    return p.A + (int64_t)(lm / p.a_rpb) * p.a_bs + (int64_t)(lm % p.a_rpb) * p.a_rs + ((lc ^ (row & 7)) * 8) + kbeg;
-  };
-  auto wsrc = [&](int i) -> const f16* {
-    const int row = 32 * wave + 8 * i + lr;
-    return p.W + (int64_t)(n0 + row) * p.K + ((lc ^ (row & 7)) * 8) + kbeg;
-  };
-  const f16* ga0 = asrc(0); const f16* ga1 = asrc(1);
-  const f16* ga2 = asrc(AI > 2 ? 2 : 0); const f16* ga3 = asrc(AI > 2 ? 3 : 0);
-  const f16* gw0 = wsrc(0); const f16* gw1 = wsrc(1); const f16* gw2 = wsrc(2); const f16* gw3 = wsrc(3);
-  const int la = (BM_ / 4) * wave * 64, lw = 32 * wave * 64;      // wave-uniform LDS element offsets of this wave's rows
-#define WIS_DMA(buf, kt)                                                                  \
-  glds16(ga0 + (kt) * BK, &sA[buf][la]); glds16(ga1 + (kt) * BK, &sA[buf][la + 8 * 64]);  \
-  if (AI > 2) { glds16(ga2 + (kt) * BK, &sA[buf][la + 16 * 64]); glds16(ga3 + (kt) * BK, &sA[buf][la + 24 * 64]); } \
-  glds16(gw0 + (kt) * BK, &sW[buf][lw]); glds16(gw1 + (kt) * BK, &sW[buf][lw + 8 * 64]); \
-  glds16(gw2 + (kt) * BK, &sW[buf][lw + 16 * 64]); glds16(gw3 + (kt) * BK, &sW[buf][lw + 24 * 64]);
-
-  f32x16 acc[2][MI];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // fragment read offsets (elements): row r, chunk c = 2*kk + hi  ->  r*64 + ((c ^ (r & 7)) * 8)
-  const int rw0 = wn * 64 + l31, rw1 = rw0 + 32, ra0 = wm * (BM_ / 2) + l31, ra1 = ra0 + 32;
-
-  const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
-  WIS_DMA(0, 0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) { WIS_DMA(cur ^ 1, kt + 1) }
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const int c = 2 * kk + hi;
-      const f16x8 wf0 = *reinterpret_cast<const f16x8*>(&sW[cur][rw0 * 64 + ((c ^ (rw0 & 7)) * 8)]);
-      const f16x8 wf1 = *reinterpret_cast<const f16x8*>(&sW[cur][rw1 * 64 + ((c ^ (rw1 & 7)) * 8)]);
-      const f16x8 af0 = *reinterpret_cast<const f16x8*>(&sA[cur][ra0 * 64 + ((c ^ (ra0 & 7)) * 8)]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, af0, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, af0, acc[1][0], 0, 0, 0);
-      if (MI > 1) {
-        const f16x8 af1 = *reinterpret_cast<const f16x8*>(&sA[cur][ra1 * 64 + ((c ^ (ra1 & 7)) * 8)]);
-        acc[0][MI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, af1, acc[0][MI - 1], 0, 0, 0);
-        acc[1][MI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, af1, acc[1][MI - 1], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile k+1 have landed
-    __syncthreads();                                     // ... and everyone's; nobody still reads buffer `cur`
-  }
-#undef WIS_DMA
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * (BM_ / 2) + mi * 32 + l31;
-      if (m < p.M) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int n = n0 + wn * 64 + ni * 32 + 8 * r4 + 4 * hi;
-          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
-          epi(m, n, v);
-        }
-      }
-    }
-}
-
-// measured on MI355X round 1 (large-v2 encoder, 2 workgroups/CU): register-staged 6.5 ms vs LDS-DMA 7.3 ms -> DMA variant is opt-in
-static bool use_glds() { static const bool v = getenv("WIS_GEMM_GLDS") != nullptr; return v; }
 
 template <class Epi>
 static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
-  if (p.N % BN || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
-  // fewer than ~1 workgroup per CU with 128-row tiles -> 64-row tiles
-  const bool small = (p.N / BN) * cdiv(p.M, 128) < 200 && p.M > 64;
-  const dim3 grid((p.N / BN) * cdiv(p.M, small ? 64 : 128));
-  if (use_glds()) {
-    if (small) hipLaunchKernelGGL((gemm_glds_kernel<Epi, 64>), grid, dim3(256), 0, st, p, epi);
-    else hipLaunchKernelGGL((gemm_glds_kernel<Epi, 128>), grid, dim3(256), 0, st, p, epi);
-  } else {
-    if (small) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64>), grid, dim3(256), 0, st, p, epi);
-    else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128>), grid, dim3(256), 0, st, p, epi);
-  }
+  if (p.N % 128 || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
+  int bm, bn; gemm_pick_tile(p, &bm, &bn);
+  const dim3 grid((p.N / bn) * cdiv(p.M, bm), 1, p.klen > 0 ? p.K / p.klen : 1);
+  if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
+  else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
+  else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   return WIS_OK;
 }
 
@@ -386,12 +301,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
 }
 int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float* scratch, const float* bias, const float* resid, float* X) {
   GemmP p = p0;
-  if (splits < 2 || p.K % (splits * BK) || p.N % BN) { set_error("splitk: K=%d splits=%d unsupported", p.K, splits); return WIS_E_UNSUPPORTED; }
+  if (splits < 2 || p.K % (splits * BK) || p.N % 128) { set_error("splitk: K=%d splits=%d unsupported", p.K, splits); return WIS_E_UNSUPPORTED; }
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
-  if (use_glds()) hipLaunchKernelGGL((gemm_glds_kernel<EpiPartial, 128>), dim3((p.N / BN) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
-  else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128>), dim3((p.N / BN) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
+  hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
   const int64_t n4 = zs / 4;
   int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, scratch, splits, zs, bias, resid, X, n4, p.N);
