@@ -401,29 +401,41 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
         st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[t2], 0, 0, 0);
       }
     }
-    const int key_base = kt * AKT + 4 * hi;
+    // softmax bookkeeping in the log2 domain (one fma + one v_exp per score); only the last key tile can hold keys >= T;
+    // the accumulator rescale is skipped while no lane of the wave saw a new maximum (the common case after a few tiles)
+    constexpr float LOG2E = 1.4426950408889634f;
     float mx = -INFINITY;
+    if (kt == ntiles - 1) {
+      const int key_base = kt * AKT + 4 * hi;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + t2 * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= T) st[t2][r] = -INFINITY;
+        }
+    }
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key_base + t2 * 32 + (r & 3) + 8 * (r >> 2);
-        if (key >= T) st[t2][r] = -INFINITY;
-        mx = fmaxf(mx, st[t2][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * LOG2E;             // m_run is kept pre-multiplied by log2(e)
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const bool grew = m_new > m_run;
     float rs = 0.f;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float pv = __expf(st[t2][r] - m_new); st[t2][r] = pv; rs += pv; }
-    l_run = l_run * alpha + rs; m_run = m_new;
+      for (int r = 0; r < 16; ++r) { const float pv = exp2f(fmaf(st[t2][r], LOG2E, -m_new)); st[t2][r] = pv; rs += pv; }
+    if (__any(grew)) {
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
+    }
+    l_run += rs; m_run = m_new;
     // P fragments straight from the accumulators: k-step s of 16 keys <-> S-tile s>>1, regs 8(s&1)..+7;
     // slot j of half `hi` is key 16s + 8(j>>2) + 4hi + (j&3)  (same permutation used for V^T below)
     f16x8 pf[4];
