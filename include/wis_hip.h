@@ -157,6 +157,9 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
  * constant-clock time of its first workgroup start and last workgroup end -> out[k][2].  use_graph = 1 replays the
  * forward as a HIP graph (what wis_generate does), 0 launches it eagerly. */
 int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, uint64_t* out, int n_out);
+/* ---- tuning tap (tap builds): shader-clock phase stamps of the last beam_step_kernel launch of utterance 0 -> out[2][16]
+ * (row 0 reserved for the logit statistics kernel, row 1 = beam step) */
+int wis_debug_sampling_cycles(wis_model_t* m, uint64_t* out);
 
 /* ---- roofline tap (bench.py): launch the decoder's weight-streaming skinny-GEMM kernel once over
  * EVERY decoder weight matrix of the model (6 per layer + the vocabulary projection = the weight

@@ -818,9 +818,8 @@ int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_al
 // grid B, block 64 (one wave per utterance).
 __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__ st_max, const float* __restrict__ st_sum,
                                                        const float* __restrict__ st_val, const int* __restrict__ st_idx,
-                                                       BeamState bs, RowMeta rm, int P, int ctx, SampleCfg cfg) {
-  constexpr int POOL_MAX = MAX_R * STAT_CHUNKS * MAX_CAND;   // 2048
-  __shared__ float pool_v[POOL_MAX]; __shared__ int pool_id[POOL_MAX];
+                                                       BeamState bs, RowMeta rm, int P, int ctx, SampleCfg cfg, unsigned long long* prof) {
+  constexpr int PSL = (STAT_CHUNKS * MAX_CAND + 63) / 64;    // pool slots per lane and row (4)
   __shared__ float lse[MAX_R];
   __shared__ float cand_v[MAX_CAND]; __shared__ int cand_word[MAX_CAND]; __shared__ int cand_org[MAX_CAND];
   __shared__ int nb_src[MAX_R]; __shared__ int nb_tok[MAX_R]; __shared__ float nb_cum[MAX_R];
@@ -829,49 +828,93 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   __shared__ int sh_anc[MAX_R * 512];
   __shared__ int sh_alive[MAX_R * 256];
   const int b = blockIdx.x, lane = threadIdx.x;
-  if (bs.done[b]) return;
+  unsigned long long* pf = (b == 0 && lane == 0) ? prof : nullptr;
+  stamp(pf, 0);
   const int k = cfg.beam, NC = cfg.n_cand, V = cfg.n_vocab;
+  const int r0 = b * k, per_row = STAT_CHUNKS * NC;
+  // The candidate pool (k rows x STAT_CHUNKS x n_cand entries) lives in REGISTERS, slot [j][u] = entry lane + 64u of row j: all
+  // of it, the row statistics and the cumulative scores are requested in one round trip before anything is waited for (the
+  // LDS-resident pool cost 9 us to build - 13 serialised round trips - and 17 us to scan ten times).
+  float pv_[MAX_R][PSL]; int pi_[MAX_R][PSL]; float cum_[MAX_R];
+#pragma unroll
+  for (int j = 0; j < MAX_R; ++j) {
+    cum_[j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < PSL; ++u) { pv_[j][u] = -INFINITY; pi_[j][u] = 0x7fffffff; }
+    if (j < k) {
+      cum_[j] = bs.cum[r0 + j];
+#pragma unroll
+      for (int u = 0; u < PSL; ++u) {
+        const int e = lane + 64 * u;
+        if (e < per_row) { pv_[j][u] = st_val[(size_t)(r0 + j) * per_row + e]; pi_[j][u] = st_idx[(size_t)(r0 + j) * per_row + e]; }
+      }
+    }
+  }
+  float smx[STAT_CHUNKS], ssm[STAT_CHUNKS];
+  {
+    const int m = r0 + (lane < k ? lane : 0);
+#pragma unroll
+    for (int c = 0; c < STAT_CHUNKS; ++c) { smx[c] = st_max[m * STAT_CHUNKS + c]; ssm[c] = st_sum[m * STAT_CHUNKS + c]; }
+  }
+  const int done_b = bs.done[b];
   const int step = bs.step_u[b];
-  const int r0 = b * k;
+  if (done_b) return;
 
+  stamp(pf, 1);
   // log-softmax normaliser per live row
   if (lane < k) {
-    const int m = r0 + lane;
     float M_ = -INFINITY;
-    for (int c = 0; c < STAT_CHUNKS; ++c) M_ = fmaxf(M_, st_max[m * STAT_CHUNKS + c]);
+#pragma unroll
+    for (int c = 0; c < STAT_CHUNKS; ++c) M_ = fmaxf(M_, smx[c]);
     float S = 0.f;
-    for (int c = 0; c < STAT_CHUNKS; ++c) {
-      const float mc = st_max[m * STAT_CHUNKS + c];
-      if (mc > -INFINITY) S += st_sum[m * STAT_CHUNKS + c] * __expf(mc - M_);
-    }
+#pragma unroll
+    for (int c = 0; c < STAT_CHUNKS; ++c) if (smx[c] > -INFINITY) S += ssm[c] * __expf(smx[c] - M_);
     lse[lane] = M_ + logf(S);
   }
   __syncthreads();
-  // candidate pool: score = logit - lse + cum ; flat id = beam * V + token
-  const int pool_n = k * STAT_CHUNKS * NC;
-  for (int i = lane; i < pool_n; i += 64) {
-    const int j = i / (STAT_CHUNKS * NC), m = r0 + j;
-    const size_t src = (size_t)m * STAT_CHUNKS * NC + (i - j * STAT_CHUNKS * NC);
-    const float v = st_val[src];
-    pool_v[i] = (v > -INFINITY) ? (v - lse[j]) + bs.cum[m] : -INFINITY;
-    int tk = st_idx[src]; if (tk > V - 1) tk = V - 1;   // exhausted chunks report INT_MAX with -inf
-    pool_id[i] = j * V + tk;
-  }
-  __syncthreads();
-  // top-NC of the pool, (score desc, flat id asc)
-  float pv = INFINITY; int pi = -1;
-  for (int rnd = 0; rnd < NC; ++rnd) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int i = lane; i < pool_n; i += 64) {
-      const float v = pool_v[i]; const int id = pool_id[i];
-      if (better(pv, pi, v, id) && better(v, id, bv, bi)) { bv = v; bi = id; }
+  stamp(pf, 2);
+  // score = logit - lse + cum ; flat id = beam * V + token; lane-local best in (score desc, flat id asc) order
+  float lbv = -INFINITY; int lbi = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < MAX_R; ++j) {
+    if (j < k) {
+#pragma unroll
+      for (int u = 0; u < PSL; ++u) {
+        if (lane + 64 * u < per_row) {
+          const float v = pv_[j][u];
+          pv_[j][u] = (v > -INFINITY) ? (v - lse[j]) + cum_[j] : -INFINITY;
+          int tk = pi_[j][u]; if (tk > V - 1) tk = V - 1;   // exhausted chunks report INT_MAX with -inf
+          pi_[j][u] = (j << 20) | tk;                       // orders like the flat id j * V + tk (V < 2^20), no division to unpack
+          if (better(pv_[j][u], pi_[j][u], lbv, lbi)) { lbv = pv_[j][u]; lbi = pi_[j][u]; }
+        }
+      }
     }
+  }
+  stamp(pf, 3);
+  // top-NC of the pool: NC rounds of a wave arg-best over the lane-local bests; every lane then retires its copies of the
+  // winner (identical (score, id) pairs - the clamped -inf entries of exhausted chunks - are picked once, as before) and
+  // refreshes its local best
+  for (int rnd = 0; rnd < NC; ++rnd) {
+    float bv = lbv; int bi = lbi;
     wave_argbest(bv, bi);
-    if (lane == 0) { cand_v[rnd] = bv; cand_word[rnd] = bi % V; cand_org[rnd] = bi / V; }
-    pv = bv; pi = bi;
+    if (lane == 0) { cand_v[rnd] = bv; cand_word[rnd] = bi & 0xFFFFF; cand_org[rnd] = (bi >> 20) & 0x7FF; }
+    lbv = -INFINITY; lbi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < MAX_R; ++j) {
+      if (j < k) {
+#pragma unroll
+        for (int u = 0; u < PSL; ++u) {
+          if (64 * u < per_row) {
+            if (pi_[j][u] == bi && pv_[j][u] == bv) { pv_[j][u] = -INFINITY; pi_[j][u] = 0x7fffffff; }
+            if (better(pv_[j][u], pi_[j][u], lbv, lbi)) { lbv = pv_[j][u]; lbi = pi_[j][u]; }
+          }
+        }
+      }
+    }
   }
   __syncthreads();
 
+  stamp(pf, 4);
   // serial bookkeeping
   if (lane == 0) {
     const bool is_last = (step + 1 >= cfg.max_new);
@@ -900,12 +943,14 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   }
   __syncthreads();
 
+  stamp(pf, 5);
   // stage this utterance's token histories and ancestry rows, then write the permuted rows back
   const int hist = step;                 // tokens already in alive[]
   const int npos = P - 1 + step + 1;     // cache positions valid after this step
   for (int i = lane; i < k * hist; i += 64) { const int j = i / hist, t = i - j * hist; sh_alive[j * 256 + t] = bs.alive[(size_t)(r0 + j) * cfg.max_new + t]; }
   for (int i = lane; i < k * npos; i += 64) { const int j = i / npos, p = i - j * npos; sh_anc[j * 512 + p] = bs.anc[(size_t)(r0 + j) * ctx + p]; }
   __syncthreads();
+  stamp(pf, 6);
   // finished hypotheses of this step
   for (int hh = 0; hh < n_newhyp; ++hh) {
     const int kk = hyp_src[hh], org = cand_org[kk], n = hyp_n[hh];
@@ -937,6 +982,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
     for (int t = lane; t < n; t += 64) bs.out_ids[(size_t)b * cfg.max_new + t] = src[t];
     return;
   }
+  stamp(pf, 7);
   // next live beams
   for (int j = 0; j < k; ++j) {
     const int org = cand_org[nb_src[j]];
@@ -954,11 +1000,12 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
     }
   }
   if (lane == 0) bs.step_u[b] = step + 1;
+  stamp(pf, 8);
 }
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
-                     const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg) {
-  if (cfg.beam > MAX_R || cfg.n_cand > MAX_CAND || cfg.max_new > 256 || ctx > 512) { set_error("beam_step: config out of range"); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg);
+                     const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof) {
+  if (cfg.beam > MAX_R || cfg.n_cand > MAX_CAND || cfg.max_new > 256 || ctx > 512 || cfg.n_vocab > (1 << 20)) { set_error("beam_step: config out of range"); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
   return WIS_OK;
 }
 

@@ -90,7 +90,7 @@ struct BeamState {
   int* out_ids; int* out_len; float* out_score;   // final result [B][max_new], [B], [B]
 };
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
-                     const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg);
+                     const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof = nullptr);
 // language detection: softmax over lang_ids of the row's logits
 int launch_lang_probs(hipStream_t st, const float* logits, int ld, const int* lang_ids, int n_lang, float* probs, int B);
 

@@ -344,7 +344,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->d_in, (size_t)Bm * WIS_N_SAMPLES));
   WIS_RET(dalloc(m, &m->d_nsamp, Bm));
   WIS_RET(dalloc(m, &m->d_probs, (size_t)Bm * (c.n_lang > 0 ? c.n_lang : 1)));
-  WIS_RET(dalloc(m, &m->d_prof, (size_t)c.n_dec_layers * 8 * 16));
+  WIS_RET(dalloc(m, &m->d_prof, ((size_t)c.n_dec_layers * 8 + 2) * 16));   // + sampling kernels (tap builds)
   WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 65536, hipHostMallocDefault));
   for (int i = 0; i < 8; ++i) WIS_HIP_CHECK(hipEventCreate(&m->ev[i]));
   return WIS_OK;
@@ -631,14 +631,14 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     WIS_RET(upload_rows(m, tok, pos, slot, ls));
     WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1));
-    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc));
+    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
 
   auto one_step = [&]() -> int {
     WIS_RET(dec_forward(m, Mrows, beam, B, true, beam, 1));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, beam, 1, 0));
-    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc));
+    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
     return WIS_OK;
   };
   hipGraphExec_t gexec = nullptr;
@@ -801,6 +801,14 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
   for (int i = 0; i < 6; ++i)
     WIS_HIP_CHECK(hipMemcpyAsync(out + i * 16, m->d_prof + rows[i] * 16, 16 * 8, hipMemcpyDeviceToHost, m->st));
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  return WIS_OK;
+}
+
+int wis_debug_sampling_cycles(wis_model_t* m, uint64_t* out) {
+  if (!m || !out) { set_error("wis_debug_sampling_cycles: bad argument"); return WIS_E_ARG; }
+  if (!WIS_TAPS) { set_error("tuning taps are not compiled in (rebuild with WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1)"); return WIS_E_UNSUPPORTED; }
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_HIP_CHECK(hipMemcpy(out, m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16, 2 * 16 * 8, hipMemcpyDeviceToHost));
   return WIS_OK;
 }
 

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("wis_last_timing", _i, [_vp, C.POINTER(Timing)]),
     ("wis_debug_phase_cycles", _i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
     ("wis_debug_timeline", _i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_uint64), _i]),
+    ("wis_debug_sampling_cycles", _i, [_vp, C.POINTER(C.c_uint64)]),
     ("wis_bench_weight_stream", _i, [_vp, _i, _i, _fp, C.POINTER(_i), C.POINTER(C.c_double)]),
     ("wis_dev_alloc", _i, [_i, _sz, C.POINTER(_vp)]),
     ("wis_dev_free", _i, [_i, _vp]),
