@@ -109,3 +109,38 @@ def test_asr_and_willow_endpoints(served, golden_dir):
             assert sum(t != direct[1] for t in texts) <= 2       # near-tie flips only (batch composition changes rounding)
 
     asyncio.run(go())
+
+
+def test_streaming_session_equals_offline(golden_dir):
+    """BASELINE configs[4] shape: audio arrives in 0.5 s frames; > 30 s recordings are transcribed window by window while
+    the audio is still arriving, and stop() returns exactly the offline do_whisper result."""
+    from wis_hip import audio
+    from wis_hip.settings import APISettings
+    from wis_hip.streaming import StreamingSession
+    from wis_hip.whisper import WhisperModels, do_whisper
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.concurrent_gpu_chunks = 1           # offline batches of one window, like the streaming schedule: bit-identical arithmetic
+    models = WhisperModels(s, device_index=[0])
+    # (1) the 29.2 s reference clip: one window, the whole pipeline runs at stop()
+    pcm, _ = audio.load_audio(os.path.join(golden_dir, "clips", "30sec.flac"))
+    off = do_whisper(pcm, "tiny", 5, models=models, fixed_new_tokens=12)
+    sess = StreamingSession("tiny", 5, models=models, fixed_new_tokens=12)
+    for i in range(0, pcm.shape[0], 8000):
+        sess.feed((pcm[i:i + 8000] * 32768.0).astype("<i2").tobytes(), 2)       # int16 frames, as a WebRTC track delivers them
+    mid = sess.interim()
+    assert mid[5] == off[5] == 29248 and mid.tokens == off.tokens
+    fin = sess.stop()
+    assert fin.tokens == off.tokens and fin[1] == off[1] and sess.eager_windows == 0
+    # (2) 64 s of seeded noise: 5 windows, the first three complete (and get transcribed) before the recording ends
+    rng = np.random.default_rng(11)
+    long_pcm = (0.05 * rng.standard_normal(64 * 16000)).astype(np.float32)
+    off = do_whisper(long_pcm, "tiny", 5, models=models, fixed_new_tokens=6)
+    sess = StreamingSession("tiny", 5, models=models, fixed_new_tokens=6)
+    for i in range(0, long_pcm.shape[0], 8000):
+        sess.feed(long_pcm[i:i + 8000])
+    assert sess.eager_windows == 4        # starts 0, 14, 28, 42 s have their 22 s; the tail window (56 s) does not
+    fin = sess.stop()
+    assert fin.tokens == off.tokens and fin[5] == off[5] == 64000
+    with pytest.raises(RuntimeError):
+        sess.feed(long_pcm[:10])

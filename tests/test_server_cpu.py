@@ -160,3 +160,38 @@ def test_endpoints_reference_error_behaviour():
             assert r.status_code == 400
 
     asyncio.run(go())
+
+
+def test_datachannel_protocol_state_machine():
+    """reference main.py:906-996: ping/start/stop -> pong/log/infer/error, per-message model / beam overrides."""
+    import json
+    from wis_hip.streaming import DataChannelProtocol
+    made = []
+
+    class FakeSession:
+        def __init__(self, model, beam_size, task, detect_language, force_language, models=None):
+            self.args, self.fed = (model, beam_size, task, detect_language), 0
+            made.append(self)
+
+        def feed(self, frame, width):
+            self.fed += len(frame) // width
+
+        def stop(self):
+            return ("en", f"heard {self.fed} samples", 12.5, None, 80, int(self.fed / 16))
+
+    p = DataChannelProtocol(models=_FakeModels(), model="medium", beam_size=1, session_factory=FakeSession)
+    dec = lambda xs: [json.loads(x) for x in xs]
+    assert dec(p.on_message("not json")) == [{"type": "error", "message": "could not parse message", "obj": None}]
+    assert dec(p.on_message(json.dumps({"type": "ping", "message": "hi"}))) == [{"type": "pong", "message": "hi", "obj": None}]
+    assert dec(p.on_message(json.dumps({"type": "stop"})))[0]["message"] == "Recording not yet started"
+    p.on_audio(b"\0\0" * 100)                                   # before "start": dropped
+    assert dec(p.on_message(json.dumps({"type": "start"})))[0]["type"] == "log"
+    for _ in range(10):
+        p.on_audio(b"\1\0" * 1600)
+    out = dec(p.on_message(json.dumps({"type": "stop", "obj": {"model": "large", "beam_size": 5}})))
+    assert made[-1].args == ("large", 5, "transcribe", False) and made[-1].fed == 16000
+    assert [m["type"] for m in out] == ["log", "infer", "log", "log", "log"]
+    assert out[1]["obj"] == {"text": "heard 16000 samples"} and "beam size 5" in out[0]["message"]
+    assert out[3]["message"] == "ASR Audio Duration: 1000 ms" and out[4]["message"] == "ASR Speedup: 80x faster than realtime"
+    assert dec(p.on_message(json.dumps({"type": "nope"})))[0]["message"] == 'unknown message type "nope"'
+    assert dec(p.on_message(json.dumps({"type": "stop"})))[0]["type"] == "error"      # recorder was consumed

@@ -1,0 +1,213 @@
+"""Long-form / streaming ASR over the HIP path (BASELINE.json configs[4]).
+
+The reference has no streaming inference: its WebRTC handler records the whole track and then makes one ordinary
+`do_whisper` call (main.py:963-971).  Whisper's encoder is non-causal over its 30 s window, so what CAN be
+done incrementally without changing results is the reference's own long-audio schedule (wis/audio.py:106-134): 22 s
+windows with 4 s of context either side, stepping 14 s.  A `StreamingSession` accepts PCM as it arrives and, as soon as
+the audio is known to need chunking (> 30 s buffered), transcribes every window whose 22 s are complete on a worker thread
+(through the model's micro-batcher, so several sessions share device batches); `stop()` then only has the tail window left
+and returns exactly what `do_whisper` returns for the complete recording.  `interim()` gives the hypothesis for what has
+been heard so far (an extra decode; the final result never depends on it).
+
+`DataChannelProtocol` is the reference's data-channel message protocol (`ping` / `start` / `stop` -> `pong` / `log` /
+`infer` / `error`, main.py:906-996) driven by such a session instead of `MediaRecorderLite` + `do_whisper`; the WebRTC
+transport itself (aiortc) is not available here and stays out of scope.
+"""
+import json
+import math
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import audio, ctranslate2, weights as W
+from .whisper import InvalidAudio, WhisperResult, _Tokenizer, check_language, default_models
+
+_STEP = audio.chunk_len - audio.stride_left - audio.stride_right     # 14 s between window starts
+
+
+class StreamingSession:
+    def __init__(self, model, beam_size=None, task="transcribe", detect_language=False, force_language=None, models=None,
+                 fixed_new_tokens=0):
+        self.models = models or default_models()
+        s = self.models.settings
+        self.model_name, self.task = model, task
+        self.beam_size = s.beam_size if beam_size is None else beam_size
+        self.detect_language, self.force_language = detect_language, force_language
+        self.fixed_new_tokens = fixed_new_tokens
+        if force_language and not check_language(force_language):
+            raise ValueError(f"unsupported language {force_language!r}")
+        self._whisper = self.models.get(model)
+        self._pcm = np.zeros(0, np.float32)
+        self._lock = threading.Lock()
+        self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="wis-stream")
+        self._windows = {}            # (start, length) -> Future[list[int]]   window token ids, computed eagerly
+        self._language = None
+        self._closed = False
+        self.eager_windows = 0        # windows transcribed before stop() (stats / tests)
+
+    # ---- audio in ----------------------------------------------------------------------------------------------------
+    def feed(self, samples, sample_width=None):
+        """float32 PCM in [-1, 1) at 16 kHz, or raw little-endian int16 bytes (`sample_width=2`, a Willow / WebRTC frame)."""
+        if self._closed:
+            raise RuntimeError("session is closed")
+        if isinstance(samples, (bytes, bytearray, memoryview)):
+            if sample_width not in (None, 2):
+                raise InvalidAudio("only 16-bit PCM frames are supported")
+            samples = np.frombuffer(bytes(samples), "<i2").astype(np.float32) / 32768.0
+        x = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        with self._lock:
+            self._pcm = np.concatenate([self._pcm, x])
+            self._schedule_complete_windows()
+
+    @property
+    def buffered_ms(self):
+        return int(self._pcm.shape[0] / audio.SAMPLE_RATE * 1000)
+
+    # ---- scheduling --------------------------------------------------------------------------------------------------
+    def _prompt(self, language):
+        task_id = W.TRANSLATE if self.task == "translate" else W.TRANSCRIBE
+        return [W.SOT, _Tokenizer.language_token_id(language), task_id, W.NO_TIMESTAMPS]
+
+    def _resolve_language(self, first_window):
+        if self._language is None:
+            s = self.models.settings
+            language = s.language
+            if self.detect_language and not self.force_language:
+                mel = audio.log_mel_spectrogram(audio.pad_or_trim(first_window)).numpy()[None]
+                res = self._whisper.detect_language(ctranslate2.StorageView.from_array(np.ascontiguousarray(mel)))
+                language = res[0][0][0].strip("<|>")
+            elif self.force_language:
+                language = self.force_language
+            if not check_language(language):
+                raise ValueError(f"unsupported language {language!r}")
+            self._language = language
+        return self._language
+
+    def _window_tokens(self, piece, beam):
+        language = self._resolve_language(piece)
+        mel = audio.log_mel_spectrogram(audio.pad_or_trim(piece)).numpy()[None]
+        r = self._whisper.generate(ctranslate2.StorageView.from_array(np.ascontiguousarray(mel)), [self._prompt(language)], beam_size=beam,
+                                   return_scores=False, fixed_new_tokens=self.fixed_new_tokens)
+        return r[0].sequences_ids[0]
+
+    def _schedule_complete_windows(self):
+        """Called with the lock held.  Once more than 30 s are buffered the final call WILL chunk (main.py:588), with the
+        long-audio beam (>= 12 s, main.py:582-586); every window that already has its full 22 s has its final content."""
+        s = self.models.settings
+        n = self._pcm.shape[0]
+        if not s.support_chunking or n <= 30 * audio.SAMPLE_RATE:
+            return
+        start = 0
+        while start + audio.chunk_len <= n:
+            key = (start, audio.chunk_len)
+            if key not in self._windows:
+                piece = self._pcm[start:start + audio.chunk_len].copy()
+                self._windows[key] = self._pool.submit(self._window_tokens, piece, s.long_beam_size)
+                self.eager_windows += 1
+            start += _STEP
+
+    # ---- results -----------------------------------------------------------------------------------------------------
+    def _transcribe(self, final):
+        t0 = time.perf_counter()
+        with self._lock:
+            pcm = self._pcm.copy()
+        if pcm.shape[0] == 0:
+            raise InvalidAudio("empty audio")
+        s = self.models.settings
+        duration_ms = int(pcm.shape[0] / audio.SAMPLE_RATE * 1000)
+        beam = s.long_beam_size if duration_ms >= s.long_beam_size_threshold else self.beam_size
+        if duration_ms > 30 * 1000 and s.support_chunking:
+            seqs = []
+            for piece, stride in audio.chunk_iter(pcm):
+                start = len(seqs) * _STEP
+                fut = self._windows.get((start, piece.shape[0]))
+                ids = fut.result() if fut is not None else self._window_tokens(piece, beam)
+                seqs.append((ids, stride))
+            tokens = [int(t) for t in audio.find_longest_common_sequence(seqs, self.models.tokenizer)]
+        else:
+            tokens = self._window_tokens(pcm, beam)
+        text = self.models.tokenizer.decode(tokens).strip()
+        ms = (time.perf_counter() - t0) * 1000
+        out = WhisperResult((self._language, text, ms, None, math.floor(duration_ms / ms) if ms > 0 else 0, duration_ms))
+        out.tokens = tokens
+        return out
+
+    def interim(self):
+        """Hypothesis for the audio received so far (does not end the session)."""
+        return self._transcribe(final=False)
+
+    def stop(self):
+        """End of the recording: the same 6-tuple `do_whisper` returns for the complete audio (infer_time counts only the work
+        left at stop time - the windows transcribed while the audio was arriving are already done)."""
+        try:
+            return self._transcribe(final=True)
+        finally:
+            self.close()
+
+    def close(self):
+        self._closed = True
+        self._pool.shutdown(wait=False, cancel_futures=True)
+
+
+class DataChannelProtocol:
+    """The reference's WebRTC data-channel protocol (main.py:906-996) as a transport-free state machine: feed it the JSON text
+    messages and the decoded audio frames, send back the JSON strings it returns."""
+
+    def __init__(self, models=None, model=None, beam_size=None, task="transcribe", detect_language=None, session_factory=StreamingSession):
+        self.models = models or default_models()
+        s = self.models.settings
+        self.model = model or s.whisper_model_default
+        self.beam_size = s.beam_size if beam_size is None else beam_size
+        self.detect_language = s.detect_language if detect_language is None else detect_language
+        self.task = task
+        self._factory = session_factory
+        self._frames = None           # list of PCM frames while recording
+
+    @staticmethod
+    def _msg(type_, message=None, obj=None):
+        return json.dumps({"type": type_, "message": message, "obj": obj})
+
+    def on_audio(self, frame, sample_width=2):
+        if self._frames is not None:
+            self._frames.append((frame, sample_width))
+
+    def on_message(self, message):
+        if not isinstance(message, str):
+            return []
+        try:
+            m = json.loads(message)
+            mtype, mmsg, mobj = m["type"], m.get("message"), m.get("obj")
+        except Exception:
+            return [self._msg("error", "could not parse message")]
+        if mtype == "ping":
+            return [self._msg("pong", mmsg)]
+        if mtype == "start":
+            self._frames = []
+            return [self._msg("log", "ASR Recording - start talking and press stop when done")]
+        if mtype == "stop":
+            if self._frames is None:
+                return [self._msg("error", "Recording not yet started")]
+            obj = mobj or {}
+            model = obj.get("model") or self.model
+            beam_size = obj.get("beam_size") or self.beam_size
+            detect_language = obj.get("detect_language") or self.detect_language
+            out = [self._msg("log", f"Doing ASR with model {model} beam size {beam_size} detect language {detect_language} - please wait")]
+            frames, self._frames = self._frames, None
+            # model / beam are only known at "stop" (per-message overrides, main.py:940-943), so the session starts here and
+            # the recorded frames are replayed into it
+            try:
+                sess = self._factory(model, beam_size, self.task, detect_language, None, models=self.models)
+                for frame, width in frames:
+                    sess.feed(frame, width)
+                language, text, infer_time, translation, infer_speedup, audio_duration = sess.stop()
+            except (InvalidAudio, ValueError) as e:
+                return out + [self._msg("error", str(e))]
+            out.append(self._msg("infer", obj=dict(text=text)))
+            if translation:
+                out.append(self._msg("log", f"ASR Translation from {language}:  {translation}"))
+            out += [self._msg("log", f"ASR Infer time: {infer_time} ms"), self._msg("log", f"ASR Audio Duration: {audio_duration} ms"),
+                    self._msg("log", f"ASR Speedup: {infer_speedup}x faster than realtime")]
+            return out
+        return [self._msg("error", f'unknown message type "{mtype}"')]
