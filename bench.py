@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--clip", default="3sec")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--compute-type", default="float16", choices=["float16", "int8_float16"],
+                    help="decoder weight storage; the headline number is float16 (int8_float16 mirrors the reference's GPU default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -137,7 +139,8 @@ def main():
     if not use_dist:
         weights = W.synthetic_weights(args.model, seed=1234)
         arena, index = W.build_arena(weights)
-        handle = ct2.create_handle(a, arena, index, dev, max_batch=max(args.batch, 1), max_beam=max(args.beam, 1))
+        handle = ct2.create_handle(a, arena, index, dev, max_batch=max(args.batch, 1), max_beam=max(args.beam, 1),
+                                   weight_bits=8 if args.compute_type == "int8_float16" else 16)
         del arena
     else:
         # one-time RCCL broadcast of the weight arena from rank 0 over xGMI; no collective at request time
@@ -152,6 +155,7 @@ def main():
         dist.broadcast(buf, src=0)
         torch.cuda.synchronize()
         handle = ct2.create_handle(a, None, index, dev, max_batch=max(args.batch, 1), max_beam=max(args.beam, 1),
+                                   weight_bits=8 if args.compute_type == "int8_float16" else 16,
                                    arena_device_ptr=(buf.data_ptr(), total))
         del buf
         torch.cuda.empty_cache()
@@ -236,7 +240,7 @@ def main():
                       else f"realtime_multiple (audio_ms / infer_ms), Whisper {args.model} beam={args.beam}, {args.clip} clip",
             "value": round(total_audio_s / elapsed, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "p50_ms": round(float(np.median(lat)), 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic weights (seeded, true large-v2 shapes); audio = reference clip client/3sec.flac; "
+            "vs_baseline": None, "dtype": "f16" if args.compute_type == "float16" else "f16 (int8 decoder weights, f16 activations)", "data": "synthetic weights (seeded, true large-v2 shapes); audio = reference clip client/3sec.flac; "
                                                           f"fixed decode length S={fixed_new} (SURVEY 8d convention)",
             "config": {"workload": f"whisper-{args.model} beam={args.beam} clip={args.clip} ({audio_ms:.0f} ms) batch={B}/GPU, PCM resident in HBM -> ids on host",
                        "utterances_per_step_per_gpu": B, "parallelism": f"{world} independent replicas (utterance sharding, no data-path collective)"},

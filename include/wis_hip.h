@@ -79,6 +79,9 @@ typedef struct {
   const int32_t* suppress_ids;       int32_t n_suppress;        /* CT2 config.json:suppress_ids */
   const int32_t* suppress_ids_begin; int32_t n_suppress_begin;  /* [220, 50257] */
   const int32_t* lang_ids;           int32_t n_lang;            /* 50259..50357 */
+  int32_t decoder_weight_bits;  /* 0 / 16: f16 decoder weights (compute type "float16"); 8: per-row int8 weights with f16
+                                 * activations ("int8_float16", the reference's GPU default main.py:242) - halves the decode
+                                 * weight stream; encoder, embedding lookup and the cross K/V projection stay f16 */
 } wis_config_t;
 
 #define WIS_DT_F32 0
@@ -191,7 +194,7 @@ int wis_op_enc_attention(int device, const void* qk_f16, const void* vt_f16, voi
 /* skinny GEMM used by the decoder: y[M][N] = epi(LN?(x)[M][K] . W[N][K]^T + bias); W is the
  * plain row-major f16 matrix (packed internally for the call).
  * flags: 1 = GELU, 2 = residual add in place into y f32, 4 = y f32 (else f16), 8 = fuse LayerNorm
- * (x is f32 [M][K], gamma/beta given); without 8, x is f16 [M][K]. */
+ * (x is f32 [M][K], gamma/beta given); without 8, x is f16 [M][K]; 32 = quantise W to per-row int8 first (int8_float16). */
 int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta,
                 const void* W_f16, const float* bias, void* y, int M, int N, int K, int flags);
 

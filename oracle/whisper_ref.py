@@ -45,6 +45,11 @@ class WhisperRef:
         self.enc_pos = torch.from_numpy(np.asarray(enc_pos, np.float32))
 
     # ---- building blocks ---------------------------------------------------------------
+    def _proj(self):
+        """Output projection: tied to the embeddings unless the weight set carries its own matrix (int8_float16 parity: the
+        projection is quantised, the embedding lookup is not; wis_hip.weights.quantize_decoder_weights)."""
+        return self.w["decoder/projection/weight"] if "decoder/projection/weight" in self.w else self.w["decoder/embeddings/weight"]
+
     def _ln(self, x, p):
         return F.layer_norm(x, (self.d,), self.w[p + "/gamma"], self.w[p + "/beta"], 1e-5)
 
@@ -99,7 +104,7 @@ class WhisperRef:
             h = self._ln(x, p + "ffn/layer_norm")
             x = x + self._lin(F.gelu(self._lin(h, p + "ffn/linear_0")), p + "ffn/linear_1")
         x = self._ln(x, "decoder/layer_norm")
-        return x @ self.w["decoder/embeddings/weight"].t()
+        return x @ self._proj().t()
 
     # ---- decoder: incremental form (self-attention KV cache, cross K/V projected once and shared by the beams) ----
     @torch.no_grad()
@@ -136,7 +141,7 @@ class WhisperRef:
             h = self._ln(x, p + "ffn/layer_norm")
             x = x + self._lin(F.gelu(self._lin(h, p + "ffn/linear_0")), p + "ffn/linear_1")
         x = self._ln(x[:, -1], "decoder/layer_norm")
-        return x @ self.w["decoder/embeddings/weight"].t()
+        return x @ self._proj().t()
 
     # ---- logits processors -----------------------------------------------
     @staticmethod

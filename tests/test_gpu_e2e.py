@@ -223,3 +223,38 @@ def test_model_from_device_resident_arena(mels):
     r_host = host.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)
     r_dev = dev.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)
     assert [r.sequences_ids for r in r_host] == [r.sequences_ids for r in r_dev]
+
+
+def test_int8_float16_compute_type(mels, lib):
+    """SURVEY §8(f)4 / reference main.py:242: per-row int8 decoder weights with f16 activations.  The oracle runs on the
+    de-quantised weights (wis_hip.weights.quantize_decoder_weights restates the engine's quantiser in numpy), so the bars are
+    the f16 ones: the 8-bit path adds no arithmetic error of its own (int8 values are exact in f16, row scales are applied in fp32)."""
+    import ctypes as C
+    from oracle.whisper_ref import WhisperRef
+    from wis_hip import _lib, ctranslate2 as ct2, weights as W
+    w = W.synthetic_weights("tiny", seed=1234, std=0.02, emb_std=0.06, ln_jitter=0.1)
+    a = W.arch("tiny")
+    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=4, max_beam=5, compute_type="int8_float16")
+    assert model.compute_type == "int8_float16"
+    f16_model = ct2.Whisper("unused", weights=w, arch=a, max_batch=4, max_beam=5)
+    assert lib.wis_model_device_bytes(model._replicas[0].handle) < lib.wis_model_device_bytes(f16_model._replicas[0].handle)
+    ref = WhisperRef(W.quantize_decoder_weights(w), a["d_model"], a["n_layers"], a["n_heads"])
+    B, T = 2, 7
+    rng = np.random.default_rng(3)
+    dec_in = np.ascontiguousarray(np.concatenate([np.tile(np.array(PROMPT, np.int32), (B, 1)), rng.integers(0, 50000, size=(B, T - 4)).astype(np.int32)], axis=1))
+    out = np.zeros((B, T, a["n_vocab"]), np.float32)
+    _lib.check(lib.wis_debug_logits(_handle(model), _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T,
+                                    out.ctypes.data_as(C.POINTER(C.c_float))))
+    exp = ref.decode_logits(dec_in, ref.encode(mels)).numpy()
+    e, mx = _relerr(out, exp), np.abs(out - exp).max()
+    print(f"int8_float16 logits: rel-L2 {e:.3e}, max abs {mx:.3e}")
+    assert mx <= 5e-2 and e <= 5e-3
+    # and it is a DIFFERENT model from the f16 one (the quantisation is really in effect)
+    out16 = np.zeros_like(out)
+    _lib.check(lib.wis_debug_logits(_handle(f16_model), _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T,
+                                    out16.ctypes.data_as(C.POINTER(C.c_float))))
+    assert _relerr(out16, exp) > 3 * e
+    assert _check_generate(model, ref, mels, 1, 8) >= 1
+    assert _check_generate(model, ref, mels, 5, 8) >= 1
+    with pytest.raises(ValueError):
+        ct2.Whisper("unused", weights=w, arch=a, compute_type="bfloat16")

@@ -155,7 +155,10 @@ def test_enc_attention(lib, B, T, H):
                                          # more workgroups than CUs + several 16-row blocks + fused LN: the shapes that exposed a
                                          # cross-wave statistics hazard in round 1 (last row wrong in ~0.5 % of workgroups)
                                          (20, 5120, 640, 8 | 1), (24, 5120, 1280, 8 | 1), (40, 7680, 1280, 8 | 1), (40, 5120, 1280, 8 | 4),
-                                         (8, 5120, 1280, 8 | 4), (5, 1280, 5120, 0), (16, 1280, 4096, 2)])
+                                         (8, 5120, 1280, 8 | 4), (5, 1280, 5120, 0), (16, 1280, 4096, 2),
+                                         # int8_float16 (flag 32): per-row int8 weights, every kernel mode (LN-fused, f16 activations, generic ring, batched rows)
+                                         (5, 1280, 1280, 32 | 8 | 4), (5, 1280, 1280, 32 | 2), (5, 1280, 5120, 32 | 2), (5, 3840, 1280, 32 | 8 | 4),
+                                         (40, 1280, 5120, 32 | 2), (40, 5120, 1280, 32 | 1), (3, 1004, 384, 32 | 4), (1, 51872, 1280, 32 | 8 | 4)])
 def test_gemv(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 31 + N + K)
@@ -169,7 +172,13 @@ def test_gemv(lib, M, N, K, flags):
     else:
         x = rng.standard_normal((M, K)).astype(np.float16)
         xin = x.astype(np.float64)
-    ref = xin @ Wt.astype(np.float64).T + bias
+    Wref = Wt.astype(np.float64)
+    if flags & 32:            # the engine quantises the rows itself: the reference uses the de-quantised matrix
+        from wis_hip.weights import quantize_rows
+        q, sc = quantize_rows(Wt)
+        Wref = q.astype(np.float64) * sc.astype(np.float64)[:, None]
+        assert np.abs(Wref - Wt.astype(np.float64)).max() <= 0.5 * sc.max() * 1.0001     # within half a quantisation step
+    ref = xin @ Wref.T + bias
     if flags & 1:
         ref = _gelu(ref)
     y0 = rng.standard_normal((M, N)).astype(np.float32)

@@ -50,6 +50,78 @@ __global__ void pack_gemv_kernel(const f16* __restrict__ W, f16* __restrict__ Wp
     *reinterpret_cast<f16x8*>(Wp + idx * 8) = v;
   }
 }
+// ---- 8-bit weights (compute type int8_float16; SURVEY §8(f)4, reference main.py:242): the same fragment order with one BYTE
+// per weight, [Npad/16][K/32][64 lanes][8 B], stored offset-binary (q + 128) with one fp32 dequantisation scale per output row
+// (CTranslate2's per-row scheme: scale = absmax / 127, q = rint(w / scale)).  The kernel widens a lane's 8 bytes to 8 exact
+// f16 values with two byte permutes and two packed subtractions per dword ((0x6400 | u) is the f16 number 1024 + u), feeds
+// the SAME f16 MFMA (activations stay f16, accumulation fp32) and multiplies the row scale into the epilogue.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <bool W8> struct WFrag;
+template <> struct WFrag<false> {
+  typedef u32x4 T;
+  static __device__ __forceinline__ T zero() { return T{0u, 0u, 0u, 0u}; }
+  static __device__ __forceinline__ f16x8 cvt(const T& w) { return *reinterpret_cast<const f16x8*>(&w); }
+};
+template <> struct WFrag<true> {
+  typedef u32x2 T;
+  static __device__ __forceinline__ T zero() { return T{0x80808080u, 0x80808080u}; }     // q = 0
+  static __device__ __forceinline__ f16x8 cvt(const T& w) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const unsigned K64 = 0x64646464u;
+    unsigned a[4] = {__builtin_amdgcn_perm(K64, w.x, 0x04010400u), __builtin_amdgcn_perm(K64, w.x, 0x04030402u),
+                     __builtin_amdgcn_perm(K64, w.y, 0x04010400u), __builtin_amdgcn_perm(K64, w.y, 0x04030402u)};
+    const h2 off = {(f16)1152.0f, (f16)1152.0f};
+    f16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const h2 v = *reinterpret_cast<const h2*>(&a[i]) - off; r[2 * i] = v[0]; r[2 * i + 1] = v[1]; }
+    return r;
+  }
+};
+// per-row dequantisation scale (absmax / 127, times the folded query scaling) of W [N][K]; rows >= N get 0
+__global__ void row_scale_kernel(const f16* __restrict__ W, float* __restrict__ scale, int N, int Npad, int K, int n_scale, float qscale) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  if (n >= Npad) return;
+  float mx = 0.f;
+  if (n < N) for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf((float)W[(size_t)n * K + k]));
+  mx = wave_max(mx);
+  if (lane == 0) scale[n] = (n < N) ? (mx > 0.f ? mx / 127.0f : 1.0f) * (n < n_scale ? qscale : 1.0f) : 0.f;
+}
+__global__ void pack_gemv8_kernel(const f16* __restrict__ W, const float* __restrict__ scale, unsigned char* __restrict__ Wp, int N, int Npad, int K,
+                                  int n_scale, float qscale) {
+  const int ksteps = K / 32;
+  const size_t total = (size_t)Npad * ksteps * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx & 15);
+    size_t t = idx >> 4;
+    const int kq = (int)(t & 3); t >>= 2;
+    const int ks = (int)(t % ksteps), nt = (int)(t / ksteps);
+    const int n = 16 * nt + row, k = 32 * ks + 8 * kq;
+    unsigned char out[8];
+    if (n < N) {
+      const float inv = 1.0f / (scale[n] / (n < n_scale ? qscale : 1.0f));     // quantise the UNSCALED row; the folded factor lives in scale[]
+      const f16x8 v = *reinterpret_cast<const f16x8*>(W + (size_t)n * K + k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float q = rintf((float)v[j] * inv);
+        q = fminf(fmaxf(q, -127.f), 127.f);
+        out[j] = (unsigned char)((int)q + 128);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[j] = 128;
+    }
+    *reinterpret_cast<u32x2*>(Wp + idx * 8) = *reinterpret_cast<const u32x2*>(out);
+  }
+}
+int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* scale, int N, int Npad, int K, int n_scale, float qscale) {
+  if (K % 32 || Npad % 16 || Npad < N) { set_error("pack_gemv8: bad shape N=%d Npad=%d K=%d", N, Npad, K); return WIS_E_ARG; }
+  hipLaunchKernelGGL(row_scale_kernel, dim3(Npad), dim3(64), 0, st, W, scale, N, Npad, K, n_scale, qscale);
+  const size_t total = (size_t)Npad * (K / 32) * 4;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_gemv8_kernel, dim3(blocks), dim3(256), 0, st, W, scale, Wp, N, Npad, K, n_scale, qscale);
+  return WIS_OK;
+}
+
 // tile height of an [N][K] decoder matrix: the full 16-row MFMA fragment unless the matrix is both narrow (fewer than
 // ~200 tiles) and deep (K >= 2048: FFN2), where 4-row tiles spread the long per-tile stream over every CU.  For the
 // narrow d x d matrices the kernel is latency-bound and extra workgroups only add prologue work.
@@ -79,8 +151,9 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 // generic ring of 16 fragments with refill.
 
 // MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
-template <int MB, int MODE, int SC, int RM>
+template <int MB, int MODE, int SC, int RM, bool W8>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
+  typedef typename WFrag<W8>::T WT;
   constexpr int GV_PF = SC > 0 ? SC : 16;
   constexpr int rows = 16;   // full MFMA A fragments (4/8-row tiles were measured: more workgroups only add prologue work)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,8 +171,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   // fragment (tile, k-step) = 4*rows 16-byte pieces: piece (kq, row) at kq*rows + row; lanes with row >= rows stay zero
   const bool wact = (lane & 15) < rows;
   const int wstep = 4 * rows;                     // pieces per k-step
-  const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)nt * ksteps * wstep + (lane >> 4) * rows + (lane & 15);
-  const u32x4 wzero = {0u, 0u, 0u, 0u};
+  const WT* wp4 = reinterpret_cast<const WT*>(p.Wp) + (size_t)nt * ksteps * wstep + (lane >> 4) * rows + (lane & 15);
+  const WT wzero = WFrag<W8>::zero();
   const int k4n = K >> 2;                        // float4 per row
   const bool ln = p.flags & GV_LN;
   // fast LayerNorm path (host-selected, M <= 8, K <= 2048): the whole M x K activation lives in registers; thread
@@ -146,9 +219,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
   }
   // weight prefetch for chunk 0 (independent of x)
-  u32x4 wf[GV_PF];
+  WT wf[GV_PF];
   {
-    const u32x4* wq = wp4 + (size_t)ksl0 * wstep;
+    const WT* wq = wp4 + (size_t)ksl0 * wstep;
 #pragma unroll
     for (int u = 0; u < GV_PF; ++u) { wf[u] = wzero; if ((SC > 0 || u < S) && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep); }
   }
@@ -229,7 +302,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
 
   const int c8n = KC / 8;
   for (int kc0 = 0; kc0 < K; kc0 += KC) {
-    const u32x4* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * wstep;
+    const WT* wq = wp4 + (size_t)(kc0 / 32 + ksl0) * wstep;
     const bool more = MB > 1 && kc0 + KC < K;     // multi-chunk register staging exists for the batched row counts only
     if (kc0 > 0 && SC == 0) {
 #pragma unroll
@@ -274,7 +347,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     if (SC > 0) {
 #pragma unroll
       for (int u = 0; u < GV_PF; ++u) {
-        const f16x8 a = *reinterpret_cast<const f16x8*>(&wf[u]);
+        const f16x8 a = WFrag<W8>::cvt(wf[u]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + u) * 32);
@@ -287,7 +360,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
 #pragma unroll
         for (int u = 0; u < GV_PF; ++u) {
           if (base + u < S) {
-            const f16x8 a = *reinterpret_cast<const f16x8*>(&wf[u]);
+            const f16x8 a = WFrag<W8>::cvt(wf[u]);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
               const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + xrow[mb] + (ksl0 + base + u) * 32);
@@ -324,6 +397,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
     const int m = mb * 16 + (ln & 15), n = rows * nt + 4 * (ln >> 4);
     if (m < M && n < p.N && 4 * (ln >> 4) < rows) {
+      if (W8) { const float4 sc = *reinterpret_cast<const float4*>(p.wscale + n); s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w; }
       if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
       if (p.flags & GV_QKV) {
         const int d = p.d;
@@ -389,11 +463,12 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   } else if (!(p.flags & GV_LN) && p.M * (KC / 8) <= 30 * 256) mode = 2;       // register-staged f16 chunks (single or multi chunk)
   const int sck = KC / 128;
   const int sc = ((KC == p.K || mode == 2) && (sck == 3 || sck == 4 || sck == 6 || sck == 8 || sck == 10)) ? sck : 0;
-#define WIS_GV(MBv, MODEv, SCv, RMv) do { \
+#define WIS_GV1(MBv, MODEv, SCv, RMv, W8v) do { \
     if (lds > 65536) { static bool big_ok = false; \
-      if (!big_ok) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
+      if (!big_ok) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
                        set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } big_ok = true; } } \
-    hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv>), grid, block, lds, st, pp, KC); } while (0)
+    hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), grid, block, lds, st, pp, KC); } while (0)
+#define WIS_GV(MBv, MODEv, SCv, RMv) do { if (p.wscale) WIS_GV1(MBv, MODEv, SCv, RMv, true); else WIS_GV1(MBv, MODEv, SCv, RMv, false); } while (0)
 #define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \
                                                       case 8: WIS_GV(MBv, MODEv, 8, RMv); break; case 10: WIS_GV(MBv, MODEv, 10, RMv); break; default: WIS_GV(MBv, MODEv, 0, RMv); } } while (0)
   if (MB == 1) {
@@ -404,6 +479,7 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   else { if (mode == 2) WIS_GV_SC(3, 2, 1); else WIS_GV(3, 0, 0, 1); }
 #undef WIS_GV_SC
 #undef WIS_GV
+#undef WIS_GV1
   return WIS_OK;
 }
 

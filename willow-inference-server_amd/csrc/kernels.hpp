@@ -45,6 +45,7 @@ struct GemvP {
   const void* x;                 // f32 [M][K] when GV_LN else f16 [M][K]
   const float* gamma; const float* beta;
   const f16* Wp; const float* bias;
+  const float* wscale;           // non-null: Wp is the 8-bit packed image, one dequantisation scale per output row
   void* y;                       // [M][N] f32 (GV_OUT_F32 / GV_RESID in place) or f16
   int M, N, K, flags;
   // GV_QKV epilogue: n < d -> q (f32 [M][d]); d <= n < 2d -> K cache; n >= 2d -> V cache
@@ -53,6 +54,7 @@ struct GemvP {
   int rows;                      // weight rows per workgroup tile (16 / 8 / 4; 0 => 16): must match the packing
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
+int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* scale, int N, int Npad, int K, int n_scale, float qscale);
 // pack W [N][K] f16 row-major -> Wp [Npad/rows][K/32][4][rows][8]; matrix rows >= N are zero; scale matrix rows
 // [0, n_scale) by `scale` (folds the 1/sqrt(dh) query scaling into the projection)
 int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale, int rows = 16);

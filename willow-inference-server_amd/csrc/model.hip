@@ -81,6 +81,7 @@ struct DecLayerW {
   f16 *p_qkv, *p_out, *p_cq, *p_cout, *p_f1, *p_f2;   // MFMA-fragment packed
   f16 *w_ckv;                                        // row-major [2d][d] (encoder-side GEMM)
   float *b_qkv, *b_out, *b_cq, *b_ckv, *b_cout, *b_f1, *b_f2;
+  float *s_qkv = nullptr, *s_out = nullptr, *s_cq = nullptr, *s_cout = nullptr, *s_f1 = nullptr, *s_f2 = nullptr;   // int8_float16: row scales
 };
 
 struct GraphKey {
@@ -119,6 +120,8 @@ struct wis_model {
   wis_timing_t timing;
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph;
+  float* s_proj = nullptr;      // int8_float16: row scales of the vocabulary projection
+  bool w8 = false;              // decoder weights stored as 8-bit packed fragments
   unsigned long long* d_prof;   // [L*8][16] stamp rows, one per layer kernel (wis_debug_phase_cycles / wis_debug_timeline)
   bool prof_on; bool prof_all;
 };
@@ -184,13 +187,22 @@ int to_f16_mat(wis_model* m, const Loader& L, const std::string& name, int64_t r
   return WIS_OK;
 }
 // row-major source -> MFMA-fragment packed (through a temporary f16 image)
-int to_packed(wis_model* m, const Loader& L, const std::string& name, int N, int K, f16** out, f16* tmp, int n_scale = 0, float scale = 1.f, int* npad_out = nullptr) {
+int to_packed(wis_model* m, const Loader& L, const std::string& name, int N, int K, f16** out, f16* tmp, int n_scale = 0, float scale = 1.f, int* npad_out = nullptr,
+              float** scale_out = nullptr) {
   TensorSrc s; WIS_RET(L.get(name, N, K, &s));
   const int rows = gemv_rows_for(N, K);
   const int Npad = cdiv(N, rows) * rows;
-  WIS_RET(dalloc(m, out, (size_t)Npad * K));
   hipLaunchKernelGGL(convert_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, m->st, s.p, s.f16, tmp, 1, (int64_t)N, (int64_t)K, (int64_t)K, (int64_t)0, 1.f);
-  WIS_RET(launch_pack_gemv(m->st, tmp, *out, N, Npad, K, n_scale, scale, rows));
+  if (m->w8 && scale_out) {       // 8-bit fragments + per-row dequantisation scales (the query scaling is folded into the scales)
+    unsigned char* q8 = nullptr;
+    WIS_RET(dalloc(m, &q8, (size_t)Npad * K));
+    WIS_RET(dalloc(m, scale_out, (size_t)Npad));
+    WIS_RET(launch_pack_gemv8(m->st, tmp, q8, *scale_out, N, Npad, K, n_scale, scale));
+    *out = reinterpret_cast<f16*>(q8);
+  } else {
+    WIS_RET(dalloc(m, out, (size_t)Npad * K));
+    WIS_RET(launch_pack_gemv(m->st, tmp, *out, N, Npad, K, n_scale, scale, rows));
+  }
   if (npad_out) *npad_out = Npad;
   return WIS_OK;
 }
@@ -256,7 +268,7 @@ int load_weights(wis_model* m, const Loader& L) {
     if (rc) break;
     // ---- decoder
     if ((rc = to_f16_mat(m, L, "decoder/embeddings/weight", V, d, &m->emb))) break;
-    if ((rc = to_packed(m, L, "decoder/embeddings/weight", V, d, &m->p_proj, tmp, 0, 1.f, &m->n_vocab_pad))) break;
+    if ((rc = to_packed(m, L, "decoder/embeddings/weight", V, d, &m->p_proj, tmp, 0, 1.f, &m->n_vocab_pad, &m->s_proj))) break;
     if ((rc = to_f16_mat(m, L, "decoder/position_encodings/encodings", c.n_text_ctx, d, &m->dec_pos))) break;
     if ((rc = to_f32(m, L, "decoder/layer_norm/gamma", d, &m->dec_ln_g))) break;
     if ((rc = to_f32(m, L, "decoder/layer_norm/beta", d, &m->dec_ln_b))) break;
@@ -266,23 +278,23 @@ int load_weights(wis_model* m, const Loader& L) {
       DecLayerW& w = m->dec[l];
       if ((rc = to_f32(m, L, p + "self_attention/layer_norm/gamma", d, &w.ln1_g))) break;
       if ((rc = to_f32(m, L, p + "self_attention/layer_norm/beta", d, &w.ln1_b))) break;
-      if ((rc = to_packed(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.p_qkv, tmp, d, qs))) break;
+      if ((rc = to_packed(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.p_qkv, tmp, d, qs, nullptr, &w.s_qkv))) break;
       if ((rc = to_f32(m, L, p + "self_attention/linear_0/bias", 3 * d, &w.b_qkv, d, qs))) break;
-      if ((rc = to_packed(m, L, p + "self_attention/linear_1/weight", d, d, &w.p_out, tmp))) break;
+      if ((rc = to_packed(m, L, p + "self_attention/linear_1/weight", d, d, &w.p_out, tmp, 0, 1.f, nullptr, &w.s_out))) break;
       if ((rc = to_f32(m, L, p + "self_attention/linear_1/bias", d, &w.b_out))) break;
       if ((rc = to_f32(m, L, p + "attention/layer_norm/gamma", d, &w.ln2_g))) break;
       if ((rc = to_f32(m, L, p + "attention/layer_norm/beta", d, &w.ln2_b))) break;
-      if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs))) break;
+      if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs, nullptr, &w.s_cq))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_0/bias", d, &w.b_cq, d, qs))) break;
       if ((rc = to_f16_mat(m, L, p + "attention/linear_1/weight", 2 * d, d, &w.w_ckv))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_1/bias", 2 * d, &w.b_ckv))) break;
-      if ((rc = to_packed(m, L, p + "attention/linear_2/weight", d, d, &w.p_cout, tmp))) break;
+      if ((rc = to_packed(m, L, p + "attention/linear_2/weight", d, d, &w.p_cout, tmp, 0, 1.f, nullptr, &w.s_cout))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_2/bias", d, &w.b_cout))) break;
       if ((rc = to_f32(m, L, p + "ffn/layer_norm/gamma", d, &w.ln3_g))) break;
       if ((rc = to_f32(m, L, p + "ffn/layer_norm/beta", d, &w.ln3_b))) break;
-      if ((rc = to_packed(m, L, p + "ffn/linear_0/weight", 4 * d, d, &w.p_f1, tmp))) break;
+      if ((rc = to_packed(m, L, p + "ffn/linear_0/weight", 4 * d, d, &w.p_f1, tmp, 0, 1.f, nullptr, &w.s_f1))) break;
       if ((rc = to_f32(m, L, p + "ffn/linear_0/bias", 4 * d, &w.b_f1))) break;
-      if ((rc = to_packed(m, L, p + "ffn/linear_1/weight", d, 4 * d, &w.p_f2, tmp))) break;
+      if ((rc = to_packed(m, L, p + "ffn/linear_1/weight", d, 4 * d, &w.p_f2, tmp, 0, 1.f, nullptr, &w.s_f2))) break;
       if ((rc = to_f32(m, L, p + "ffn/linear_1/bias", d, &w.b_f2))) break;
     }
   } while (0);
@@ -436,39 +448,39 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     unsigned long long* pr = (m->prof_on && (l == 0 || m->prof_all)) ? m->d_prof + (size_t)l * 8 * 16 : nullptr;
     GemvP g; memset(&g, 0, sizeof(g));
     // self-attention block
-    g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
+    g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.wscale = w.s_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
     memset(&g, 0, sizeof(g));
-    g.x = m->dao; g.Wp = w.p_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
+    g.x = m->dao; g.Wp = w.p_out; g.wscale = w.s_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // cross-attention block
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
+    g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.wscale = w.s_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
     memset(&g, 0, sizeof(g));
-    g.x = m->dao; g.Wp = w.p_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
+    g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
+    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.wscale = w.s_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
-    g.x = m->dh; g.Wp = w.p_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 112 : nullptr;
+    g.x = m->dh; g.Wp = w.p_f2; g.wscale = w.s_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 112 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
   if (want_logits) {
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
@@ -505,7 +517,7 @@ const char* wis_last_error(void) { return get_error(); }
 int wis_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int wis_supported_compute_types(int device, char* out, size_t cap) {
   (void)device;
-  const char* s = "float16,float32";
+  const char* s = "float16,float32,int8_float16";
   if (!out || cap < strlen(s) + 1) { set_error("buffer too small"); return WIS_E_ARG; }
   strcpy(out, s); return WIS_OK;
 }
@@ -521,6 +533,7 @@ int wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_by
   DeviceCtx* ctx; WIS_RET(get_ctx(device, &ctx));
   wis_model* m = new wis_model();
   m->cfg = *cfg; m->device = device; m->ctx = ctx;
+  m->w8 = cfg->decoder_weight_bits == 8;
   m->use_graph = getenv("WIS_NO_GRAPH") == nullptr;
   memset(&m->timing, 0, sizeof(m->timing));
   int rc = WIS_OK;
@@ -864,24 +877,24 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   auto pass = [&](bool count) -> int {
     for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
       const DecLayerW& w = m->dec[l];
-      struct { const f16* wp; const float* b; const float* g; const float* be; int N, K; bool ln; } mats[6] = {
-        {w.p_qkv, w.b_qkv, w.ln1_g, w.ln1_b, 3 * d, d, true}, {w.p_out, w.b_out, nullptr, nullptr, d, d, false},
-        {w.p_cq, w.b_cq, w.ln2_g, w.ln2_b, d, d, true},        {w.p_cout, w.b_cout, nullptr, nullptr, d, d, false},
-        {w.p_f1, w.b_f1, w.ln3_g, w.ln3_b, 4 * d, d, true},    {w.p_f2, w.b_f2, nullptr, nullptr, d, 4 * d, false}};
+      struct { const f16* wp; const float* sc; const float* b; const float* g; const float* be; int N, K; bool ln; } mats[6] = {
+        {w.p_qkv, w.s_qkv, w.b_qkv, w.ln1_g, w.ln1_b, 3 * d, d, true}, {w.p_out, w.s_out, w.b_out, nullptr, nullptr, d, d, false},
+        {w.p_cq, w.s_cq, w.b_cq, w.ln2_g, w.ln2_b, d, d, true},        {w.p_cout, w.s_cout, w.b_cout, nullptr, nullptr, d, d, false},
+        {w.p_f1, w.s_f1, w.b_f1, w.ln3_g, w.ln3_b, 4 * d, d, true},    {w.p_f2, w.s_f2, w.b_f2, nullptr, nullptr, d, 4 * d, false}};
       for (auto& t : mats) {
         GemvP g; memset(&g, 0, sizeof(g));
-        g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.gamma = t.g; g.beta = t.be; g.Wp = t.wp; g.bias = t.b;
+        g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.gamma = t.g; g.beta = t.be; g.Wp = t.wp; g.wscale = t.sc; g.bias = t.b;
         g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
         g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-    WIS_RET(launch_gemv(st, g));
-        if (count) { ++launches; bytes += (double)t.N * t.K * 2; }
+        WIS_RET(launch_gemv(st, g));
+        if (count) { ++launches; bytes += (double)t.N * t.K * (m->w8 ? 1 : 2); }
       }
     }
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(m->cfg.n_vocab, g.K);
     WIS_RET(launch_gemv(st, g));
-    if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * 2; }
+    if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * (m->w8 ? 1 : 2); }
     return WIS_OK;
   };
   WIS_HIP_CHECK(hipMemsetAsync(m->dx, 0, (size_t)MAX_ROWS * d * 4, st));
@@ -946,17 +959,22 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
   hipStream_t st = ctx_stream(c);
   if (flags & GV_QKV) { set_error("wis_op_gemv: flag 16 is internal"); return WIS_E_ARG; }
   const int Npad = cdiv(N, gemv_rows_for(N, K)) * gemv_rows_for(N, K);
-  f16* wp = nullptr;
+  const bool w8 = flags & 32;
+  flags &= ~32;
+  f16* wp = nullptr; float* wsc = nullptr;
   WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Npad * K * 2));
+  if (w8) WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wsc), (size_t)Npad * 4));
   const int rows = gemv_rows_for(N, K);
-  int rc = launch_pack_gemv(st, reinterpret_cast<const f16*>(W), wp, N, Npad, K, 0, 1.f, rows);
+  int rc = w8 ? launch_pack_gemv8(st, reinterpret_cast<const f16*>(W), reinterpret_cast<unsigned char*>(wp), wsc, N, Npad, K, 0, 1.f)
+              : launch_pack_gemv(st, reinterpret_cast<const f16*>(W), wp, N, Npad, K, 0, 1.f, rows);
   if (!rc) {
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = x; g.gamma = gamma; g.beta = beta; g.Wp = wp; g.bias = bias; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags; g.rows = rows;
+    g.x = x; g.gamma = gamma; g.beta = beta; g.Wp = wp; g.wscale = wsc; g.bias = bias; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags; g.rows = rows;
     rc = launch_gemv(st, g);
   }
   hipError_t e = hipStreamSynchronize(st);
   hipFree(wp);
+  if (wsc) hipFree(wsc);
   if (rc) return rc;
   if (e != hipSuccess) { set_error("wis_op_gemv: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;

@@ -30,7 +30,7 @@ class Config(C.Structure):
                                           "no_speech")] + [
         ("suppress_ids", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32),
         ("suppress_ids_begin", C.POINTER(C.c_int32)), ("n_suppress_begin", C.c_int32),
-        ("lang_ids", C.POINTER(C.c_int32)), ("n_lang", C.c_int32)]
+        ("lang_ids", C.POINTER(C.c_int32)), ("n_lang", C.c_int32), ("decoder_weight_bits", C.c_int32)]
 
 
 class Tensor(C.Structure):

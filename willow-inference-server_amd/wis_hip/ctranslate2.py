@@ -66,7 +66,7 @@ class _Replica:
         self.inflight = 0
 
 
-def make_config(a, max_batch, max_beam, suppress_ids=None, suppress_begin=None, lang_ids=None, n_vocab=None):
+def make_config(a, max_batch, max_beam, suppress_ids=None, suppress_begin=None, lang_ids=None, n_vocab=None, weight_bits=16):
     sup = np.asarray(W.SUPPRESS_IDS if suppress_ids is None else suppress_ids, np.int32)
     beg = np.asarray(W.SUPPRESS_IDS_BEGIN if suppress_begin is None else suppress_begin, np.int32)
     lang = np.asarray(W.LANG_IDS if lang_ids is None else lang_ids, np.int32)
@@ -80,6 +80,7 @@ def make_config(a, max_batch, max_beam, suppress_ids=None, suppress_begin=None, 
     cfg.suppress_ids = sup.ctypes.data_as(C.POINTER(C.c_int32)); cfg.n_suppress = len(sup)
     cfg.suppress_ids_begin = beg.ctypes.data_as(C.POINTER(C.c_int32)); cfg.n_suppress_begin = len(beg)
     cfg.lang_ids = lang.ctypes.data_as(C.POINTER(C.c_int32)); cfg.n_lang = len(lang)
+    cfg.decoder_weight_bits = int(weight_bits)
     cfg._keep = (sup, beg, lang)
     return cfg
 
@@ -152,14 +153,22 @@ class Whisper:
         if device not in ("cuda", "auto", "hip", "gpu"):
             raise ValueError(f"wis_hip runs on MI355X GPUs only (device={device!r}); there is no CPU path")
         _lib.require_gpu()
-        self.compute_type = "float16"
+        # "float16" (default / "auto") or "int8_float16" (the reference's GPU default, main.py:242): per-row int8 DECODER
+        # weights with f16 activations; everything else stays f16
+        if compute_type in ("int8_float16", "int8"):
+            self.compute_type = "int8_float16"
+        elif compute_type in ("default", "auto", "float16", "float32"):
+            self.compute_type = "float16"
+        else:
+            raise ValueError(f"unsupported compute_type {compute_type!r} (float16, int8_float16)")
         cfg = {}
         if weights is None:
             weights, arch, cfg = self._load(model_path)
         self.arch, self.decode_config = arch, cfg
         devs = list(device_index) if isinstance(device_index, (list, tuple)) else [int(device_index)]
         arena, index = W.build_arena(weights)
-        kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"))
+        kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"),
+                  weight_bits=8 if self.compute_type == "int8_float16" else 16)
         self._replicas = [_Replica(create_handle(arch, arena, index, d, max_batch, max_beam, **kw), d) for d in devs]
         self.max_batch, self.max_beam = max_batch, max_beam
         self._pick = threading.Lock()

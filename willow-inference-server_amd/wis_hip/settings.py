@@ -38,6 +38,8 @@ class APISettings:
     # CTranslate2 model dir (models/tovera-wis-whisper-*, utils.sh:99-108), "synthetic:{size}" seeded synthetic weights.
     whisper_model_path: str = "synthetic:{size}"
     max_batch: int = 8
+    # "float16" or "int8_float16" (the reference picks int8_float16 on GPUs, main.py:242: here it quantises the decoder weights)
+    compute_type: str = "float16"
 
     def __post_init__(self):
         env = {k.lower(): v for k, v in os.environ.items()}

@@ -226,6 +226,35 @@ def write_ct2_model_bin(path, weights, spec="WhisperSpec", revision=3, aliases=N
             wstr(f, tgt)
 
 
+# ---- int8_float16: what the engine does to the decoder weights, restated for the oracle -------------------------
+DECODER_LINEARS = ("self_attention/linear_0", "self_attention/linear_1", "attention/linear_0", "attention/linear_2", "ffn/linear_0", "ffn/linear_1")
+
+
+def quantize_rows(w):
+    """CTranslate2's per-row int8 scheme as csrc/dec_kernels.hip implements it (float32 arithmetic, round-half-even):
+    scale = absmax(row) / 127 (1 for an all-zero row), q = clip(rint(w / scale), -127, 127).  Returns (q int8, scale f32)."""
+    w32 = np.asarray(w, np.float32)
+    mx = np.abs(w32).max(axis=1)
+    scale = np.where(mx > 0, mx / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+    inv = (np.float32(1.0) / scale).astype(np.float32)
+    q = np.clip(np.rint(w32 * inv[:, None]), -127, 127).astype(np.int8)
+    return q, scale
+
+
+def quantize_decoder_weights(weights):
+    """name -> array dict in which every decoder matrix the engine stores as int8 under compute_type="int8_float16" (the six
+    linears of each decoder layer and the vocabulary projection) is replaced by its float32 de-quantised value; the embedding
+    LOOKUP table, the cross K/V projection and the whole encoder stay f16, exactly as in the engine."""
+    out = dict(weights)
+    for name in list(weights):
+        if name.startswith("decoder/layer_") and name.endswith("/weight") and any(name.endswith(l + "/weight") for l in DECODER_LINEARS):
+            q, sc = quantize_rows(weights[name])
+            out[name] = q.astype(np.float32) * sc[:, None]
+    q, sc = quantize_rows(weights["decoder/embeddings/weight"])
+    out["decoder/projection/weight"] = q.astype(np.float32) * sc[:, None]
+    return out
+
+
 # ---- Hugging Face checkpoints (SURVEY §8(f)1; HF names per transformers modeling_whisper.py, SURVEY Appendix B) ----------------
 def from_hf_state_dict(sd, dtype=np.float16):
     """HF `WhisperForConditionalGeneration` state dict (name -> ndarray) -> CTranslate2 WhisperSpec names.

@@ -72,7 +72,7 @@ class WhisperModels:
         with self._lock:
             if size not in self._models:
                 path = self.path_for(size)
-                self._models[size] = ctranslate2.models.Whisper(path, device="cuda", compute_type="float16",
+                self._models[size] = ctranslate2.models.Whisper(path, device="cuda", compute_type=self.settings.compute_type,
                                                                 inter_threads=self.settings.ctranslate2_threads,
                                                                 device_index=self.device_index, max_batch=self.settings.max_batch)
                 if os.path.isdir(path):
