@@ -12,13 +12,13 @@
 //    prologue: every workgroup re-normalises the (tiny, L2-resident) M x d activation itself.
 //  * self-attention KV cache is never reordered: an ancestry table (anc[slot][pos] -> physical
 //    slot) is gathered per step instead of the K/V tensors.
-//  * cross-attention K is stored [H][dh/8][T][8] so lane-per-key reads are 16-byte coalesced,
-//    V as [H][T][64]; the `beam` query rows of an utterance are folded into one pass over the
-//    utterance's K/V (shared per utterance, never tiled per beam); the T axis is split across
-//    workgroups with an in-launch, placement-independent last-arriver combine.
+//  * cross-attention K is stored [H][dh/8][T][8] and V transposed [H][64][Tpad] so that both are MFMA A fragments read with
+//    16-byte loads; the `beam` query rows of an utterance are folded into one pass over the utterance's K/V (shared per
+//    utterance, never tiled per beam); the T axis is split into 256-key chunks across workgroups with an in-launch,
+//    placement-independent last-arriver combine.
 //  * suppress masks, log-softmax statistics and the top-2*beam candidates are computed in one
 //    pass over the logits (16 chunks per row), the beam bookkeeping runs on device (one wave per
-//    utterance) so the host never sees logits and a whole step is CUDA-graph-free replayable.
+//    utterance) so the host never sees logits and a whole step replays as one HIP graph.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -433,10 +433,12 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int MB = cdiv(p.M, 16);
   // largest K-chunk (multiple of 128 dividing K) whose f16 image of M rows fits the LDS: 64 KiB for <= 16 rows (several
   // workgroups per CU), the whole 160 KiB CU array (minus slack) for the batched-decode row counts
-  static size_t lds_dev_max = 0;
+  static size_t lds_dev_max = 0;      // same for every device of the node (one GPU model per node)
+  int cur_dev = 0;
+  if (hipGetDevice(&cur_dev) != hipSuccess) cur_dev = 0;
   if (!lds_dev_max) {
-    int dev = 0, v = 0; hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v < 65536) v = 65536;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, cur_dev) != hipSuccess || v < 65536) v = 65536;
     lds_dev_max = (size_t)v;
   }
   // (two half-size chunks so that two workgroups fit a CU were measured slower for N = 4d: 24.3 vs 19.0 us at 40 rows)
@@ -464,9 +466,9 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int sck = KC / 128;
   const int sc = ((KC == p.K || mode == 2) && (sck == 3 || sck == 4 || sck == 6 || sck == 8 || sck == 10)) ? sck : 0;
 #define WIS_GV1(MBv, MODEv, SCv, RMv, W8v) do { \
-    if (lds > 65536) { static bool big_ok = false; \
-      if (!big_ok) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
-                       set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } big_ok = true; } } \
+    if (lds > 65536) { static bool big_ok[64] = {};          /* the attribute is per device: one process may drive several GPUs */ \
+      if (!big_ok[cur_dev & 63]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
+                       set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } big_ok[cur_dev & 63] = true; } } \
     hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), grid, block, lds, st, pp, KC); } while (0)
 #define WIS_GV(MBv, MODEv, SCv, RMv) do { if (p.wscale) WIS_GV1(MBv, MODEv, SCv, RMv, true); else WIS_GV1(MBv, MODEv, SCv, RMv, false); } while (0)
 #define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \

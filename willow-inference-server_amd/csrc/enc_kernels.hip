@@ -199,7 +199,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi e
 static void gemm_pick_tile(const GemmP& p, int* bm, int* bn) {
   static int ebm = -1, ebn = -1;
   if (ebm < 0) { ebm = 0; ebn = 0; if (const char* e = getenv("WIS_GEMM_TILE")) sscanf(e, "%dx%d", &ebm, &ebn); }
-  if (ebm && ebn && p.N % ebn == 0) { *bm = ebm; *bn = ebn; return; }
+  const bool known = (ebm == 64 && ebn == 128) || (ebm == 128 && ebn == 128) || (ebm == 256 && ebn == 256);
+  if (known && p.N % ebn == 0 && (ebm != 64 || p.M > 64)) { *bm = ebm; *bn = ebn; return; }
   if (p.N % 256 == 0 && (p.N / 256) * cdiv(p.M, 256) >= 200) { *bm = 256; *bn = 256; return; }     // batched encoder
   const bool small = (p.N / 128) * cdiv(p.M, 128) < 200 && p.M > 64;
   *bm = small ? 64 : 128; *bn = 128;
