@@ -175,9 +175,13 @@ def test_gemv(lib, M, N, K, flags):
     Wref = Wt.astype(np.float64)
     if flags & 32:            # the engine quantises the rows itself: the reference uses the de-quantised matrix
         from wis_hip.weights import quantize_rows
-        q, sc = quantize_rows(Wt)
-        Wref = q.astype(np.float64) * sc.astype(np.float64)[:, None]
-        assert np.abs(Wref - Wt.astype(np.float64)).max() <= 0.5 * sc.max() * 1.0001     # within half a quantisation step
+        if flags & 8:         # a projection behind a LayerNorm is stored gamma-folded, and quantised in that form
+            from wis_hip.weights import quantize_folded
+            Wref = quantize_folded(Wt, g).astype(np.float64)
+        else:
+            q, sc = quantize_rows(Wt)
+            Wref = q.astype(np.float64) * sc.astype(np.float64)[:, None]
+            assert np.abs(Wref - Wt.astype(np.float64)).max() <= 0.5 * sc.max() * 1.0001     # within half a quantisation step
     ref = xin @ Wref.T + bias
     if flags & 1:
         ref = _gelu(ref)

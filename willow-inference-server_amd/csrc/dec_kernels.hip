@@ -122,6 +122,46 @@ int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* sc
   return WIS_OK;
 }
 
+// ---- LayerNorm folded into the following projection (pre-LN blocks: y = W . LN(x) + b).  With W' = W o gamma (columns scaled),
+//   y_n = rs * ( sum_k W'_nk x_k  -  mu * c_n ) + b'_n,     c_n = sum_k W'_nk,     b'_n = b_n + sum_k W_nk beta_k,
+// so the skinny GEMM runs on the RAW activation row (cast to f16) and the row statistics (mu, rs) are only needed in its
+// epilogue - the normalise-and-restage pass, its barrier and the gamma / beta loads leave the kernel's critical path.
+// One wave per matrix row: rewrites W in place as f16(W * gamma), accumulates c from the ROUNDED products (what the MFMA
+// will see) and adds W . beta to the bias.  Rows < n_scale carry the folded query scaling (applied to W by the packer).
+__global__ void fold_ln_kernel(f16* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ bias,
+                               float* __restrict__ csum, int N, int K, int n_scale, float qscale) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  if (n >= N) return;
+  float c = 0.f, wb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = (float)W[(size_t)n * K + k];
+    const f16 wg = (f16)(w * gamma[k]);
+    W[(size_t)n * K + k] = wg;
+    c += (float)wg; wb += w * beta[k];
+  }
+  c = wave_sum(c); wb = wave_sum(wb);
+  const float f = n < n_scale ? qscale : 1.0f;
+  if (lane == 0) { csum[n] = c * f; bias[n] += wb * f; }
+}
+// 8-bit variant of c: from the de-quantised values the MFMA will see (scale_n * sum_k q_nk; scale[] already carries qscale)
+__global__ void csum8_kernel(const f16* __restrict__ W, const float* __restrict__ scale, float* __restrict__ csum, int N, int K, int n_scale, float qscale) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  if (n >= N) return;
+  const float inv = 1.0f / (scale[n] / (n < n_scale ? qscale : 1.0f));
+  float c = 0.f;
+  for (int k = lane; k < K; k += 64) { float q = rintf((float)W[(size_t)n * K + k] * inv); c += fminf(fmaxf(q, -127.f), 127.f); }
+  c = wave_sum(c);
+  if (lane == 0) csum[n] = c * scale[n];
+}
+int launch_fold_ln(hipStream_t st, f16* W, const float* gamma, const float* beta, float* bias, float* csum, int N, int K, int n_scale, float qscale) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(64), 0, st, W, gamma, beta, bias, csum, N, K, n_scale, qscale);
+  return WIS_OK;
+}
+int launch_csum8(hipStream_t st, const f16* W, const float* scale, float* csum, int N, int K, int n_scale, float qscale) {
+  hipLaunchKernelGGL(csum8_kernel, dim3(N), dim3(64), 0, st, W, scale, csum, N, K, n_scale, qscale);
+  return WIS_OK;
+}
+
 // tile height of an [N][K] decoder matrix: the full 16-row MFMA fragment unless the matrix is both narrow (fewer than
 // ~200 tiles) and deep (K >= 2048: FFN2), where 4-row tiles spread the long per-tile stream over every CU.  For the
 // narrow d x d matrices the kernel is latency-bound and extra workgroups only add prologue work.
@@ -174,26 +214,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const WT* wp4 = reinterpret_cast<const WT*>(p.Wp) + (size_t)nt * ksteps * wstep + (lane >> 4) * rows + (lane & 15);
   const WT wzero = WFrag<W8>::zero();
   const int k4n = K >> 2;                        // float4 per row
-  const bool ln = p.flags & GV_LN;
-  // fast LayerNorm path (host-selected, M <= 8, K <= 2048): the whole M x K activation lives in registers; thread
-  // owns float4 columns k4 = tid, tid + 256 of every row (no index arithmetic), statistics are a single shifted pass
-  // (c = x[r][0]: var = E[(x-c)^2] - E[x-c]^2) so the block needs ONE reduction + barrier before staging.
+  // LayerNorm-folded path (MODE 1; host-selected, M <= 8, K <= 2048): the raw fp32 rows live in registers, thread owns float4
+  // columns k4 = tid, tid + 256 of every row; they are cast to f16 and staged at once, the statistics (single shifted pass,
+  // c = x[r][0]: var = E[(x-c)^2] - E[x-c]^2) are reduced AFTER the MFMA loop and meet the accumulators in the epilogue.
   constexpr bool fast = MODE == 1;
   constexpr int RMAX = fast ? RM : 1;        // RM in {3, 5, 8}: smallest that holds M (rows >= M are clamped duplicates)
-  float4 xv[RMAX][2], gv[2], bv[2];
+  float4 xv[RMAX][2];
   float cshift[RMAX];
   unsigned long long* pf = (blockIdx.x == 0 && tid == 0) ? p.prof : nullptr;
   if (tid == 0) tl_begin(p.prof);
   stamp(pf, 0);
   if (fast) {
     const float4* x4 = reinterpret_cast<const float4*>(p.x);
-    const float4* g4 = reinterpret_cast<const float4*>(p.gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(p.beta);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k4 = tid + 256 * j;
       if (k4 < k4n) {
-        gv[j] = g4[k4]; bv[j] = b4[k4];
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; xv[r][j] = x4[(size_t)rr * k4n + k4]; }   // rows >= M: clamped duplicates
       }
@@ -227,70 +263,30 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   }
 
   stamp(pf, 1);
+  float sa[RMAX], sb[RMAX];
   if (fast) {
-    float sa[RMAX], sb[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
+      const int rr = r < M ? r : M - 1;       // clamped rows rewrite row M-1 with identical values (benign)
       sa[r] = 0.f; sb[r] = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (tid + 256 * j < k4n) {
+        const int k4 = tid + 256 * j;
+        if (k4 < k4n) {
+          const f16x4 o = {(f16)xv[r][j].x, (f16)xv[r][j].y, (f16)xv[r][j].z, (f16)xv[r][j].w};
+          *reinterpret_cast<f16x4*>(xs + (size_t)rr * xstr + k4 * 4) = o;
           const float a = xv[r][j].x - cshift[r], b = xv[r][j].y - cshift[r], c = xv[r][j].z - cshift[r], e = xv[r][j].w - cshift[r];
           sa[r] += (a + b) + (c + e); sb[r] += (a * a + b * b) + (c * c + e * e);
         }
       }
     }
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const float ta = wave_sum(sa[r]), tb = wave_sum(sb[r]);
-      if (lane == 0) { sred[wave * 16 + 2 * r] = ta; sred[wave * 16 + 2 * r + 1] = tb; }
-    }
-    __syncthreads();
     stamp(pf, 2);
-    const float invK = 1.0f / (float)K;
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      {
-        const int rr = r < M ? r : M - 1;       // clamped rows rewrite row M-1 with identical values (benign)
-        const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) * invK;
-        const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) * invK;
-        const float mu = cshift[r] + A;
-        const float rs = __builtin_amdgcn_rsqf(fmaxf(Bq - A * A, 0.f) + 1e-5f);   // v_rsq_f32 (1 ulp); the result is rounded to f16 anyway
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k4 = tid + 256 * j;
-          if (k4 < k4n) {
-            f16x4 o;
-            o[0] = (f16)((xv[r][j].x - mu) * rs * gv[j].x + bv[j].x); o[1] = (f16)((xv[r][j].y - mu) * rs * gv[j].y + bv[j].y);
-            o[2] = (f16)((xv[r][j].z - mu) * rs * gv[j].z + bv[j].z); o[3] = (f16)((xv[r][j].w - mu) * rs * gv[j].w + bv[j].w);
-            *reinterpret_cast<f16x4*>(xs + (size_t)rr * xstr + k4 * 4) = o;
-          }
-        }
-      }
-    }
   } else if (fastx) {
 #pragma unroll
     for (int i = 0; i < NXH; ++i) {
       const int idx = tid + 256 * i;
       if (idx < nx) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
     }
-  } else if (ln) {
-    const float* xf = reinterpret_cast<const float*>(p.x);
-    for (int r = wave; r < M; r += 4) {
-      const float4* x4 = reinterpret_cast<const float4*>(xf + (size_t)r * K);
-      float sm = 0.f;
-      for (int i = lane; i < k4n; i += 64) { const float4 v = x4[i]; sm += (v.x + v.y) + (v.z + v.w); }
-      const float mean = wave_sum(sm) / (float)K;
-      float q = 0.f;
-      for (int i = lane; i < k4n; i += 64) {
-        const float4 v = x4[i];
-        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
-        q += (a * a + b * b) + (c * c + e * e);
-      }
-      const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
-      if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
-    }
-    __syncthreads();
   }
 
   f32x4 acc[MB];
@@ -314,27 +310,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = idx / c8; xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
     }
     if (!fast && !fastx) {
-      // stage x[:, kc0:kc0+KC] as f16
-      if (ln) {
-        // wave w normalises exactly the rows whose statistics it computed (r = w, w+4, ...): the statistics never
-        // cross waves
-        for (int r = wave; r < M; r += 4) {
-          const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-          const float* xr0 = reinterpret_cast<const float*>(p.x) + (size_t)r * K + kc0;
-          for (int c8 = lane; c8 < c8n; c8 += 64) {
-            const int k = kc0 + c8 * 8;
-            const float4 a = *reinterpret_cast<const float4*>(xr0 + c8 * 8), b = *reinterpret_cast<const float4*>(xr0 + c8 * 8 + 4);
-            const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + k), g1 = *reinterpret_cast<const float4*>(p.gamma + k + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(p.beta + k), b1 = *reinterpret_cast<const float4*>(p.beta + k + 4);
-            f16x8 o;
-            o[0] = (f16)((a.x - mean) * rstd * g0.x + b0.x); o[1] = (f16)((a.y - mean) * rstd * g0.y + b0.y);
-            o[2] = (f16)((a.z - mean) * rstd * g0.z + b0.z); o[3] = (f16)((a.w - mean) * rstd * g0.w + b0.w);
-            o[4] = (f16)((b.x - mean) * rstd * g1.x + b1.x); o[5] = (f16)((b.y - mean) * rstd * g1.y + b1.y);
-            o[6] = (f16)((b.z - mean) * rstd * g1.z + b1.z); o[7] = (f16)((b.w - mean) * rstd * g1.w + b1.w);
-            *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) = o;
-          }
-        }
-      } else {
+      // stage x[:, kc0:kc0+KC] (f16 activations)
+      {
         for (int idx = tid; idx < M * c8n; idx += 256) {
           const int r = idx / c8n, c8 = idx - r * c8n, k = kc0 + c8 * 8;
           *reinterpret_cast<f16x8*>(xs + (size_t)r * xstr + c8 * 8) =
@@ -381,6 +358,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
   }
   stamp(pf, 4);
+  if (fast) {   // LayerNorm statistics of the folded form: reduced here, behind the MFMAs, published with the accumulators
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const float ta = wave_sum(sa[r]), tb = wave_sum(sb[r]);
+      if (lane == 0) { sred[wave * 16 + 2 * r] = ta; sred[wave * 16 + 2 * r + 1] = tb; }
+    }
+  }
   // cross-wave reduction; D[i = n][j = m]: lane holds m = lane&15, n = 4*(lane>>4) + r
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -398,6 +382,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     const int m = mb * 16 + (ln & 15), n = rows * nt + 4 * (ln >> 4);
     if (m < M && n < p.N && 4 * (ln >> 4) < rows) {
       if (W8) { const float4 sc = *reinterpret_cast<const float4*>(p.wscale + n); s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w; }
+      if (fast) {   // y = rs * (W' x - mu * c) [+ b' below]
+        const int r = m < RMAX ? m : RMAX - 1;
+        const float invK = 1.0f / (float)K;
+        const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) * invK;
+        const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) * invK;
+        float shift = cshift[0];                          // the row's shift x[m][0], still in registers
+#pragma unroll
+        for (int q = 1; q < RMAX; ++q) shift = (r == q) ? cshift[q] : shift;
+        const float mu = shift + A;
+        const float rs = 1.0f / sqrtf(fmaxf(Bq - A * A, 0.f) + 1e-5f);
+        const float4 cs = *reinterpret_cast<const float4*>(p.csum + n);
+        s.x = rs * (s.x - mu * cs.x); s.y = rs * (s.y - mu * cs.y); s.z = rs * (s.z - mu * cs.z); s.w = rs * (s.w - mu * cs.w);
+      }
       if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
       if (p.flags & GV_QKV) {
         const int d = p.d;
@@ -457,9 +454,14 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int npad = cdiv(p.N, rows) * rows;
   dim3 grid(npad / rows), block(256);
   int mode = 0;
+  if (p.flags & GV_LN) {
+    // folded LayerNorm: raw fp32 rows in registers - at most 8 rows of at most 2048 columns; callers split larger row counts
+    // into layernorm_kernel (no affine) + the f16-activation path (model.hip: launch_ln_gemv)
+    if (p.M > 8 || p.K > 2048 || KC != p.K || !p.csum) { set_error("gemv: fused LayerNorm needs M <= 8, K <= 2048 and the folded column sums (M=%d K=%d)", p.M, p.K); return WIS_E_UNSUPPORTED; }
+  }
   if (MB == 1) {
     if (KC == p.K) {
-      if ((p.flags & GV_LN) && p.M <= 8 && p.K <= 2048) mode = 1;
+      if (p.flags & GV_LN) mode = 1;
       else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
     }
   } else if (!(p.flags & GV_LN) && p.M * (KC / 8) <= 30 * 256) mode = 2;       // register-staged f16 chunks (single or multi chunk)

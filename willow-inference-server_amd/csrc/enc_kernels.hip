@@ -52,14 +52,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-  const float4* g4 = reinterpret_cast<const float4*>(gamma);
-  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);      // gamma == nullptr: plain normalisation (the affine part is folded
+  const float4* b4 = reinterpret_cast<const float4*>(beta);       // into the weights of the projection that follows)
   f16x4* y4 = reinterpret_cast<f16x4*>(y + (size_t)row * d);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = lane + 64 * i;
     if (idx < n4) {
-      const float4 g = g4[idx], b = b4[idx];
+      const float4 g = gamma ? g4[idx] : make_float4(1.f, 1.f, 1.f, 1.f), b = gamma ? b4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
       f16x4 o;
       o[0] = (f16)((v[i].x - mean) * rstd * g.x + b.x);
       o[1] = (f16)((v[i].y - mean) * rstd * g.y + b.y);

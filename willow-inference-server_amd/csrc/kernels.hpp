@@ -42,8 +42,9 @@ struct RowMeta {
 // skinny GEMM (decoder): y = epi(LN?(x) . Wp^T + b), Wp packed in MFMA 16x16x32 A-fragment order
 enum { GV_GELU = 1, GV_RESID = 2, GV_OUT_F32 = 4, GV_LN = 8, GV_QKV = 16 };
 struct GemvP {
-  const void* x;                 // f32 [M][K] when GV_LN else f16 [M][K]
-  const float* gamma; const float* beta;
+  const void* x;                 // f32 [M][K] (raw, un-normalised) when GV_LN else f16 [M][K]
+  const float* gamma; const float* beta;   // only used by the split path (model.hip launch_ln_gemv); the kernel never reads them
+  const float* csum;             // GV_LN: column sums of the gamma-folded weights (see fold_ln_kernel); bias then is b + W.beta
   const f16* Wp; const float* bias;
   const float* wscale;           // non-null: Wp is the 8-bit packed image, one dequantisation scale per output row
   void* y;                       // [M][N] f32 (GV_OUT_F32 / GV_RESID in place) or f16
@@ -54,6 +55,8 @@ struct GemvP {
   int rows;                      // weight rows per workgroup tile (16 / 8 / 4; 0 => 16): must match the packing
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
+int launch_fold_ln(hipStream_t st, f16* W, const float* gamma, const float* beta, float* bias, float* csum, int N, int K, int n_scale, float qscale);
+int launch_csum8(hipStream_t st, const f16* W, const float* scale, float* csum, int N, int K, int n_scale, float qscale);
 int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* scale, int N, int Npad, int K, int n_scale, float qscale);
 // pack W [N][K] f16 row-major -> Wp [Npad/rows][K/32][4][rows][8]; matrix rows >= N are zero; scale matrix rows
 // [0, n_scale) by `scale` (folds the 1/sqrt(dh) query scaling into the projection)

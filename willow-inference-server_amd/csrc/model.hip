@@ -82,6 +82,7 @@ struct DecLayerW {
   f16 *w_ckv;                                        // row-major [2d][d] (encoder-side GEMM)
   float *b_qkv, *b_out, *b_cq, *b_ckv, *b_cout, *b_f1, *b_f2;
   float *s_qkv = nullptr, *s_out = nullptr, *s_cq = nullptr, *s_cout = nullptr, *s_f1 = nullptr, *s_f2 = nullptr;   // int8_float16: row scales
+  float *c_qkv = nullptr, *c_cq = nullptr, *c_f1 = nullptr;   // column sums of the LayerNorm-folded weights (dec_kernels.hip fold_ln_kernel)
 };
 
 struct GraphKey {
@@ -121,6 +122,7 @@ struct wis_model {
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph;
   float* s_proj = nullptr;      // int8_float16: row scales of the vocabulary projection
+  float* c_proj = nullptr; float* b_proj = nullptr;   // LayerNorm-folded vocabulary projection: column sums, W . beta
   bool w8 = false;              // decoder weights stored as 8-bit packed fragments
   unsigned long long* d_prof;   // [L*8][16] stamp rows, one per layer kernel (wis_debug_phase_cycles / wis_debug_timeline)
   bool prof_on; bool prof_all;
@@ -187,17 +189,26 @@ int to_f16_mat(wis_model* m, const Loader& L, const std::string& name, int64_t r
   return WIS_OK;
 }
 // row-major source -> MFMA-fragment packed (through a temporary f16 image)
+// ln_gamma / ln_beta (device, fp32 [K]) != nullptr: the projection follows a LayerNorm - fold it (fold_ln_kernel): `bias`
+// (device fp32, >= N entries, already loaded) receives W . beta, *csum_out the column sums of the folded weights.
 int to_packed(wis_model* m, const Loader& L, const std::string& name, int N, int K, f16** out, f16* tmp, int n_scale = 0, float scale = 1.f, int* npad_out = nullptr,
-              float** scale_out = nullptr) {
+              float** scale_out = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float* bias = nullptr, float** csum_out = nullptr) {
   TensorSrc s; WIS_RET(L.get(name, N, K, &s));
   const int rows = gemv_rows_for(N, K);
   const int Npad = cdiv(N, rows) * rows;
   hipLaunchKernelGGL(convert_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, m->st, s.p, s.f16, tmp, 1, (int64_t)N, (int64_t)K, (int64_t)K, (int64_t)0, 1.f);
+  if (ln_gamma) {
+    if (!bias || !csum_out) { set_error("to_packed: LayerNorm folding needs a bias vector and a column-sum output"); return WIS_E_ARG; }
+    WIS_RET(dalloc(m, csum_out, (size_t)Npad));
+    WIS_HIP_CHECK(hipMemsetAsync(*csum_out, 0, (size_t)Npad * 4, m->st));
+    WIS_RET(launch_fold_ln(m->st, tmp, ln_gamma, ln_beta, bias, *csum_out, N, K, n_scale, scale));
+  }
   if (m->w8 && scale_out) {       // 8-bit fragments + per-row dequantisation scales (the query scaling is folded into the scales)
     unsigned char* q8 = nullptr;
     WIS_RET(dalloc(m, &q8, (size_t)Npad * K));
     WIS_RET(dalloc(m, scale_out, (size_t)Npad));
     WIS_RET(launch_pack_gemv8(m->st, tmp, q8, *scale_out, N, Npad, K, n_scale, scale));
+    if (ln_gamma) WIS_RET(launch_csum8(m->st, tmp, *scale_out, *csum_out, N, K, n_scale, scale));   // sums of what the MFMA will really see
     *out = reinterpret_cast<f16*>(q8);
   } else {
     WIS_RET(dalloc(m, out, (size_t)Npad * K));
@@ -268,32 +279,37 @@ int load_weights(wis_model* m, const Loader& L) {
     if (rc) break;
     // ---- decoder
     if ((rc = to_f16_mat(m, L, "decoder/embeddings/weight", V, d, &m->emb))) break;
-    if ((rc = to_packed(m, L, "decoder/embeddings/weight", V, d, &m->p_proj, tmp, 0, 1.f, &m->n_vocab_pad, &m->s_proj))) break;
     if ((rc = to_f16_mat(m, L, "decoder/position_encodings/encodings", c.n_text_ctx, d, &m->dec_pos))) break;
     if ((rc = to_f32(m, L, "decoder/layer_norm/gamma", d, &m->dec_ln_g))) break;
     if ((rc = to_f32(m, L, "decoder/layer_norm/beta", d, &m->dec_ln_b))) break;
+    // every projection that follows a LayerNorm is stored LayerNorm-folded (W o gamma, bias + W . beta, column sums): the final
+    // LayerNorm into the tied vocabulary projection (which has no bias of its own) ...
+    if ((rc = dalloc(m, &m->b_proj, (size_t)V + 64))) break;
+    if (hipMemsetAsync(m->b_proj, 0, ((size_t)V + 64) * 4, m->st) != hipSuccess) { set_error("memset failed"); rc = WIS_E_HIP; break; }
+    if ((rc = to_packed(m, L, "decoder/embeddings/weight", V, d, &m->p_proj, tmp, 0, 1.f, &m->n_vocab_pad, &m->s_proj, m->dec_ln_g, m->dec_ln_b, m->b_proj, &m->c_proj))) break;
     m->dec.resize(c.n_dec_layers);
     for (int l = 0; l < c.n_dec_layers && !rc; ++l) {
       const std::string p = "decoder/layer_" + std::to_string(l) + "/";
       DecLayerW& w = m->dec[l];
       if ((rc = to_f32(m, L, p + "self_attention/layer_norm/gamma", d, &w.ln1_g))) break;
       if ((rc = to_f32(m, L, p + "self_attention/layer_norm/beta", d, &w.ln1_b))) break;
-      if ((rc = to_packed(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.p_qkv, tmp, d, qs, nullptr, &w.s_qkv))) break;
+      // ... and ln1 -> QKV, ln2 -> cross-Q, ln3 -> FFN1 of every layer (bias first: the fold adds W . beta to it)
       if ((rc = to_f32(m, L, p + "self_attention/linear_0/bias", 3 * d, &w.b_qkv, d, qs))) break;
+      if ((rc = to_packed(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.p_qkv, tmp, d, qs, nullptr, &w.s_qkv, w.ln1_g, w.ln1_b, w.b_qkv, &w.c_qkv))) break;
       if ((rc = to_packed(m, L, p + "self_attention/linear_1/weight", d, d, &w.p_out, tmp, 0, 1.f, nullptr, &w.s_out))) break;
       if ((rc = to_f32(m, L, p + "self_attention/linear_1/bias", d, &w.b_out))) break;
       if ((rc = to_f32(m, L, p + "attention/layer_norm/gamma", d, &w.ln2_g))) break;
       if ((rc = to_f32(m, L, p + "attention/layer_norm/beta", d, &w.ln2_b))) break;
-      if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs, nullptr, &w.s_cq))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_0/bias", d, &w.b_cq, d, qs))) break;
+      if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs, nullptr, &w.s_cq, w.ln2_g, w.ln2_b, w.b_cq, &w.c_cq))) break;
       if ((rc = to_f16_mat(m, L, p + "attention/linear_1/weight", 2 * d, d, &w.w_ckv))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_1/bias", 2 * d, &w.b_ckv))) break;
       if ((rc = to_packed(m, L, p + "attention/linear_2/weight", d, d, &w.p_cout, tmp, 0, 1.f, nullptr, &w.s_cout))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_2/bias", d, &w.b_cout))) break;
       if ((rc = to_f32(m, L, p + "ffn/layer_norm/gamma", d, &w.ln3_g))) break;
       if ((rc = to_f32(m, L, p + "ffn/layer_norm/beta", d, &w.ln3_b))) break;
-      if ((rc = to_packed(m, L, p + "ffn/linear_0/weight", 4 * d, d, &w.p_f1, tmp, 0, 1.f, nullptr, &w.s_f1))) break;
       if ((rc = to_f32(m, L, p + "ffn/linear_0/bias", 4 * d, &w.b_f1))) break;
+      if ((rc = to_packed(m, L, p + "ffn/linear_0/weight", 4 * d, d, &w.p_f1, tmp, 0, 1.f, nullptr, &w.s_f1, w.ln3_g, w.ln3_b, w.b_f1, &w.c_f1))) break;
       if ((rc = to_packed(m, L, p + "ffn/linear_1/weight", d, 4 * d, &w.p_f2, tmp, 0, 1.f, nullptr, &w.s_f2))) break;
       if ((rc = to_f32(m, L, p + "ffn/linear_1/bias", d, &w.b_f2))) break;
     }
@@ -426,9 +442,9 @@ int run_cross_kv(wis_model* m, int B) {
 // (batched decode: B*beam up to 48) every workgroup re-normalising all rows costs more than one extra launch, so the rows are
 // normalised once by layernorm_kernel into an f16 buffer and the GEMM takes its f16-activation path.
 static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
-  if (g.M > 8 && (g.flags & GV_LN)) {
-    WIS_RET(launch_layernorm(st, reinterpret_cast<const float*>(g.x), g.gamma, g.beta, m->dln, g.M, g.K));
-    g.x = m->dln; g.gamma = nullptr; g.beta = nullptr; g.flags &= ~GV_LN;
+  if (g.M > 8 && (g.flags & GV_LN)) {   // plain normalisation (the affine part lives in the folded weights / bias), then f16 activations
+    WIS_RET(launch_layernorm(st, reinterpret_cast<const float*>(g.x), nullptr, nullptr, m->dln, g.M, g.K));
+    g.x = m->dln; g.csum = nullptr; g.flags &= ~GV_LN;
   }
   return launch_gemv(st, g);
 }
@@ -448,7 +464,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     unsigned long long* pr = (m->prof_on && (l == 0 || m->prof_all)) ? m->d_prof + (size_t)l * 8 * 16 : nullptr;
     GemvP g; memset(&g, 0, sizeof(g));
     // self-attention block
-    g.x = m->dx; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.Wp = w.p_qkv; g.wscale = w.s_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
+    g.x = m->dx; g.csum = w.c_qkv; g.Wp = w.p_qkv; g.wscale = w.s_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
@@ -460,7 +476,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     WIS_RET(launch_ln_gemv(m, st, g));
     // cross-attention block
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.Wp = w.p_cq; g.wscale = w.s_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
+    g.x = m->dx; g.csum = w.c_cq; g.Wp = w.p_cq; g.wscale = w.s_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
@@ -470,7 +486,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
     memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.Wp = w.p_f1; g.wscale = w.s_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
+    g.x = m->dx; g.csum = w.c_f1; g.Wp = w.p_f1; g.wscale = w.s_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
@@ -480,7 +496,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   }
   if (want_logits) {
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.x = m->dx; g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
@@ -877,13 +893,13 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   auto pass = [&](bool count) -> int {
     for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
       const DecLayerW& w = m->dec[l];
-      struct { const f16* wp; const float* sc; const float* b; const float* g; const float* be; int N, K; bool ln; } mats[6] = {
-        {w.p_qkv, w.s_qkv, w.b_qkv, w.ln1_g, w.ln1_b, 3 * d, d, true}, {w.p_out, w.s_out, w.b_out, nullptr, nullptr, d, d, false},
-        {w.p_cq, w.s_cq, w.b_cq, w.ln2_g, w.ln2_b, d, d, true},        {w.p_cout, w.s_cout, w.b_cout, nullptr, nullptr, d, d, false},
-        {w.p_f1, w.s_f1, w.b_f1, w.ln3_g, w.ln3_b, 4 * d, d, true},    {w.p_f2, w.s_f2, w.b_f2, nullptr, nullptr, d, 4 * d, false}};
+      struct { const f16* wp; const float* sc; const float* b; const float* cs; int N, K; bool ln; } mats[6] = {
+        {w.p_qkv, w.s_qkv, w.b_qkv, w.c_qkv, 3 * d, d, true}, {w.p_out, w.s_out, w.b_out, nullptr, d, d, false},
+        {w.p_cq, w.s_cq, w.b_cq, w.c_cq, d, d, true},        {w.p_cout, w.s_cout, w.b_cout, nullptr, d, d, false},
+        {w.p_f1, w.s_f1, w.b_f1, w.c_f1, 4 * d, d, true},    {w.p_f2, w.s_f2, w.b_f2, nullptr, d, 4 * d, false}};
       for (auto& t : mats) {
         GemvP g; memset(&g, 0, sizeof(g));
-        g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.gamma = t.g; g.beta = t.be; g.Wp = t.wp; g.wscale = t.sc; g.bias = t.b;
+        g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.csum = t.cs; g.Wp = t.wp; g.wscale = t.sc; g.bias = t.b;
         g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
         g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
         WIS_RET(launch_gemv(st, g));
@@ -891,7 +907,7 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
       }
     }
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.gamma = m->dec_ln_g; g.beta = m->dec_ln_b; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.x = m->dx; g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(m->cfg.n_vocab, g.K);
     WIS_RET(launch_gemv(st, g));
     if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * (m->w8 ? 1 : 2); }
@@ -959,22 +975,35 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
   hipStream_t st = ctx_stream(c);
   if (flags & GV_QKV) { set_error("wis_op_gemv: flag 16 is internal"); return WIS_E_ARG; }
   const int Npad = cdiv(N, gemv_rows_for(N, K)) * gemv_rows_for(N, K);
-  const bool w8 = flags & 32;
+  const bool w8 = flags & 32, ln = flags & GV_LN;
   flags &= ~32;
-  f16* wp = nullptr; float* wsc = nullptr;
-  WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Npad * K * 2));
-  if (w8) WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wsc), (size_t)Npad * 4));
-  const int rows = gemv_rows_for(N, K);
-  int rc = w8 ? launch_pack_gemv8(st, reinterpret_cast<const f16*>(W), reinterpret_cast<unsigned char*>(wp), wsc, N, Npad, K, 0, 1.f)
-              : launch_pack_gemv(st, reinterpret_cast<const f16*>(W), wp, N, Npad, K, 0, 1.f, rows);
-  if (!rc) {
+  if (ln && (!gamma || !beta)) { set_error("wis_op_gemv: flag 8 needs gamma and beta"); return WIS_E_ARG; }
+  // the same preparation the model loader does: optional LayerNorm fold into a private copy of W / bias, then packing
+  f16 *wp = nullptr, *wtmp = nullptr, *xn = nullptr; float *wsc = nullptr, *b2 = nullptr, *cs = nullptr;
+  int rc = WIS_OK;
+  do {
+    if (hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Npad * K * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&wtmp), (size_t)N * K * 2) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&b2), (size_t)Npad * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&cs), (size_t)Npad * 4) != hipSuccess ||
+        (w8 && hipMalloc(reinterpret_cast<void**>(&wsc), (size_t)Npad * 4) != hipSuccess) ||
+        (ln && M > 8 && hipMalloc(reinterpret_cast<void**>(&xn), (size_t)M * K * 2) != hipSuccess)) { set_error("wis_op_gemv: out of device memory"); rc = WIS_E_NOMEM; break; }
+    hipMemcpyAsync(wtmp, W, (size_t)N * K * 2, hipMemcpyDeviceToDevice, st);
+    hipMemsetAsync(b2, 0, (size_t)Npad * 4, st); hipMemsetAsync(cs, 0, (size_t)Npad * 4, st);
+    if (bias) hipMemcpyAsync(b2, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, st);
+    if (ln && (rc = launch_fold_ln(st, wtmp, gamma, beta, b2, cs, N, K, 0, 1.f))) break;
+    const int rows = gemv_rows_for(N, K);
+    rc = w8 ? launch_pack_gemv8(st, wtmp, reinterpret_cast<unsigned char*>(wp), wsc, N, Npad, K, 0, 1.f) : launch_pack_gemv(st, wtmp, wp, N, Npad, K, 0, 1.f, rows);
+    if (rc) break;
+    if (w8 && ln && (rc = launch_csum8(st, wtmp, wsc, cs, N, K, 0, 1.f))) break;
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = x; g.gamma = gamma; g.beta = beta; g.Wp = wp; g.wscale = wsc; g.bias = bias; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags; g.rows = rows;
+    g.x = x; g.csum = ln ? cs : nullptr; g.Wp = wp; g.wscale = wsc; g.bias = (bias || ln) ? b2 : nullptr; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags; g.rows = rows;
+    if (ln && M > 8) {      // the product's split path (launch_ln_gemv): plain normalisation, then f16 activations against the folded weights
+      if ((rc = launch_layernorm(st, reinterpret_cast<const float*>(x), nullptr, nullptr, xn, M, K))) break;
+      g.x = xn; g.csum = nullptr; g.flags &= ~GV_LN;
+    }
     rc = launch_gemv(st, g);
-  }
+  } while (0);
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(wp);
-  if (wsc) hipFree(wsc);
+  hipFree(wp); hipFree(wtmp); hipFree(b2); hipFree(cs); hipFree(wsc); hipFree(xn);
   if (rc) return rc;
   if (e != hipSuccess) { set_error("wis_op_gemv: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;

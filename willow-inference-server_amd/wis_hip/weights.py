@@ -241,17 +241,38 @@ def quantize_rows(w):
     return q, scale
 
 
+def quantize_folded(w, gamma):
+    """What the engine stores for a projection that follows a LayerNorm: the gamma-folded matrix f16(W * gamma) quantised per
+    row; returned as the equivalent UNFOLDED float32 matrix (divided by gamma again) so that an oracle applying gamma itself
+    reproduces it."""
+    g = np.asarray(gamma, np.float32)
+    wg = (np.asarray(w, np.float32) * g[None, :]).astype(np.float16)
+    q, sc = quantize_rows(wg)
+    deq = q.astype(np.float32) * sc[:, None]
+    safe = np.where(g != 0, g, np.float32(1.0))
+    return np.where(g[None, :] != 0, deq / safe[None, :], np.float32(0.0)).astype(np.float32)
+
+
 def quantize_decoder_weights(weights):
     """name -> array dict in which every decoder matrix the engine stores as int8 under compute_type="int8_float16" (the six
-    linears of each decoder layer and the vocabulary projection) is replaced by its float32 de-quantised value; the embedding
+    linears of each decoder layer and the vocabulary projection) is replaced by its float32 de-quantised value - the matrices
+    that follow a LayerNorm (QKV, cross-Q, FFN1, the projection) as the engine quantises them, gamma-folded; the embedding
     LOOKUP table, the cross K/V projection and the whole encoder stay f16, exactly as in the engine."""
     out = dict(weights)
+    ln_of = {"self_attention/linear_0": "self_attention/layer_norm", "attention/linear_0": "attention/layer_norm", "ffn/linear_0": "ffn/layer_norm"}
     for name in list(weights):
-        if name.startswith("decoder/layer_") and name.endswith("/weight") and any(name.endswith(l + "/weight") for l in DECODER_LINEARS):
+        if not (name.startswith("decoder/layer_") and name.endswith("/weight")):
+            continue
+        lin = next((l for l in DECODER_LINEARS if name.endswith(l + "/weight")), None)
+        if lin is None:
+            continue
+        if lin in ln_of:
+            gamma = weights[name[:-len(lin + "/weight")] + ln_of[lin] + "/gamma"]
+            out[name] = quantize_folded(weights[name], gamma)
+        else:
             q, sc = quantize_rows(weights[name])
             out[name] = q.astype(np.float32) * sc[:, None]
-    q, sc = quantize_rows(weights["decoder/embeddings/weight"])
-    out["decoder/projection/weight"] = q.astype(np.float32) * sc[:, None]
+    out["decoder/projection/weight"] = quantize_folded(weights["decoder/embeddings/weight"], weights["decoder/layer_norm/gamma"])
     return out
 
 
