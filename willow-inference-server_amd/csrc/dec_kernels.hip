@@ -358,6 +358,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
   }
   stamp(pf, 4);
+  // epilogue operands (bias, folded column sums, row scales, residual, KV-cache row): requested NOW - every weight fragment has
+  // been consumed, so they cannot hold up the in-order vmcnt queue - and covered by the reductions and the barrier below
+  // (requested at kernel start they delayed the activation / weight loads and cost more than they saved)
+  const bool ep_act = tid < MB * 64;
+  const int ep_m = (tid >> 6) * 16 + (lane & 15), ep_n = rows * nt + 4 * (lane >> 4);
+  const bool ep_ok = ep_act && ep_m < M && ep_n < p.N && 4 * (lane >> 4) < rows;
+  float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+  int ep_slot = 0, ep_pos = 0;
+  if (ep_ok) {
+    if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
+    if (fast) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);
+    if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);
+    if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }
+    else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n);
+  }
   if (fast) {   // LayerNorm statistics of the folded form: reduced here, behind the MFMAs, published with the accumulators
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -379,9 +394,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
       const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + mb) * 64 + ln) * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    const int m = mb * 16 + (ln & 15), n = rows * nt + 4 * (ln >> 4);
-    if (m < M && n < p.N && 4 * (ln >> 4) < rows) {
-      if (W8) { const float4 sc = *reinterpret_cast<const float4*>(p.wscale + n); s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w; }
+    const int m = ep_m, n = ep_n;
+    if (ep_ok) {
+      if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
       if (fast) {   // y = rs * (W' x - mu * c) [+ b' below]
         const int r = m < RMAX ? m : RMAX - 1;
         const float invK = 1.0f / (float)K;
@@ -392,17 +407,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
         for (int q = 1; q < RMAX; ++q) shift = (r == q) ? cshift[q] : shift;
         const float mu = shift + A;
         const float rs = 1.0f / sqrtf(fmaxf(Bq - A * A, 0.f) + 1e-5f);
-        const float4 cs = *reinterpret_cast<const float4*>(p.csum + n);
-        s.x = rs * (s.x - mu * cs.x); s.y = rs * (s.y - mu * cs.y); s.z = rs * (s.z - mu * cs.z); s.w = rs * (s.w - mu * cs.w);
+        s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
       }
-      if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
+      s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
       if (p.flags & GV_QKV) {
         const int d = p.d;
         if (n < d) {
           *reinterpret_cast<float4*>(p.q + (size_t)m * d + n) = s;
         } else {
           const bool isk = n < 2 * d;
-          f16* dst = (isk ? p.kc : p.vc) + ((size_t)p.slot[m] * p.ctx + p.pos[m]) * d + (n - (isk ? d : 2 * d));
+          f16* dst = (isk ? p.kc : p.vc) + ((size_t)ep_slot * p.ctx + ep_pos) * d + (n - (isk ? d : 2 * d));
           const f16x4 o = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
           *reinterpret_cast<f16x4*>(dst) = o;
         }
@@ -410,8 +424,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
         if (p.flags & GV_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
         const size_t o = (size_t)m * p.N + n;
         if (p.flags & GV_RESID) {
-          float4* y = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o);
-          const float4 t = *y; *y = make_float4(t.x + s.x, t.y + s.y, t.z + s.z, t.w + s.w);
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(ep_res.x + s.x, ep_res.y + s.y, ep_res.z + s.z, ep_res.w + s.w);
         } else if (p.flags & GV_OUT_F32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = s;
         } else {
