@@ -846,9 +846,12 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
     const int nidx = lo + tid + 256 * i;
     float v = -INFINITY;
     if (nidx < hi) {
+      // all three streams are requested before the step counter has arrived (one round trip instead of two); the begin-of-
+      // sequence bias is applied by select
+      const float bb = bias_begin[nidx];
       v = row[nidx];
       if (bias_all) v += bias_all[nidx];
-      if (first) v += bias_begin[nidx];
+      if (first) v += bb;
       if (mask_eot && nidx == cfg.eot) v = -INFINITY;
       if (force_eot && nidx != cfg.eot) v = -INFINITY;
     }
