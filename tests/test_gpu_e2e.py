@@ -258,3 +258,15 @@ def test_int8_float16_compute_type(mels, lib):
     assert _check_generate(model, ref, mels, 5, 8) >= 1
     with pytest.raises(ValueError):
         ct2.Whisper("unused", weights=w, arch=a, compute_type="bfloat16")
+
+
+def test_roofline_tap_runs_at_every_row_count(tiny, lib):
+    """bench.py's roofline tap (wis_bench_weight_stream) at single-utterance and batched row counts: above 8 rows the LayerNorm
+    runs as its own launch, the tap must take the same route as dec_forward."""
+    import ctypes as C
+    from wis_hip import _lib
+    model, ref, w, a = tiny
+    for rows in (1, 5, 8, 20, 40):
+        ms, nl, nb = C.c_float(), C.c_int(), C.c_double()
+        _lib.check(lib.wis_bench_weight_stream(_handle(model), rows, 1, C.byref(ms), C.byref(nl), C.byref(nb)))
+        assert nl.value == 6 * a["n_layers"] + 1 and nb.value > 0 and ms.value > 0

@@ -902,14 +902,14 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
         g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.csum = t.cs; g.Wp = t.wp; g.wscale = t.sc; g.bias = t.b;
         g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
         g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-        WIS_RET(launch_gemv(st, g));
+        WIS_RET(launch_ln_gemv(m, st, g));   // (more than 8 rows: LayerNorm runs as its own launch, as in dec_forward)
         if (count) { ++launches; bytes += (double)t.N * t.K * (m->w8 ? 1 : 2); }
       }
     }
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = m->dx; g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(m->cfg.n_vocab, g.K);
-    WIS_RET(launch_gemv(st, g));
+    WIS_RET(launch_ln_gemv(m, st, g));   // (more than 8 rows: LayerNorm runs as its own launch, as in dec_forward)
     if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * (m->w8 ? 1 : 2); }
     return WIS_OK;
   };
