@@ -522,7 +522,7 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 // Logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul (decode rows own their slot, prefill rows share
 // the utterance's first slot).
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
-                                                           const int* __restrict__ anc, const int* __restrict__ pos,
+                                                           const int* __restrict__ pos,
                                                            f16* __restrict__ out, int d, int ctx, int rpu, int sstride, int rmul,
                                                            unsigned long long* prof) {
   __shared__ float red[4][64];
@@ -530,21 +530,22 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
   if (lane == 0) tl_begin(prof);
   stamp(pf, 0);
+  // the row's history lives in ITS OWN slot (kv_reorder_kernel made it so after the last beam step): the K / V addresses of the
+  // first 64 positions depend on nothing that has to be loaded, so q, the row's length and all of K and V travel in ONE round
+  // trip (positions >= len are fetched from valid memory and masked below)
   const int ls = (m / rpu) * sstride + (m % rpu) * rmul;
-  const int* arow = anc + (size_t)ls * ctx;
-  int a0[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a0[i] = arow[8 * i + pl];          // ctx >= 64: always in bounds; issued before len is known
   const int len = pos[m] + 1;
   const float4 q0 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c);
   const float4 q1 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c + 4);
   const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
   const int hoff = h * 64 + 8 * c;
+  const f16* krow = kc + (size_t)ls * ctx * d + hoff;
+  const f16* vrow = vc + (size_t)ls * ctx * d + hoff;
   u32x4 kr[8], vr[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const int p = 8 * i + pl; if (p < len) kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)a0[i] * ctx + p) * d + hoff); }
+  for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)(8 * i + pl) * d);      // ctx >= 64: in bounds
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const int p = 8 * i + pl; if (p < len) vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)a0[i] * ctx + p) * d + hoff); }
+  for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(8 * i + pl) * d);
   stamp(pf, 1);
   float m_run = -INFINITY, l_run = 0.f;
   float acc[8];
@@ -556,9 +557,8 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
       for (int i = 0; i < 8; ++i) {
         const int p = p0 + 8 * i + pl;
         if (p < len) {
-          const int ap = arow[p];
-          kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)ap * ctx + p) * d + hoff);
-          vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)ap * ctx + p) * d + hoff);
+          kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)p * d);
+          vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)p * d);
         }
       }
     }
@@ -610,10 +610,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   stamp(pf, 4);
   if (lane == 0) tl_end(prof);
 }
-int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
+int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof) {
   if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, anc, pos, out, d, ctx, rpu, sstride, rmul, prof);
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, out, d, ctx, rpu, sstride, rmul, prof);
   return WIS_OK;
 }
 
@@ -921,7 +921,6 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   __shared__ int nb_src[MAX_R]; __shared__ int nb_tok[MAX_R]; __shared__ float nb_cum[MAX_R];
   __shared__ int hyp_src[MAX_R]; __shared__ int hyp_slot[MAX_R]; __shared__ int hyp_n[MAX_R]; __shared__ int n_newhyp;
   __shared__ int s_finished;
-  __shared__ int sh_anc[MAX_R * 512];
   __shared__ int sh_alive[MAX_R * 256];
   const int b = blockIdx.x, lane = threadIdx.x;
   unsigned long long* pf = (b == 0 && lane == 0) ? prof : nullptr;
@@ -1040,11 +1039,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   __syncthreads();
 
   stamp(pf, 5);
-  // stage this utterance's token histories and ancestry rows, then write the permuted rows back
+  // stage this utterance's token histories, then write the permuted rows back (the KV rows follow in kv_reorder_kernel)
   const int hist = step;                 // tokens already in alive[]
   const int npos = P - 1 + step + 1;     // cache positions valid after this step
   for (int i = lane; i < k * hist; i += 64) { const int j = i / hist, t = i - j * hist; sh_alive[j * 256 + t] = bs.alive[(size_t)(r0 + j) * cfg.max_new + t]; }
-  for (int i = lane; i < k * npos; i += 64) { const int j = i / npos, p = i - j * npos; sh_anc[j * 512 + p] = bs.anc[(size_t)(r0 + j) * ctx + p]; }
   __syncthreads();
   stamp(pf, 6);
   // finished hypotheses of this step
@@ -1084,11 +1082,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
     const int org = cand_org[nb_src[j]];
     int* al = bs.alive + (size_t)(r0 + j) * cfg.max_new;
     for (int t = lane; t < hist; t += 64) al[t] = sh_alive[org * 256 + t];
-    int* an = bs.anc + (size_t)(r0 + j) * ctx;
-    for (int p = lane; p < npos; p += 64) an[p] = sh_anc[org * 512 + p];
     if (lane == 0) {
       al[hist] = nb_tok[j];
-      if (npos < ctx) an[npos] = r0 + j;           // the next step writes its own K/V at position npos
+      // KV slot this beam continues from: the merged prefill + first step left the prompt's K/V in the utterance's first slot
+      bs.parent[r0 + j] = (step == 0) ? r0 : r0 + org;
       bs.cum[r0 + j] = nb_cum[j];
       rm.tok[r0 + j] = nb_tok[j];
       rm.pos[r0 + j] = npos;
@@ -1102,6 +1099,43 @@ int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, c
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof) {
   if (cfg.beam > MAX_R || cfg.n_cand > MAX_CAND || cfg.max_new > 256 || ctx > 512 || cfg.n_vocab > (1 << 20)) { set_error("beam_step: config out of range"); return WIS_E_UNSUPPORTED; }
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
+  return WIS_OK;
+}
+
+// =======================================================================================
+// Beam reorder of the self-attention KV cache (CTranslate2 gathers its cache tensors by beam_origin after every step): slot j of
+// an utterance becomes a copy of slot parent[j] for every layer and every valid position.  grid (8 position slices, 2 L, B);
+// thread = one 16-byte column chunk of ALL the utterance's rows at a position: it loads the k parents' chunks, waits, then
+// stores - reads and writes of an address meet only inside one thread, so the permutation is safe in place.  Moving
+// beam x positions x d bytes per step (16 MB at position 20, large-v2) buys the self-attention kernel a K/V address that
+// depends on nothing it has to load: one fabric round trip per layer instead of two.
+__global__ __launch_bounds__(256) void kv_reorder_kernel(f16* __restrict__ kc, f16* __restrict__ vc, size_t lstride, const int* __restrict__ parent,
+                                                         const int* __restrict__ step_u, const int* __restrict__ done, int k, int P, int ctx, int d) {
+  const int b = blockIdx.z, lk = blockIdx.y, tid = threadIdx.x;
+  if (k < 2 || done[b]) return;
+  const int r0 = b * k;
+  int par[MAX_R]; bool ident = true;
+#pragma unroll
+  for (int j = 0; j < MAX_R; ++j) { par[j] = r0 + j; if (j < k) { par[j] = parent[r0 + j]; ident = ident && par[j] == r0 + j; } }
+  if (ident) return;
+  const int npos = P - 1 + step_u[b];           // beam_step already counted this step: positions 0 .. npos-1 hold history
+  f16* cache = ((lk & 1) ? vc : kc) + (size_t)(lk >> 1) * lstride;
+  const int c8 = d >> 3;
+  for (int p = blockIdx.x; p < npos; p += gridDim.x) {
+    for (int ch = tid; ch < c8; ch += 256) {
+      u32x4 v[MAX_R];
+#pragma unroll
+      for (int j = 0; j < MAX_R; ++j) if (j < k) v[j] = *reinterpret_cast<const u32x4*>(cache + ((size_t)par[j] * ctx + p) * d + ch * 8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every parent chunk is in registers before any row is overwritten
+#pragma unroll
+      for (int j = 0; j < MAX_R; ++j) if (j < k && par[j] != r0 + j) *reinterpret_cast<u32x4*>(cache + ((size_t)(r0 + j) * ctx + p) * d + ch * 8) = v[j];
+    }
+  }
+}
+int launch_kv_reorder(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const BeamState& bs, int B, int beam, int P, int ctx, int d) {
+  if (beam < 2) return WIS_OK;        // greedy: a row always continues itself
+  if (beam > MAX_R) { set_error("kv_reorder: beam %d > %d", beam, MAX_R); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(kv_reorder_kernel, dim3(8, 2 * L, B), dim3(256), 0, st, kc, vc, layer_stride, bs.parent, bs.step_u, bs.done, beam, P, ctx, d);
   return WIS_OK;
 }
 

@@ -65,7 +65,7 @@ int gemv_rows_for(int N, int K);     // tile height used for an [N][K] decoder m
 
 int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d);
 // logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
-int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* anc, const int* pos, f16* out,
+int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr);
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
@@ -87,13 +87,15 @@ struct BeamState {
   int* n_hyp;       // [B]
   float* cum;       // [B*beam] cumulative log-prob of live beams
   int* alive;       // [B*beam][max_new] token history of live beams
-  int* anc;         // [B*beam][ctx] ancestry: physical slot holding position p of this logical slot
+  int* parent;      // [B*beam] KV slot each live beam descends from after the last beam step (kv_reorder_kernel applies it)
   float* hyp_score; // [B][max_hyp] raw cumulative score
   int* hyp_len;     // [B][max_hyp]
   int* hyp_tok;     // [B][max_hyp][max_new]
   int* all_done;    // [1] (also mirrored to pinned host memory by the driver)
   int* out_ids; int* out_len; float* out_score;   // final result [B][max_new], [B], [B]
 };
+// after a beam step: every live beam's KV rows (all layers, positions < P - 1 + step) become a copy of its parent's
+int launch_kv_reorder(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const BeamState& bs, int B, int beam, int P, int ctx, int d);
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof = nullptr);
 // language detection: softmax over lang_ids of the row's logits

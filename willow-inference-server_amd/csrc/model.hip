@@ -6,7 +6,7 @@
 // converted ONCE into the layouts the kernels stream (row-major f16 [N][K] for the encoder MFMA
 // GEMM, MFMA-fragment-packed for the decoder's skinny GEMMs), all activations / KV caches live in
 // HBM for the handle's lifetime, and a decode step (~260 kernels) is captured once into a HIP
-// graph and replayed: every step-dependent value (positions, tokens, beam ancestry, scores)
+// graph and replayed: every step-dependent value (positions, tokens, beam parents, scores)
 // lives in device memory, so the host only launches graphs and polls a done counter.
 #include <math.h>
 #include <stdlib.h>
@@ -110,7 +110,8 @@ struct wis_model {
   f16 *img, *c1, *xn, *qk, *vt, *ao, *hbuf, *mem;
   float* x; float* skbuf;
   std::vector<f16*> kx, vx;             // per decoder layer cross K / V
-  std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d]
+  std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d] (views into kc_all / vc_all)
+  f16 *kc_all = nullptr, *vc_all = nullptr; size_t kv_layer_stride = 0;
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
   RowMeta rm; BeamState bs;
@@ -340,12 +341,15 @@ int alloc_buffers(wis_model* m) {
   WIS_HIP_CHECK(hipMemsetAsync(m->c1, 0, (size_t)Bm * 3002 * d * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->vt, 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
   m->kx.resize(L); m->vx.resize(L); m->kc.resize(L); m->vc.resize(L);
+  m->kv_layer_stride = (size_t)slots * ctx * d;
+  WIS_RET(dalloc(m, &m->kc_all, m->kv_layer_stride * L));
+  WIS_RET(dalloc(m, &m->vc_all, m->kv_layer_stride * L));
   for (int l = 0; l < L; ++l) {
     WIS_RET(dalloc(m, &m->kx[l], (size_t)Bm * H * 8 * T * 8));
     WIS_RET(dalloc(m, &m->vx[l], (size_t)Bm * H * 64 * m->Tpad));
     WIS_HIP_CHECK(hipMemsetAsync(m->vx[l], 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
-    WIS_RET(dalloc(m, &m->kc[l], (size_t)slots * ctx * d));
-    WIS_RET(dalloc(m, &m->vc[l], (size_t)slots * ctx * d));
+    m->kc[l] = m->kc_all + (size_t)l * slots * ctx * d;     // one block per cache: kv_reorder_kernel walks the layers by stride
+    m->vc[l] = m->vc_all + (size_t)l * slots * ctx * d;
   }
   WIS_RET(dalloc(m, &m->dx, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dq, (size_t)MAX_ROWS * d));
@@ -362,7 +366,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.step_u, Bm)); WIS_RET(dalloc(m, &m->bs.done, Bm)); WIS_RET(dalloc(m, &m->bs.n_hyp, Bm));
   WIS_RET(dalloc(m, &m->bs.cum, slots));
   WIS_RET(dalloc(m, &m->bs.alive, (size_t)slots * max_new));
-  WIS_RET(dalloc(m, &m->bs.anc, (size_t)slots * ctx));
+  WIS_RET(dalloc(m, &m->bs.parent, (size_t)slots));
   WIS_RET(dalloc(m, &m->bs.hyp_score, (size_t)Bm * max_hyp)); WIS_RET(dalloc(m, &m->bs.hyp_len, (size_t)Bm * max_hyp));
   WIS_RET(dalloc(m, &m->bs.hyp_tok, (size_t)Bm * max_hyp * max_new));
   WIS_RET(dalloc(m, &m->bs.all_done, 4));
@@ -469,7 +473,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.prof = pr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->bs.anc, m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.wscale = w.s_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
@@ -625,13 +629,8 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   // ---- decode state
   const int Mrows = B * beam;
   {
-    // ancestry: every prompt position (0..P-1) of every beam lives in the utterance's first slot; later positions are own
-    std::vector<int> anc((size_t)Mrows * ctx);
-    for (int r = 0; r < Mrows; ++r)
-      for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = (p < P) ? (r / beam) * beam : r;
     std::vector<float> cum(Mrows);
     for (int r = 0; r < Mrows; ++r) cum[r] = (r % beam == 0) ? 0.f : -INFINITY;   // CT2 GPU path: beams tiled up front, scores [0, -inf, ...]
-    WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, st));
     WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, st));
     WIS_HIP_CHECK(hipMemsetAsync(m->bs.step_u, 0, (size_t)B * 4, st));
     WIS_HIP_CHECK(hipMemsetAsync(m->bs.done, 0, (size_t)B * 4, st));
@@ -661,6 +660,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
+    WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
 
@@ -668,6 +668,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     WIS_RET(dec_forward(m, Mrows, beam, B, true, beam, 1));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, beam, 1, 0));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
+    WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
     return WIS_OK;
   };
   hipGraphExec_t gexec = nullptr;
@@ -741,15 +742,9 @@ int wis_last_timing(const wis_model_t* m, wis_timing_t* t) {
   *t = m->timing; return WIS_OK;
 }
 
-// rows (b): R = 1, identity ancestry
+// rows (b): R = 1, every row reads its own KV slot
 static int single_row_setup(wis_model* m, int B, const std::vector<int>& tok, int pos) {
   const int ctx = m->cfg.n_text_ctx;
-  if (pos == 0) {
-    std::vector<int> anc((size_t)B * ctx);
-    for (int r = 0; r < B; ++r) for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = r;
-    WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, m->st));
-    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
-  }
   std::vector<int> ps(B, pos), slot(B), ls(B);
   for (int r = 0; r < B; ++r) { slot[r] = r; ls[r] = r; }
   return upload_rows(m, tok, ps, slot, ls);
@@ -812,9 +807,6 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
   WIS_RET(check_batch(m, B, beam));
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx;
   if (pos < 0 || pos >= ctx) { set_error("bad pos"); return WIS_E_ARG; }
-  std::vector<int> anc((size_t)Mrows * ctx);
-  for (int r = 0; r < Mrows; ++r) for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = r;
-  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, m->st));
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
   std::vector<int> tok(Mrows, 100), ps(Mrows, pos), slot(Mrows), ls(Mrows);
   for (int r = 0; r < Mrows; ++r) { slot[r] = r; ls[r] = r; }
@@ -848,9 +840,6 @@ int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, 
   WIS_RET(check_batch(m, B, beam));
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx, nk = m->cfg.n_dec_layers * 8;
   if (pos < 0 || pos >= ctx || n_out < nk) { set_error("wis_debug_timeline: bad pos / out size (need %d rows)", nk); return WIS_E_ARG; }
-  std::vector<int> anc((size_t)Mrows * ctx);
-  for (int r = 0; r < Mrows; ++r) for (int p = 0; p < ctx; ++p) anc[(size_t)r * ctx + p] = r;
-  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, m->st));
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
   std::vector<int> tok(Mrows, 100), ps(Mrows, pos), slot(Mrows), ls(Mrows);
   for (int r = 0; r < Mrows; ++r) { slot[r] = r; ls[r] = r; }
