@@ -10,8 +10,8 @@
 //    from LDS); 4 waves split K, partial accumulators meet in LDS, the epilogue (bias, GELU,
 //    fp32 residual, KV-cache scatter) is fused.  The pre-LN LayerNorm is fused into the
 //    prologue: every workgroup re-normalises the (tiny, L2-resident) M x d activation itself.
-//  * self-attention KV cache is never reordered: an ancestry table (anc[slot][pos] -> physical
-//    slot) is gathered per step instead of the K/V tensors.
+//  * self-attention KV cache: after every beam step the rows of each live beam are rewritten in place from its parent's
+//    (kv_reorder_kernel), so the attention kernel's K/V addresses depend on nothing it has to load.
 //  * cross-attention K is stored [H][dh/8][T][8] and V transposed [H][64][Tpad] so that both are MFMA A fragments read with
 //    16-byte loads; the `beam` query rows of an utterance are folded into one pass over the utterance's K/V (shared per
 //    utterance, never tiled per beam); the T axis is split into 256-key chunks across workgroups with an in-launch,

@@ -36,7 +36,7 @@ struct RowMeta {
   int* tok;     // input token of the row
   int* pos;     // text position of the row (KV-cache index it writes)
   int* slot;    // physical KV slot the row writes
-  int* lslot;   // logical slot whose ancestry table the row reads
+  int* lslot;   // logical KV slot of the row (prefill rows of an utterance share one)
 };
 
 // skinny GEMM (decoder): y = epi(LN?(x) . Wp^T + b), Wp packed in MFMA 16x16x32 A-fragment order
