@@ -8,8 +8,8 @@
 //    so every wave-level load is ONE fully coalesced 1 KiB global_load_dwordx4 that feeds
 //    v_mfma_f32_16x16x32_f16 directly (rows of the M<=16 activation block are the B operand, read
 //    from LDS); 4 waves split K, partial accumulators meet in LDS, the epilogue (bias, GELU,
-//    fp32 residual, KV-cache scatter) is fused.  The pre-LN LayerNorm is fused into the
-//    prologue: every workgroup re-normalises the (tiny, L2-resident) M x d activation itself.
+//    fp32 residual, KV-cache scatter) is fused.  The pre-LN LayerNorm is FOLDED into the
+//    projection's weights (fold_ln_kernel): the kernel multiplies the raw rows and applies mean / rstd in its epilogue.
 //  * self-attention KV cache: after every beam step the rows of each live beam are rewritten in place from its parent's
 //    (kv_reorder_kernel), so the attention kernel's K/V addresses depend on nothing it has to load.
 //  * cross-attention K is stored [H][dh/8][T][8] and V transposed [H][64][Tpad] so that both are MFMA A fragments read with
