@@ -187,7 +187,8 @@ int wis_op_gemm(int device, const void* A_f16, int lda, const void* W_f16, const
 /* y f16 [M][d] = LayerNorm(x f32 [M][d]) * gamma + beta, eps 1e-5 */
 int wis_op_layernorm(int device, const float* x, const float* gamma, const float* beta,
                      void* y_f16, int M, int d);
-/* non-causal MHA over T keys: qk f16 [B*T][2d] (Q pre-scaled | K), vt f16 [B][H][64][Tpad],
+/* non-causal MHA over T keys: qk f16 [B*T][2d] (Q pre-scaled | K), vt f16 [B][H][64][Tpad] with key t stored at
+ * (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1) (bits 2, 3 swapped inside groups of 16: the P.V MFMA fragment order),
  * out f16 [B*T][d] */
 int wis_op_enc_attention(int device, const void* qk_f16, const void* vt_f16, void* out_f16,
                          int B, int T, int Tpad, int H);

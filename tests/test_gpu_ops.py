@@ -137,7 +137,9 @@ def test_enc_attention(lib, B, T, H):
     v = (rng.standard_normal((B, T, H, 64))).astype(np.float16)
     q[0, 3, 0] *= 6.0     # a spiky query row exercises the online-softmax rescale
     qk = np.concatenate([q.reshape(B, T, d), k.reshape(B, T, d)], axis=2).reshape(B * T, 2 * d)
-    vt = np.zeros((B, H, 64, Tpad), np.float16); vt[:, :, :, :T] = v.transpose(0, 2, 3, 1)
+    # V^T image as the encoder's QKV epilogue writes it: keys in groups of 16 with bits 2 and 3 of the index swapped
+    tt = np.arange(T); tp = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)
+    vt = np.zeros((B, H, 64, Tpad), np.float16); vt[:, :, :, tp] = v.transpose(0, 2, 3, 1)
     s = np.einsum("bqhd,bkhd->bhqk", q.astype(np.float64), k.astype(np.float64))
     p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
     ref = np.einsum("bhqk,bkhd->bqhd", p, v.astype(np.float64)).reshape(B * T, d)

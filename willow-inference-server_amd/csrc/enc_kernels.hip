@@ -259,7 +259,11 @@ struct EpiQKV {
     v += ld4(bias + n);
     if (n < 2 * d) { st4h(qk + (size_t)m * 2 * d + n, v); return; }
     const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
-    f16* o = vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + t;
+    // keys are stored with bits 2 and 3 of their index swapped inside every group of 16: the 8 keys a lane of the attention
+    // kernel feeds to one P.V MFMA step (16 s + 8 (j >> 2) + 4 hi + (j & 3), the order its score accumulators come in) are then
+    // contiguous - one conflict-free ds_read_b128 instead of two bank-conflicting 8-byte reads
+    const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+    f16* o = vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
   }
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
     }
     l_run += rs; m_run = m_new;
     // P fragments straight from the accumulators: k-step s of 16 keys <-> S-tile s>>1, regs 8(s&1)..+7;
-    // slot j of half `hi` is key 16s + 8(j>>2) + 4hi + (j&3)  (same permutation used for V^T below)
+    // slot j of half `hi` is key 16s + 8(j>>2) + 4hi + (j&3)  (V^T is stored in exactly that order)
     f16x8 pf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -449,10 +453,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const f16* vr = &sV[cur][(dt * 32 + l31) * ASTR + 16 * s + 4 * hi];
-        const f16x4 v0 = *reinterpret_cast<const f16x4*>(vr);
-        const f16x4 v1 = *reinterpret_cast<const f16x4*>(vr + 8);
-        const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(&sV[cur][(dt * 32 + l31) * ASTR + 16 * s + 8 * hi]);   // (bit-swapped key order, see EpiQKV)
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[dt], 0, 0, 0);
       }
     if (kt + 1 < ntiles) { WIS_SSTORE(cur ^ 1) }
