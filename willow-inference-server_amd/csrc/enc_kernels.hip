@@ -271,10 +271,16 @@ struct EpiQKV {
 // cross-attention K/V projection of the encoder memory for ONE decoder layer:
 //   K -> Kx f16 [B][H][8][T][8]    (16-byte dh-groups contiguous along T = the MFMA A-fragment rows of the decode kernel)
 //   V -> V^T f16 [B][H][64][Tpad]  (keys contiguous, zero padded to Tpad)
+// The projections of ALL decoder layers run as ONE GEMM over the concatenated weights [L * 2d][d] (7680 tiles for large-v2 at
+// B = 1: thirty full rounds of the chip, instead of 32 launches of 240 tiles): n -> (layer n / 2d, column n % 2d); a 128- or
+// 256-wide tile never straddles layers because 2d is a multiple of 256 for every Whisper size but tiny (768: multiple of 128
+// and of 256).
 struct EpiCrossKV {
-  const float* bias; f16* kx; f16* vt; int d; int T; int Tpad; int H;
-  __device__ void operator()(int m, int n, f32x4 v) const {
-    v += ld4(bias + n);
+  const float* bias; f16* kx; f16* vt; int d; int T; int Tpad; int H; int64_t kx_lstride, vt_lstride;
+  __device__ void operator()(int m, int n_all, f32x4 v) const {
+    v += ld4(bias + n_all);
+    const int l = n_all / (2 * d), n = n_all - l * 2 * d;
+    f16* kx = this->kx + l * kx_lstride; f16* vt = this->vt + l * vt_lstride;
     const int b = m / T, t = m - b * T;
     if (n < d) {
       const int h = n >> 6, dh = n & 63, g = dh >> 3, j = dh & 7;
@@ -333,8 +339,9 @@ int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, 
   EpiQKV e{bias, qk, vt, d, T, Tpad, H};
   return launch_gemm_t(st, p, e);
 }
-int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H) {
-  EpiCrossKV e{bias, kx, vt, d, T, Tpad, H};
+int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H, int64_t kx_lstride, int64_t vt_lstride) {
+  if (p.N % (2 * d)) { set_error("crosskv: N=%d is not a whole number of layers", p.N); return WIS_E_ARG; }
+  EpiCrossKV e{bias, kx, vt, d, T, Tpad, H, kx_lstride, vt_lstride};
   return launch_gemm_t(st, p, e);
 }
 

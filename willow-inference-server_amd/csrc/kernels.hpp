@@ -23,7 +23,7 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p, int splits, float* 
 int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C, int T);
 int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
 int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);
-int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H);
+int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H, int64_t kx_lstride, int64_t vt_lstride);
 int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H);
 
 // ---- decoder ---------------------------------------------------------------------------

@@ -112,6 +112,8 @@ struct wis_model {
   std::vector<f16*> kx, vx;             // per decoder layer cross K / V
   std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d] (views into kc_all / vc_all)
   f16 *kc_all = nullptr, *vc_all = nullptr; size_t kv_layer_stride = 0;
+  f16 *kx_all = nullptr, *vx_all = nullptr, *w_ckv_all = nullptr; float* b_ckv_all = nullptr;   // cross K/V: one block each, all layers
+  size_t kx_lstride = 0, vx_lstride = 0;
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
   RowMeta rm; BeamState bs;
@@ -179,13 +181,13 @@ struct Loader {
 
 int to_f32(wis_model* m, const Loader& L, const std::string& name, int64_t n, float** out, int64_t n_scale = 0, float scale = 1.f) {
   TensorSrc s; WIS_RET(L.get(name, n, 1, &s));
-  WIS_RET(dalloc(m, out, (size_t)n));
+  if (!*out) WIS_RET(dalloc(m, out, (size_t)n));          // *out preset: a view into a block the caller allocated
   hipLaunchKernelGGL(convert_kernel, dim3(blocks_for(n)), dim3(256), 0, m->st, s.p, s.f16, *out, 0, n, (int64_t)1, (int64_t)1, n_scale, scale);
   return WIS_OK;
 }
 int to_f16_mat(wis_model* m, const Loader& L, const std::string& name, int64_t rows, int64_t cols, f16** out, int64_t n_scale = 0, float scale = 1.f) {
   TensorSrc s; WIS_RET(L.get(name, rows, cols, &s));
-  WIS_RET(dalloc(m, out, (size_t)rows * cols));
+  if (!*out) WIS_RET(dalloc(m, out, (size_t)rows * cols));
   hipLaunchKernelGGL(convert_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, m->st, s.p, s.f16, *out, 1, rows, cols, cols, n_scale, scale);
   return WIS_OK;
 }
@@ -289,6 +291,8 @@ int load_weights(wis_model* m, const Loader& L) {
     if (hipMemsetAsync(m->b_proj, 0, ((size_t)V + 64) * 4, m->st) != hipSuccess) { set_error("memset failed"); rc = WIS_E_HIP; break; }
     if ((rc = to_packed(m, L, "decoder/embeddings/weight", V, d, &m->p_proj, tmp, 0, 1.f, &m->n_vocab_pad, &m->s_proj, m->dec_ln_g, m->dec_ln_b, m->b_proj, &m->c_proj))) break;
     m->dec.resize(c.n_dec_layers);
+    if ((rc = dalloc(m, &m->w_ckv_all, (size_t)c.n_dec_layers * 2 * d * d))) break;      // one [L * 2d][d] matrix: a single GEMM projects every layer
+    if ((rc = dalloc(m, &m->b_ckv_all, (size_t)c.n_dec_layers * 2 * d))) break;
     for (int l = 0; l < c.n_dec_layers && !rc; ++l) {
       const std::string p = "decoder/layer_" + std::to_string(l) + "/";
       DecLayerW& w = m->dec[l];
@@ -303,6 +307,7 @@ int load_weights(wis_model* m, const Loader& L) {
       if ((rc = to_f32(m, L, p + "attention/layer_norm/beta", d, &w.ln2_b))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_0/bias", d, &w.b_cq, d, qs))) break;
       if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs, nullptr, &w.s_cq, w.ln2_g, w.ln2_b, w.b_cq, &w.c_cq))) break;
+      w.w_ckv = m->w_ckv_all + (size_t)l * 2 * d * d; w.b_ckv = m->b_ckv_all + (size_t)l * 2 * d;
       if ((rc = to_f16_mat(m, L, p + "attention/linear_1/weight", 2 * d, d, &w.w_ckv))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_1/bias", 2 * d, &w.b_ckv))) break;
       if ((rc = to_packed(m, L, p + "attention/linear_2/weight", d, d, &w.p_cout, tmp, 0, 1.f, nullptr, &w.s_cout))) break;
@@ -344,10 +349,13 @@ int alloc_buffers(wis_model* m) {
   m->kv_layer_stride = (size_t)slots * ctx * d;
   WIS_RET(dalloc(m, &m->kc_all, m->kv_layer_stride * L));
   WIS_RET(dalloc(m, &m->vc_all, m->kv_layer_stride * L));
+  m->kx_lstride = (size_t)Bm * H * 8 * T * 8; m->vx_lstride = (size_t)Bm * H * 64 * m->Tpad;
+  WIS_RET(dalloc(m, &m->kx_all, m->kx_lstride * L));
+  WIS_RET(dalloc(m, &m->vx_all, m->vx_lstride * L));
+  WIS_HIP_CHECK(hipMemsetAsync(m->vx_all, 0, m->vx_lstride * L * 2, m->st));
   for (int l = 0; l < L; ++l) {
-    WIS_RET(dalloc(m, &m->kx[l], (size_t)Bm * H * 8 * T * 8));
-    WIS_RET(dalloc(m, &m->vx[l], (size_t)Bm * H * 64 * m->Tpad));
-    WIS_HIP_CHECK(hipMemsetAsync(m->vx[l], 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
+    m->kx[l] = m->kx_all + (size_t)l * m->kx_lstride;
+    m->vx[l] = m->vx_all + (size_t)l * m->vx_lstride;
     m->kc[l] = m->kc_all + (size_t)l * slots * ctx * d;     // one block per cache: kv_reorder_kernel walks the layers by stride
     m->vc[l] = m->vc_all + (size_t)l * slots * ctx * d;
   }
@@ -437,9 +445,9 @@ int run_encoder(wis_model* m, int B) {
 int run_cross_kv(wis_model* m, int B) {
   const wis_config_t& c = m->cfg;
   const int d = c.d_model, T = c.n_audio_ctx;
-  for (int l = 0; l < c.n_dec_layers; ++l)
-    WIS_RET(launch_gemm_crosskv(m->st, gemm_plain(m->mem, d, m->dec[l].w_ckv, B * T, 2 * d, d), m->dec[l].b_ckv, m->kx[l], m->vx[l], d, T, m->Tpad, c.n_heads));
-  return WIS_OK;
+  // every decoder layer's K/V projection of the encoder memory in one GEMM (weights, biases and outputs are single blocks)
+  return launch_gemm_crosskv(m->st, gemm_plain(m->mem, d, m->w_ckv_all, B * T, c.n_dec_layers * 2 * d, d), m->b_ckv_all, m->kx_all, m->vx_all, d, T, m->Tpad,
+                             c.n_heads, (int64_t)m->kx_lstride, (int64_t)m->vx_lstride);
 }
 
 // LayerNorm + skinny GEMM.  Up to 8 rows the LayerNorm is fused into the GEMM prologue (register resident); with more rows
