@@ -92,3 +92,29 @@ def test_loader_rejects_unsupported_geometry(tmp_path):
         W.load_hf_dir(str(tmp_path))
     with pytest.raises(FileNotFoundError):
         W.load_model_dir(str(tmp_path / "nope"))
+
+
+def test_int8_quantiser_restatement_properties():
+    """wis_hip.weights.quantize_rows / quantize_folded / quantize_decoder_weights (the numpy restatement of the engine's
+    int8_float16 quantiser that the parity tests feed to the oracle)."""
+    from wis_hip import weights as W
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((37, 96)) * 0.05).astype(np.float16)
+    w[5] = 0                                                    # all-zero row: scale 1, q 0
+    q, sc = W.quantize_rows(w)
+    assert q.dtype == np.int8 and sc.dtype == np.float32 and sc[5] == 1.0 and not q[5].any()
+    assert np.abs(q).max() == 127 and (np.abs(q).max(axis=1)[np.arange(37) != 5] == 127).all()     # every non-zero row uses the full range
+    deq = q.astype(np.float32) * sc[:, None]
+    assert np.abs(deq - w.astype(np.float32)).max() <= 0.5 * sc.max() * 1.0001
+    g = (1 + 0.2 * rng.standard_normal(96)).astype(np.float32); g[7] = 0
+    wf = W.quantize_folded(w, g)
+    # folded form: (W_eff * gamma) is exactly representable as q * scale of the f16(W * gamma) rows
+    wg = (w.astype(np.float32) * g[None, :]).astype(np.float16)
+    q2, sc2 = W.quantize_rows(wg)
+    assert np.allclose(wf * g[None, :], q2.astype(np.float32) * sc2[:, None], rtol=0, atol=1e-6) and not wf[:, 7].any()
+    ws = W.synthetic_weights("tiny", seed=3)
+    qd = W.quantize_decoder_weights(ws)
+    changed = {k for k in ws if k in qd and (qd[k].dtype != ws[k].dtype or not np.array_equal(qd[k], ws[k]))}
+    assert all(k.startswith("decoder/layer_") and k.endswith("/weight") for k in changed)
+    assert len(changed) == 6 * 4 and "decoder/projection/weight" in qd and "decoder/layer_0/attention/linear_1/weight" not in changed
+    assert np.array_equal(qd["decoder/embeddings/weight"], ws["decoder/embeddings/weight"])     # the lookup table stays f16

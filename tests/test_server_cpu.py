@@ -195,3 +195,54 @@ def test_datachannel_protocol_state_machine():
     assert out[3]["message"] == "ASR Audio Duration: 1000 ms" and out[4]["message"] == "ASR Speedup: 80x faster than realtime"
     assert dec(p.on_message(json.dumps({"type": "nope"})))[0]["message"] == 'unknown message type "nope"'
     assert dec(p.on_message(json.dumps({"type": "stop"})))[0]["type"] == "error"      # recorder was consumed
+
+
+def test_streaming_session_schedule_without_gpu():
+    """The window schedule of a streaming session (which windows are transcribed before stop(), what stop() merges) with the
+    model replaced by a deterministic stand-in: must equal the offline chunk_iter + LCS computation on the complete audio."""
+    from wis_hip import audio
+    from wis_hip.streaming import StreamingSession
+
+    def fake_ids(piece):                       # "transcript" of a window: a few ids derived from its content
+        q = np.round(np.abs(piece[::16000]) * 1000).astype(int) % 50000
+        return [int(v) for v in q]
+
+    class Sess(StreamingSession):
+        def __init__(self, models):
+            self.models = models
+            s = models.settings
+            self.model_name, self.task, self.beam_size = "tiny", "transcribe", s.beam_size
+            self.detect_language = self.force_language = None
+            self.fixed_new_tokens = 0
+            self._whisper = None
+            self._pcm = np.zeros(0, np.float32)
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+            self._lock, self._pool = threading.Lock(), ThreadPoolExecutor(max_workers=2)
+            self._windows, self._language, self._closed, self.eager_windows = {}, "en", False, 0
+            self.calls = []
+
+        def _window_tokens(self, piece, beam):
+            self.calls.append((piece.shape[0], beam))
+            return fake_ids(piece)
+
+    models = _FakeModels()
+    rng = np.random.default_rng(5)
+    pcm = rng.standard_normal(75 * 16000).astype(np.float32)
+    s = Sess(models)
+    for i in range(0, pcm.shape[0], 4000):
+        s.feed(pcm[i:i + 4000])
+    # 75 s: windows start every 14 s; complete 22 s windows: starts 0, 14, 28, 42 (42 + 22 <= 75) ; 56 s and 70 s windows are tails
+    assert s.eager_windows == 4 and all(n == audio.chunk_len and b == models.settings.long_beam_size for n, b in s.calls)
+    out = s.stop()
+    expect = audio.find_longest_common_sequence([(fake_ids(p), st) for p, st in audio.chunk_iter(pcm)], models.tokenizer)
+    assert out.tokens == [int(t) for t in expect] and out[5] == 75000
+    assert len(s.calls) == 6                   # the two tail windows were transcribed at stop(), nothing twice
+    # short recording: no eager work, one window, request beam below the long-audio threshold
+    s2 = Sess(models)
+    s2.feed((pcm[:5 * 16000] * 32768 * 0.01).astype("<i2").tobytes(), 2)
+    assert s2.buffered_ms == 5000 and s2.eager_windows == 0
+    out2 = s2.stop()
+    assert s2.calls == [(5 * 16000, models.settings.beam_size)] and len(out2.tokens) == 5
+    with pytest.raises(RuntimeError):
+        s2.feed(pcm[:10])
