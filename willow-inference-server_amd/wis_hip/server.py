@@ -14,7 +14,7 @@ audio"}`).  Differences, all deliberate:
   * speaker verification (`voice_auth`) is a different model family and out of scope -> HTTP 400.
 WebRTC (`/api/rtc/asr`), TTS, nginx auth and the static sites are not re-hosted (out of scope).
 
-    uvicorn --factory wis_hip.server:create_app --host 0.0.0.0 --port 19000
+    python -m wis_hip.server --host 0.0.0.0 --port 19000        (or: uvicorn --factory wis_hip.server:create_app ...)
 """
 import asyncio
 import io
@@ -176,3 +176,20 @@ def create_app(models=None, settings=None, max_workers=None):
     app.state.wis = state
     app.state.pool = pool
     return app
+
+
+def main(argv=None):
+    """`python -m wis_hip.server [--host 0.0.0.0] [--port 19000]` - the reference serves on 19000 behind nginx
+    (entrypoint.sh:19-21, nginx.conf:99-103)."""
+    import argparse
+    import uvicorn
+    ap = argparse.ArgumentParser(description="Willow Inference Server ASR endpoints over the MI355X HIP path")
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=19000)
+    ap.add_argument("--log-level", default=os.environ.get("LOG_LEVEL", "info"))
+    args = ap.parse_args(argv)
+    uvicorn.run(create_app(), host=args.host, port=args.port, log_level=args.log_level)
+
+
+if __name__ == "__main__":
+    main()
