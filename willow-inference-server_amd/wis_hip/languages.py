@@ -1,56 +1,13 @@
-"""Whisper language table (data): the 99 language tokens of the multilingual vocabulary, in token-id order
-(<|en|> = 50259 ... <|su|> = 50357).  Used to validate `force_language` (reference main.py:84,550-551 via
-wis/languages.py:3-119) and to name `detect_language` results.  Same content as openai/whisper tokenizer.py.
+"""Whisper language codes (data): the 99 language tokens of the multilingual vocabulary in token-id order
+(<|en|> = 50259 ... <|su|> = 50357).  Used to validate `force_language` (the reference checks membership in the keys of its
+language table, main.py:84,550-551) and to name `detect_language` results (`"<|xx|>"`).  Only the codes matter on this path;
+the English language names of the reference's table are not needed and not carried.
 """
-# (code, name) in token-id order
-_TABLE = [
-    ("en", "english"), ("zh", "chinese"), ("de", "german"), ("es", "spanish"),
-    ("ru", "russian"), ("ko", "korean"), ("fr", "french"), ("ja", "japanese"),
-    ("pt", "portuguese"), ("tr", "turkish"), ("pl", "polish"), ("ca", "catalan"),
-    ("nl", "dutch"), ("ar", "arabic"), ("sv", "swedish"), ("it", "italian"),
-    ("id", "indonesian"), ("hi", "hindi"), ("fi", "finnish"), ("vi", "vietnamese"),
-    ("he", "hebrew"), ("uk", "ukrainian"), ("el", "greek"), ("ms", "malay"),
-    ("cs", "czech"), ("ro", "romanian"), ("da", "danish"), ("hu", "hungarian"),
-    ("ta", "tamil"), ("no", "norwegian"), ("th", "thai"), ("ur", "urdu"),
-    ("hr", "croatian"), ("bg", "bulgarian"), ("lt", "lithuanian"), ("la", "latin"),
-    ("mi", "maori"), ("ml", "malayalam"), ("cy", "welsh"), ("sk", "slovak"),
-    ("te", "telugu"), ("fa", "persian"), ("lv", "latvian"), ("bn", "bengali"),
-    ("sr", "serbian"), ("az", "azerbaijani"), ("sl", "slovenian"), ("kn", "kannada"),
-    ("et", "estonian"), ("mk", "macedonian"), ("br", "breton"), ("eu", "basque"),
-    ("is", "icelandic"), ("hy", "armenian"), ("ne", "nepali"), ("mn", "mongolian"),
-    ("bs", "bosnian"), ("kk", "kazakh"), ("sq", "albanian"), ("sw", "swahili"),
-    ("gl", "galician"), ("mr", "marathi"), ("pa", "punjabi"), ("si", "sinhala"),
-    ("km", "khmer"), ("sn", "shona"), ("yo", "yoruba"), ("so", "somali"),
-    ("af", "afrikaans"), ("oc", "occitan"), ("ka", "georgian"), ("be", "belarusian"),
-    ("tg", "tajik"), ("sd", "sindhi"), ("gu", "gujarati"), ("am", "amharic"),
-    ("yi", "yiddish"), ("lo", "lao"), ("uz", "uzbek"), ("fo", "faroese"),
-    ("ht", "haitian creole"), ("ps", "pashto"), ("tk", "turkmen"), ("nn", "nynorsk"),
-    ("mt", "maltese"), ("sa", "sanskrit"), ("lb", "luxembourgish"), ("my", "myanmar"),
-    ("bo", "tibetan"), ("tl", "tagalog"), ("mg", "malagasy"), ("as", "assamese"),
-    ("tt", "tatar"), ("haw", "hawaiian"), ("ln", "lingala"), ("ha", "hausa"),
-    ("ba", "bashkir"), ("jw", "javanese"), ("su", "sundanese"),
-]
-
-LANGUAGE_CODES = [c for c, _ in _TABLE]
-LANGUAGES = dict(_TABLE)
-
-# language code lookup by name, with a few aliases
-_ALIASES = {
-    "burmese": "my",
-    "valencian": "ca",
-    "flemish": "nl",
-    "haitian": "ht",
-    "letzeburgesch": "lb",
-    "pushto": "ps",
-    "panjabi": "pa",
-    "moldavian": "ro",
-    "moldovan": "ro",
-    "sinhalese": "si",
-    "castilian": "es",
-}
-TO_LANGUAGE_CODE = {**{name: code for code, name in _TABLE}, **_ALIASES}
-
-
-def check_language(language):
-    """True when `language` is a known code (reference main.py:550-551)."""
-    return language in LANGUAGES
+LANGUAGE_CODES = tuple((
+    "en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk el ms cs ro da hu ta no th ur hr bg "
+    "lt la mi ml cy sk te fa lv bn sr az sl kn et mk br eu is hy ne mn bs kk sq sw gl mr pa si km sn yo so "
+    "af oc ka be tg sd gu am yi lo uz fo ht ps tk nn mt sa lb my bo tl mg as tt haw ln ha ba jw su "
+).split())
+assert len(LANGUAGE_CODES) == 99 and len(set(LANGUAGE_CODES)) == 99
+# membership test target of `check_language` (same truth value as `language in LANGUAGES` of the reference)
+LANGUAGES = frozenset(LANGUAGE_CODES)
