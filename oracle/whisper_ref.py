@@ -14,7 +14,6 @@ the published algorithm:
     max_length 448, suppress_blank, suppress_tokens=[-1]) — restated from recall.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
-import math
 
 import numpy as np
 import torch

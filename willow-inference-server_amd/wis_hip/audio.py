@@ -10,7 +10,6 @@ semantics exactly (wis/audio.py:28-51, 119-134, 139-159).  `load_audio` replaces
 `librosa.load(audio_file, sr=16000, mono=True)` call of main.py:579.
 """
 import ctypes as C
-import io
 
 import numpy as np
 
