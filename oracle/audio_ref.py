@@ -97,18 +97,31 @@ def chunk_iter(inputs):
             yield chunk, (chunk.shape[0], left, right)
 
 
+def np123_eq_sum(a, b):
+    """np.sum(np.array(a) == np.array(b)) under numpy 1.23.5 (the reference's pin, requirements.txt:58): equal lengths ->
+    elementwise; one side of length 1 -> broadcast; any other mismatch -> scalar False (DeprecationWarning there, ValueError
+    from numpy 1.25 on) -> 0."""
+    la, lb = len(a), len(b)
+    if la == lb:
+        return int(sum(u == v for u, v in zip(a, b)))
+    if la == 1:
+        return int(sum(v == a[0] for v in b))
+    if lb == 1:
+        return int(sum(u == b[0] for u in a))
+    return 0
+
+
 def find_longest_common_sequence(sequences, special_ids):
     """wis/audio.py:139-159: stitch per-window token lists by the overlap length i maximising matches/i + i/10000
-    (matches > 1 required); strides are carried but ignored, as in the reference."""
+    (matches > 1 required); strides are carried but ignored, as in the reference.  The match count follows the reference's
+    numpy broadcasting (wis/audio.py:152): a running sequence of ONE token is compared against every head token."""
     special = set(special_ids)
     seq = [t for t in sequences[0][0] if t not in special]
     for new in sequences[1:]:
         new_seq = [t for t in new[0] if t not in special]
         index, best = 0, 0.0
         for i in range(1, len(new_seq) + 1):
-            # numpy semantics of the reference's `np.array(a[-i:]) == np.array(b[:i])` when lengths differ: scalar False
-            a, b = seq[-i:], new_seq[:i]
-            matches = sum(1 for u, v in zip(a, b) if u == v) if len(a) == len(b) else 0
+            matches = np123_eq_sum(seq[-i:], new_seq[:i])
             score = matches / i + i / 10000.0
             if matches > 1 and score > best:
                 index, best = i, score

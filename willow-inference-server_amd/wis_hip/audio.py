@@ -117,17 +117,32 @@ def chunk_iter(inputs):
         start += step
 
 
+def _overlap_hits(tail, head):
+    """`np.sum(np.array(tail) == np.array(head))` as the reference's pinned numpy 1.23.5 evaluates it
+    (wis/audio.py:152, requirements.txt:58): equal lengths compare element by element, a one-element side
+    BROADCASTS against the other (a running sequence holding a single token is compared with every
+    head token), any other length mismatch is the scalar False of the deprecated elementwise-comparison
+    fallback, i.e. 0 (newer numpy raises there instead)."""
+    if len(tail) == len(head):
+        return sum(1 for a, b in zip(tail, head) if a == b)
+    if len(tail) == 1:
+        return sum(1 for b in head if b == tail[0])
+    if len(head) == 1:
+        return sum(1 for a in tail if a == head[0])
+    return 0
+
+
 def find_longest_common_sequence(sequences, tokenizer):
     """Stitch per-window token id lists: for each next window choose the overlap length i that maximises
-    matches/i + i/10000 with matches > 1 and append the remainder.  `tokenizer.all_special_ids` are dropped first."""
+    matches/i + i/10000 with matches > 1 and append the remainder.  `tokenizer.all_special_ids` are dropped first.
+    Bit-exact with wis/audio.py:139-159 under its pinned numpy (see _overlap_hits)."""
     special = set(tokenizer.all_special_ids)
     merged = [t for t in sequences[0][0] if t not in special]
     for entry in sequences[1:]:
         cand = [t for t in entry[0] if t not in special]
         cut, best = 0, 0.0
         for i in range(1, len(cand) + 1):
-            tail, head = merged[-i:], cand[:i]
-            hits = sum(1 for a, b in zip(tail, head) if a == b) if len(tail) == len(head) else 0
+            hits = _overlap_hits(merged[-i:], cand[:i])
             score = hits / i + i / 10000.0
             if hits > 1 and score > best:
                 cut, best = i, score
