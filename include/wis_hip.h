@@ -199,6 +199,18 @@ int wis_op_enc_attention(int device, const void* qk_f16, const void* vt_f16, voi
 int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta,
                 const void* W_f16, const float* bias, void* y, int M, int N, int K, int flags);
 
+/* decoder self-attention of ONE new token per row over its cached history (the kernel inside every decode step):
+ * q f32 [M][d] (pre-scaled by 1/sqrt(64)), kc / vc f16 [slots][ctx][d] (row m reads positions 0..pos[m] of logical slot
+ * (m / rpu) * sstride + (m % rpu) * rmul), pos i32 [M] -> out f16 [M][d].  64 <= ctx <= 512, d = 64 H. */
+int wis_op_dec_self_attn(int device, const float* q, const void* kc_f16, const void* vc_f16, const int32_t* pos, void* out_f16,
+                         int M, int H, int ctx, int rpu, int sstride, int rmul);
+/* decoder cross-attention of the R (<= 16) query rows of each of B utterances over that utterance's T encoder keys, split into
+ * `chunks` key chunks (6 -> 256-key, 12 -> 128-key chunks for T = 1500) with the in-launch combine:
+ * q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8] (element (t, 8 c + j) of head h at ((h*8 + c)*T + t)*8 + j),
+ * vt f16 [B][H][64][Tpad] (V transposed, zero padded to Tpad = T rounded up to 64) -> out f16 [B*R][d]. */
+int wis_op_dec_cross_attn(int device, const float* q, const void* kx_f16, const void* vt_f16, void* out_f16,
+                          int B, int R, int H, int T, int chunks);
+
 #ifdef __cplusplus
 }
 #endif

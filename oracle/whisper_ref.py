@@ -174,7 +174,11 @@ class WhisperRef:
         non-EOT candidate beyond the first `beam`; the utterance ends when `round(beam*patience)` hypotheses exist
         (allow_early_exit additionally requires the top candidate to be finished and is only active for patience 1,
         length_penalty 0), or on the last step; hypotheses are ranked by score / len**length_penalty.
-        trace = per-step list of (top1-top2 candidate score margin) for the margin rule of SURVEY §8c."""
+        trace = per-step DECISION margin (see the comment at its computation: the k / k+1 survival boundary, every adjacent gap
+        of the top-(2k+1) list on steps that finish a hypothesis; greedy: top-1 / top-2), plus the gap between the two best
+        finished hypotheses.  The margin rule of SURVEY §8c is applied to min(trace): if it exceeds the engine's score error,
+        every decision of the search is forced and the ids must be identical.  `self.last_trace_full` keeps the stricter
+        all-adjacent-gaps variant of the same run."""
         if memory is None:
             memory = self.encode(np.asarray(mel, np.float32)[None])[0]
         memory = torch.as_tensor(np.asarray(memory, np.float32))
@@ -188,7 +192,7 @@ class WhisperRef:
         seqs = [list(prompt) for _ in range(k)]           # full decoder inputs per live beam
         cum = [0.0] + [float("-inf")] * (k - 1)           # GPU path: beams tiled up front
         hyps = []                                         # (raw_score, tokens)
-        trace = []
+        trace, trace_full = [], []
         ckv = self.cross_kv(memory)
         cache = [None] * self.L
         if P > 1:                                         # prime the self-attention cache with prompt[:-1]
@@ -204,7 +208,19 @@ class WhisperRef:
             vals, order = torch.sort(flat, descending=True, stable=True)
             cand_score = vals[:ncand].tolist()
             cand_flat = order[:ncand].tolist()
-            trace.append(cand_score[0] - cand_score[1] if ncand > 1 else float("inf"))
+            # margins of this step (finite candidates only; greedy: the top-1 / top-2 gap):
+            #   full = smallest gap between ADJACENT entries of the sorted list from top-1 / top-2 down to the (2k)-th / (2k+1)-th
+            #          boundary that decides membership of the candidate set;
+            #   dec  = smallest gap that can change a DECISION: the k-th / (k+1)-th boundary (which beams survive) - a swap of two
+            #          neighbours inside the top k only permutes the beam slots - unless a hypothesis finishes on this step (an EOT
+            #          among the top k, or the last step), where replacement candidates and hypothesis scores make every gap count.
+            head = [v for v in vals[:ncand + 1].tolist() if v > float("-inf")] if k > 1 else vals[:2].tolist()
+            gaps = [a - b for a, b in zip(head[:-1], head[1:])]
+            full = min(gaps) if gaps else float("inf")
+            finishing = (step + 1 >= max_new) or any((f % V) == self.eot for f in cand_flat[:k])
+            dec = full if (k == 1 or finishing or len(gaps) < k) else gaps[k - 1]
+            trace.append(dec)
+            trace_full.append(full)
             cand_word = [f % V for f in cand_flat]
             cand_org = [f // V for f in cand_flat]
             is_last = step + 1 >= max_new
@@ -236,6 +252,11 @@ class WhisperRef:
             return s / (len(toks) ** length_penalty) if length_penalty != 0 else s
         best = max(range(len(hyps)), key=lambda i: (norm(hyps[i]), -i))
         out = (hyps[best][1], norm(hyps[best]))
+        others = [norm(h) for i, h in enumerate(hyps) if i != best]
+        if others:                      # the final ranking of the finished hypotheses is a decision too
+            trace.append(norm(hyps[best]) - max(others))
+            trace_full.append(trace[-1])
+        self.last_trace_full = trace_full
         return out + (trace,) if return_trace else out
 
     @torch.no_grad()

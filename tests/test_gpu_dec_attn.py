@@ -1,0 +1,98 @@
+"""-m gpu: op-level parity of the decoder's two attention kernels through their C-ABI taps
+(wis_op_dec_self_attn / wis_op_dec_cross_attn, include/wis_hip.h) against fp64 numpy, at the BASELINE head counts
+(H = 20: large-v2, H = 16: medium) and at the history lengths the generate tests never reach: the online-softmax
+continuation beyond 64 cached positions (1, 63, 64, 65, 200, 447 - the reference allows 224 new tokens, main.py:687-692)
+and both cross-attention chunkings (6 x 256 keys, 12 x 128 keys).  Inputs are f16-representable (the kernels read f16 K/V
+and cast q to f16 only inside the cross-attention MFMA), so the bar is output rounding: 2e-3 absolute on O(1) values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _softmax(s):
+    s = s - s.max(axis=-1, keepdims=True)
+    e = np.exp(s)
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+@pytest.mark.parametrize("H", [20, 16])
+@pytest.mark.parametrize("rows,rpu,sstride,rmul", [(1, 1, 1, 0), (5, 5, 5, 1), (16, 8, 8, 1), (4, 4, 5, 0)])
+def test_dec_self_attn_vs_fp64(H, rows, rpu, sstride, rmul, lib):
+    """decode rows own their slot (rmul 1), prefill rows share the utterance's first slot (rmul 0, causal by position)."""
+    from wis_hip import _lib
+    d, ctx = 64 * H, 448
+    slots = 2 * max(sstride, rpu) + 2
+    rng = np.random.default_rng(100 * H + rows)
+    kc = (rng.standard_normal((slots, ctx, d)) * 0.5).astype(np.float16)
+    vc = rng.standard_normal((slots, ctx, d)).astype(np.float16)
+    d_kc, d_vc = _lib.DevBuf.from_numpy(kc), _lib.DevBuf.from_numpy(vc)
+    for hist in ([1, 63, 64, 65, 200, 447] if rmul else [3, 70]):
+        q = (rng.standard_normal((rows, d)) * 0.4).astype(np.float32)
+        if rmul:        # decode: every row at its own (different) history length around `hist`
+            pos = np.array([max(0, min(ctx - 1, hist - 1 - (r % 3))) for r in range(rows)], np.int32)
+        else:           # prefill: rows of an utterance at positions 0 .. rows-1 (+ offset)
+            pos = np.array([min(ctx - 1, hist - 1 + (r % rpu)) for r in range(rows)], np.int32)
+        d_q, d_pos = _lib.DevBuf.from_numpy(q), _lib.DevBuf.from_numpy(pos)
+        d_out = _lib.DevBuf(rows * d * 2)
+        for rep in range(2):
+            _lib.check(lib.wis_op_dec_self_attn(0, d_q.ptr, d_kc.ptr, d_vc.ptr, d_pos.ptr, d_out.ptr, rows, H, ctx, rpu, sstride, rmul))
+        got = d_out.to_numpy(np.float16, (rows, d)).astype(np.float64)
+        exp = np.zeros((rows, d))
+        for m in range(rows):
+            ls = (m // rpu) * sstride + (m % rpu) * rmul
+            n = int(pos[m]) + 1
+            for h in range(H):
+                sl = slice(64 * h, 64 * h + 64)
+                s = kc[ls, :n, sl].astype(np.float64) @ q[m, sl].astype(np.float64)
+                exp[m, sl] = _softmax(s[None])[0] @ vc[ls, :n, sl].astype(np.float64)
+        err = np.abs(got - exp).max()
+        print(f"self-attn H={H} rows={rows} hist~{hist}: max abs err {err:.2e}")
+        assert err <= 2e-3, (H, rows, hist, err)
+
+
+def _cross_layouts(K, V, T, Tpad):
+    """natural K, V f16 [B][T][d] -> the kernel's layouts (include/wis_hip.h): kx [B][H][8][T][8], vt [B][H][64][Tpad]."""
+    B, _, d = K.shape
+    H = d // 64
+    kx = np.ascontiguousarray(K.reshape(B, T, H, 8, 8).transpose(0, 2, 3, 1, 4))
+    vt = np.zeros((B, H, 64, Tpad), np.float16)
+    vt[:, :, :, :T] = V.reshape(B, T, H, 64).transpose(0, 2, 3, 1)
+    return kx, vt
+
+
+@pytest.mark.parametrize("H", [20, 16])
+@pytest.mark.parametrize("B,R", [(1, 1), (1, 5), (1, 16), (3, 5), (8, 5)])
+@pytest.mark.parametrize("chunks", [6, 12])
+def test_dec_cross_attn_vs_fp64(H, B, R, chunks, lib):
+    from wis_hip import _lib
+    d, T = 64 * H, 1500
+    Tpad = (T + 63) // 64 * 64
+    rng = np.random.default_rng(7 * H + 13 * B + R + chunks)
+    K = (rng.standard_normal((B, T, d)) * 0.6).astype(np.float16)
+    V = rng.standard_normal((B, T, d)).astype(np.float16)
+    # a few dominant keys per (utterance, head) so that the chunk maxima differ by a lot (exercises the partial combine)
+    for b in range(B):
+        for h in range(H):
+            K[b, (37 * h + 411 * b) % T, 64 * h:64 * h + 64] *= 4
+    q = (rng.standard_normal((B * R, d)) * 0.5).astype(np.float16).astype(np.float32)     # f16-representable: the kernel casts q
+    kx, vt = _cross_layouts(K, V, T, Tpad)
+    d_q, d_kx, d_vt = _lib.DevBuf.from_numpy(q), _lib.DevBuf.from_numpy(kx), _lib.DevBuf.from_numpy(vt)
+    d_out = _lib.DevBuf(B * R * d * 2)
+    outs = []
+    for rep in range(3):        # the in-launch ticket must re-arm itself
+        _lib.check(lib.wis_op_dec_cross_attn(0, d_q.ptr, d_kx.ptr, d_vt.ptr, d_out.ptr, B, R, H, T, chunks))
+        outs.append(d_out.to_numpy(np.float16, (B * R, d)).astype(np.float64))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    exp = np.zeros((B * R, d))
+    for b in range(B):
+        for h in range(H):
+            sl = slice(64 * h, 64 * h + 64)
+            s = q[b * R:(b + 1) * R, sl].astype(np.float64) @ K[b, :, sl].astype(np.float64).T
+            exp[b * R:(b + 1) * R, sl] = _softmax(s) @ V[b, :, sl].astype(np.float64)
+    err = np.abs(outs[0] - exp).max()
+    print(f"cross-attn H={H} B={B} R={R} chunks={chunks}: max abs err {err:.2e}")
+    # P is rounded to f16 before the P.V MFMA (relative 5e-4 per term, averaged over the keys) + the f16 output rounding
+    assert err <= 3e-3, (H, B, R, chunks, err)

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 
 #include "wis_hip.h"
@@ -119,10 +120,17 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 struct DeviceCtx;
 int get_ctx(int device, DeviceCtx** out);
 hipStream_t ctx_stream(DeviceCtx* c);
+std::mutex& ctx_op_mutex(DeviceCtx* c);   // serialises the single-kernel taps (wis_op_*) that share ctx_stream
 
 // log-mel on `stream`: pcm (device) -> mel f32 [n_win][80][3000] (device, may be null) and/or
-// conv1 input f16 [n_win][3002][96] (device, may be null; rows 0 and 3001 and cols 80..95 zero)
-int logmel_device(DeviceCtx* c, hipStream_t stream, const float* d_pcm, int64_t stride,
+// conv1 input f16 [n_win][3002][96] (device, may be null; rows 0 and 3001 and cols 80..95 zero).
+// d_logspec f32 [n_win][80][3000] and d_gmax u32 [n_win] are the caller's own scratch (never shared between in-flight calls).
+int logmel_device(DeviceCtx* c, hipStream_t stream, float* d_logspec, unsigned* d_gmax, const float* d_pcm, int64_t stride,
                   const int64_t* d_nsamp, int n_win, float* d_mel, f16* d_conv_in);
+// the two halves, for streaming sessions: log-spectrum of the 16-frame tiles [tile0, tile0 + n_tiles) of every window
+// (accumulates the running maximum into d_gmax, which the caller zeroes once per window), then clamp / scale / emit
+int logmel_frames(DeviceCtx* c, hipStream_t stream, float* d_logspec, unsigned* d_gmax, const float* d_pcm, int64_t stride,
+                  const int64_t* d_nsamp, int n_win, int tile0, int n_tiles);
+int logmel_finalize(hipStream_t stream, const float* d_logspec, const unsigned* d_gmax, int n_win, float* d_mel, f16* d_conv_in);
 
 }  // namespace wis

@@ -49,12 +49,49 @@ struct DeviceCtx {
   float* d_dft = nullptr;     // [NCT][25][64][4]  MFMA-B-fragment-packed DFT matrix
   float* d_filt = nullptr;    // [80][201]
   int* d_frange = nullptr;    // [80][2] first / one-past-last non-zero bin
-  float* d_logspec = nullptr; // scratch [cap_win][80][3000]
-  unsigned* d_gmax = nullptr; // [cap_win]
-  int cap_win = 0;
-  // host staging for wis_logmel
-  float* d_pcm = nullptr; int64_t* d_nsamp = nullptr; float* d_melout = nullptr; int cap_io = 0;
+  // wis_logmel workspaces: one per in-flight call (own stream, own staging and scratch), recycled through a free list, so
+  // the entry point is re-entrant: concurrent callers never share a buffer or a stream (SURVEY 8(b) conventions)
+  std::mutex ws_mu;
+  std::vector<struct LogmelWs*> ws_free;
+  std::mutex op_mu;           // serialises the single-kernel test taps (wis_op_*), which share `stream`
 };
+
+// everything one wis_logmel call touches on the device; owned by exactly one caller between acquire and release
+struct LogmelWs {
+  hipStream_t stream = nullptr;
+  float* d_pcm = nullptr; int64_t* d_nsamp = nullptr; float* d_melout = nullptr;
+  float* d_logspec = nullptr; unsigned* d_gmax = nullptr;
+  int cap = 0;                // windows
+};
+static int ws_acquire(DeviceCtx* c, int n_win, LogmelWs** out) {
+  LogmelWs* w = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->ws_mu);
+    if (!c->ws_free.empty()) { w = c->ws_free.back(); c->ws_free.pop_back(); }
+  }
+  if (!w) {
+    w = new LogmelWs();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; set_error("wis_logmel: stream create failed"); return WIS_E_HIP; }
+  }
+  if (n_win > w->cap) {       // grown only while exclusively owned: no buffer is ever freed under an in-flight call
+    hipFree(w->d_pcm); hipFree(w->d_nsamp); hipFree(w->d_melout); hipFree(w->d_logspec); hipFree(w->d_gmax);
+    w->d_pcm = nullptr; w->d_nsamp = nullptr; w->d_melout = nullptr; w->d_logspec = nullptr; w->d_gmax = nullptr; w->cap = 0;
+    if (hipMalloc(&w->d_pcm, (size_t)n_win * NSAMP * 4) != hipSuccess || hipMalloc(&w->d_nsamp, (size_t)n_win * 8) != hipSuccess ||
+        hipMalloc(&w->d_melout, (size_t)n_win * NMEL * NFRAMES * 4) != hipSuccess ||
+        hipMalloc(&w->d_logspec, (size_t)n_win * NMEL * NFRAMES * 4) != hipSuccess || hipMalloc(&w->d_gmax, (size_t)n_win * 4) != hipSuccess) {
+      set_error("wis_logmel: out of device memory for %d windows", n_win);
+      std::lock_guard<std::mutex> lk(c->ws_mu); c->ws_free.push_back(w);     // cap = 0: the next owner re-allocates
+      return WIS_E_NOMEM;
+    }
+    w->cap = n_win;
+  }
+  *out = w; return WIS_OK;
+}
+static void ws_release(DeviceCtx* c, LogmelWs* w) {
+  std::lock_guard<std::mutex> lk(c->ws_mu);
+  c->ws_free.push_back(w);
+}
+std::mutex& ctx_op_mutex(DeviceCtx* c) { return c->op_mu; }
 
 static std::mutex g_ctx_mu;
 static DeviceCtx* g_ctx[64] = {nullptr};
@@ -147,12 +184,12 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
 __global__ __launch_bounds__(256) void logmel_stft_kernel(
     const float* __restrict__ pcm, int64_t stride, const int64_t* __restrict__ nsamp,
     const float* __restrict__ dft, const float* __restrict__ filt, const int* __restrict__ frange,
-    float* __restrict__ logspec, unsigned* __restrict__ gmax) {
+    float* __restrict__ logspec, unsigned* __restrict__ gmax, int tile0) {
   __shared__ float s_x[SPAN_LDS];
   __shared__ float s_p[FT * PSTR];
   __shared__ float s_red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int w = blockIdx.y, f0 = blockIdx.x * FT;
+  const int w = blockIdx.y, f0 = (blockIdx.x + tile0) * FT;   // tile0: first 16-frame tile of this launch (streaming sessions)
   const float* x = pcm + (int64_t)w * stride;
   int64_t nv = nsamp[w]; if (nv > NSAMP) nv = NSAMP;   // pad_or_trim (wis/audio.py:28-51)
 
@@ -260,22 +297,30 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(
   }
 }
 
-int logmel_device(DeviceCtx* c, hipStream_t stream, const float* d_pcm, int64_t stride,
-                  const int64_t* d_nsamp, int n_win, float* d_mel, f16* d_conv_in) {
-  if (n_win <= 0) return WIS_OK;
-  if (n_win > c->cap_win) {
-    if (c->d_logspec) { hipFree(c->d_logspec); hipFree(c->d_gmax); c->d_logspec = nullptr; c->d_gmax = nullptr; c->cap_win = 0; }
-    WIS_HIP_CHECK(hipMalloc(&c->d_logspec, (size_t)n_win * NMEL * NFRAMES * 4));
-    WIS_HIP_CHECK(hipMalloc(&c->d_gmax, (size_t)n_win * 4));
-    c->cap_win = n_win;
-  }
-  WIS_HIP_CHECK(hipMemsetAsync(c->d_gmax, 0, (size_t)n_win * 4, stream));
-  hipLaunchKernelGGL(logmel_stft_kernel, dim3(cdiv(NFRAMES, FT), n_win), dim3(256), 0, stream,
-                     d_pcm, stride, d_nsamp, c->d_dft, c->d_filt, c->d_frange, c->d_logspec, c->d_gmax);
-  hipLaunchKernelGGL(logmel_finalize_kernel, dim3(cdiv(NFRAMES, 64), n_win), dim3(256), 0, stream,
-                     c->d_logspec, c->d_gmax, d_mel, d_conv_in);
+// The frame tiles are independent (a frame depends on 400 samples around it); only the clamp at (global max - 8) couples a
+// window, and that is the finalize pass.  d_logspec [n_win][80][3000] / d_gmax [n_win] are the CALLER's scratch: nothing in
+// here is shared between two in-flight calls.
+int logmel_frames(DeviceCtx* c, hipStream_t stream, float* d_logspec, unsigned* d_gmax, const float* d_pcm, int64_t stride,
+                  const int64_t* d_nsamp, int n_win, int tile0, int n_tiles) {
+  if (n_win <= 0 || n_tiles <= 0) return WIS_OK;
+  if (tile0 < 0 || tile0 + n_tiles > cdiv(NFRAMES, FT)) { set_error("logmel_frames: tiles [%d, %d) out of range", tile0, tile0 + n_tiles); return WIS_E_ARG; }
+  hipLaunchKernelGGL(logmel_stft_kernel, dim3(n_tiles, n_win), dim3(256), 0, stream,
+                     d_pcm, stride, d_nsamp, c->d_dft, c->d_filt, c->d_frange, d_logspec, d_gmax, tile0);
   WIS_HIP_CHECK(hipGetLastError());
   return WIS_OK;
+}
+int logmel_finalize(hipStream_t stream, const float* d_logspec, const unsigned* d_gmax, int n_win, float* d_mel, f16* d_conv_in) {
+  if (n_win <= 0) return WIS_OK;
+  hipLaunchKernelGGL(logmel_finalize_kernel, dim3(cdiv(NFRAMES, 64), n_win), dim3(256), 0, stream, d_logspec, d_gmax, d_mel, d_conv_in);
+  WIS_HIP_CHECK(hipGetLastError());
+  return WIS_OK;
+}
+int logmel_device(DeviceCtx* c, hipStream_t stream, float* d_logspec, unsigned* d_gmax, const float* d_pcm, int64_t stride,
+                  const int64_t* d_nsamp, int n_win, float* d_mel, f16* d_conv_in) {
+  if (n_win <= 0) return WIS_OK;
+  WIS_HIP_CHECK(hipMemsetAsync(d_gmax, 0, (size_t)n_win * 4, stream));
+  WIS_RET(logmel_frames(c, stream, d_logspec, d_gmax, d_pcm, stride, d_nsamp, n_win, 0, cdiv(NFRAMES, FT)));
+  return logmel_finalize(stream, d_logspec, d_gmax, n_win, d_mel, d_conv_in);
 }
 
 }  // namespace wis
@@ -283,35 +328,34 @@ int logmel_device(DeviceCtx* c, hipStream_t stream, const float* d_pcm, int64_t 
 // ---------------------------------------------------------------------------------------
 using namespace wis;
 
+// Re-entrant: every call runs on a workspace of its own (stream + staging + scratch) taken from the device's free list.
 extern "C" int wis_logmel(int device, const float* pcm, int64_t stride, const int64_t* n_samples, int n_win,
                           int pcm_on_device, float* mel_out, int mel_on_device) {
   if (!pcm || !n_samples || !mel_out || n_win < 0 || stride < 0) { set_error("wis_logmel: bad argument"); return WIS_E_ARG; }
   if (n_win == 0) return WIS_OK;
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
-  hipStream_t st = c->stream;
-  if (n_win > c->cap_io) {
-    if (c->d_pcm) { hipFree(c->d_pcm); hipFree(c->d_nsamp); hipFree(c->d_melout); c->cap_io = 0; }
-    WIS_HIP_CHECK(hipMalloc(&c->d_pcm, (size_t)n_win * NSAMP * 4));
-    WIS_HIP_CHECK(hipMalloc(&c->d_nsamp, (size_t)n_win * 8));
-    WIS_HIP_CHECK(hipMalloc(&c->d_melout, (size_t)n_win * NMEL * NFRAMES * 4));
-    c->cap_io = n_win;
-  }
-  std::vector<int64_t> ns(n_win);
-  const float* dp = pcm; int64_t dstride = stride;
-  for (int w = 0; w < n_win; ++w) {
-    ns[w] = n_samples[w] < 0 ? 0 : (n_samples[w] > NSAMP ? NSAMP : n_samples[w]);
-  }
-  if (!pcm_on_device) {
-    // copy only the valid samples of each window; the tail is treated as zero by the kernel
-    for (int w = 0; w < n_win; ++w)
-      if (ns[w]) WIS_HIP_CHECK(hipMemcpyAsync(c->d_pcm + (size_t)w * NSAMP, pcm + (size_t)w * stride, (size_t)ns[w] * 4, hipMemcpyHostToDevice, st));
-    dp = c->d_pcm; dstride = NSAMP;
-  }
-  WIS_HIP_CHECK(hipMemcpyAsync(c->d_nsamp, ns.data(), (size_t)n_win * 8, hipMemcpyHostToDevice, st));
-  float* dm = mel_on_device ? mel_out : c->d_melout;
-  WIS_RET(logmel_device(c, st, dp, dstride, c->d_nsamp, n_win, dm, nullptr));
-  if (!mel_on_device)
-    WIS_HIP_CHECK(hipMemcpyAsync(mel_out, dm, (size_t)n_win * NMEL * NFRAMES * 4, hipMemcpyDeviceToHost, st));
-  WIS_HIP_CHECK(hipStreamSynchronize(st));
-  return WIS_OK;
+  LogmelWs* ws; WIS_RET(ws_acquire(c, n_win, &ws));
+  hipStream_t st = ws->stream;
+  auto body = [&]() -> int {
+    std::vector<int64_t> ns(n_win);
+    const float* dp = pcm; int64_t dstride = stride;
+    for (int w = 0; w < n_win; ++w) ns[w] = n_samples[w] < 0 ? 0 : (n_samples[w] > NSAMP ? NSAMP : n_samples[w]);
+    if (!pcm_on_device) {
+      // copy only the valid samples of each window; the tail is treated as zero by the kernel
+      for (int w = 0; w < n_win; ++w)
+        if (ns[w]) WIS_HIP_CHECK(hipMemcpyAsync(ws->d_pcm + (size_t)w * NSAMP, pcm + (size_t)w * stride, (size_t)ns[w] * 4, hipMemcpyHostToDevice, st));
+      dp = ws->d_pcm; dstride = NSAMP;
+    }
+    WIS_HIP_CHECK(hipMemcpyAsync(ws->d_nsamp, ns.data(), (size_t)n_win * 8, hipMemcpyHostToDevice, st));
+    float* dm = mel_on_device ? mel_out : ws->d_melout;
+    WIS_RET(logmel_device(c, st, ws->d_logspec, ws->d_gmax, dp, dstride, ws->d_nsamp, n_win, dm, nullptr));
+    if (!mel_on_device)
+      WIS_HIP_CHECK(hipMemcpyAsync(mel_out, dm, (size_t)n_win * NMEL * NFRAMES * 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipStreamSynchronize(st));      // `ns` (pageable) and the caller's buffers are free again
+    return WIS_OK;
+  };
+  const int rc = body();
+  if (rc != WIS_OK) hipStreamSynchronize(st);     // nothing of this call may still be in flight when the workspace is recycled
+  ws_release(c, ws);
+  return rc;
 }

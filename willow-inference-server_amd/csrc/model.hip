@@ -119,6 +119,7 @@ struct wis_model {
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
+  float* lm_logspec = nullptr; unsigned* lm_gmax = nullptr;   // log-mel scratch of THIS replica (never shared with other callers)
   int* h_pin;      // pinned host scratch
   hipEvent_t ev[8];
   wis_timing_t timing;
@@ -383,6 +384,8 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->st_val, (size_t)MAX_ROWS * STAT_CHUNKS * MAX_CAND)); WIS_RET(dalloc(m, &m->st_idx, (size_t)MAX_ROWS * STAT_CHUNKS * MAX_CAND));
   WIS_RET(dalloc(m, &m->d_in, (size_t)Bm * WIS_N_SAMPLES));
   WIS_RET(dalloc(m, &m->d_nsamp, Bm));
+  WIS_RET(dalloc(m, &m->lm_logspec, (size_t)Bm * WIS_N_MELS * WIS_N_FRAMES));
+  WIS_RET(dalloc(m, &m->lm_gmax, Bm));
   WIS_RET(dalloc(m, &m->d_probs, (size_t)Bm * (c.n_lang > 0 ? c.n_lang : 1)));
   WIS_RET(dalloc(m, &m->d_prof, ((size_t)c.n_dec_layers * 8 + 2) * 16));   // + sampling kernels (tap builds)
   WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 65536, hipHostMallocDefault));
@@ -402,7 +405,7 @@ int stage_input(wis_model* m, const float* input, int kind, int B) {
     int64_t* hn = reinterpret_cast<int64_t*>(m->h_pin);
     for (int b = 0; b < B; ++b) hn[b] = WIS_N_SAMPLES;
     WIS_HIP_CHECK(hipMemcpyAsync(m->d_nsamp, hn, (size_t)B * 8, hipMemcpyHostToDevice, st));
-    WIS_RET(logmel_device(m->ctx, st, dp, WIS_N_SAMPLES, m->d_nsamp, B, nullptr, m->img));
+    WIS_RET(logmel_device(m->ctx, st, m->lm_logspec, m->lm_gmax, dp, WIS_N_SAMPLES, m->d_nsamp, B, nullptr, m->img));
   } else if (kind == WIS_IN_MEL_HOST || kind == WIS_IN_MEL_DEV) {
     const float* dm = input;
     if (kind == WIS_IN_MEL_HOST) {
@@ -935,6 +938,7 @@ int wis_dev_sync(int device) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_H
 
 int wis_op_gemm(int device, const void* A, int lda, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K, int flags) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
   hipStream_t st = ctx_stream(c);
   if (flags & 8) {   // split-K = 2 path of the encoder's FFN2: requires bias, residual and fp32 output
     if (!bias || !residual || (flags & 7) != (2 | 4)) { set_error("wis_op_gemm: split-K needs bias, residual, flags 2|4|8"); return WIS_E_ARG; }
@@ -955,6 +959,7 @@ int wis_op_gemm(int device, const void* A, int lda, const void* W, const float* 
 }
 int wis_op_layernorm(int device, const float* x, const float* gamma, const float* beta, void* y, int M, int d) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
   WIS_RET(launch_layernorm(ctx_stream(c), x, gamma, beta, reinterpret_cast<f16*>(y), M, d));
   WIS_HIP_CHECK(hipGetLastError());
   WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
@@ -962,6 +967,7 @@ int wis_op_layernorm(int device, const float* x, const float* gamma, const float
 }
 int wis_op_enc_attention(int device, const void* qk, const void* vt, void* out, int B, int T, int Tpad, int H) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
   WIS_RET(launch_enc_attention(ctx_stream(c), reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H));
   WIS_HIP_CHECK(hipGetLastError());
   WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
@@ -969,6 +975,7 @@ int wis_op_enc_attention(int device, const void* qk, const void* vt, void* out, 
 }
 int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y, int M, int N, int K, int flags) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
   hipStream_t st = ctx_stream(c);
   if (flags & GV_QKV) { set_error("wis_op_gemv: flag 16 is internal"); return WIS_E_ARG; }
   const int Npad = cdiv(N, gemv_rows_for(N, K)) * gemv_rows_for(N, K);
@@ -1003,6 +1010,38 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
   hipFree(wp); hipFree(wtmp); hipFree(b2); hipFree(cs); hipFree(wsc); hipFree(xn);
   if (rc) return rc;
   if (e != hipSuccess) { set_error("wis_op_gemv: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+  return WIS_OK;
+}
+
+int wis_op_dec_self_attn(int device, const float* q, const void* kc, const void* vc, const int32_t* pos, void* out,
+                         int M, int H, int ctx, int rpu, int sstride, int rmul) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
+  if (!q || !kc || !vc || !pos || !out || M < 1 || H < 1 || rpu < 1) { set_error("wis_op_dec_self_attn: bad argument"); return WIS_E_ARG; }
+  WIS_RET(launch_dec_self_attn(ctx_stream(c), q, reinterpret_cast<const f16*>(kc), reinterpret_cast<const f16*>(vc), pos, reinterpret_cast<f16*>(out),
+                               M, H, 64 * H, ctx, rpu, sstride, rmul));
+  WIS_HIP_CHECK(hipGetLastError());
+  WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
+  return WIS_OK;
+}
+int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void* vt, void* out, int B, int R, int H, int T, int chunks) {
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
+  if (!q || !kx || !vt || !out || B < 1 || H < 1 || T < 1) { set_error("wis_op_dec_cross_attn: bad argument"); return WIS_E_ARG; }
+  hipStream_t st = ctx_stream(c);
+  float* part = nullptr; unsigned* counters = nullptr;
+  int rc = WIS_OK;
+  if (hipMalloc(reinterpret_cast<void**>(&part), (size_t)B * H * 16 * 16 * 66 * 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&counters), (size_t)B * H * 4) != hipSuccess) { set_error("wis_op_dec_cross_attn: out of device memory"); rc = WIS_E_NOMEM; }
+  if (!rc) {
+    hipMemsetAsync(counters, 0, (size_t)B * H * 4, st);
+    rc = launch_dec_cross_attn(st, q, reinterpret_cast<const f16*>(kx), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), part, counters,
+                               B, R, H, 64 * H, T, cdiv(T, 64) * 64, chunks);
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(part); hipFree(counters);
+  if (rc) return rc;
+  if (e != hipSuccess) { set_error("wis_op_dec_cross_attn: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;
 }
 

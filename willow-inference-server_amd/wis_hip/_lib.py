@@ -83,6 +83,8 @@ SYMBOLS = [
     ("wis_op_layernorm", _i, [_i, _vp, _vp, _vp, _vp, _i, _i]),
     ("wis_op_enc_attention", _i, [_i, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("wis_op_gemv", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    ("wis_op_dec_self_attn", _i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    ("wis_op_dec_cross_attn", _i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
 ]
 
 _lib = None
