@@ -144,3 +144,121 @@ def test_streaming_session_equals_offline(golden_dir):
     assert fin.tokens == off.tokens and fin[5] == off[5] == 64000
     with pytest.raises(RuntimeError):
         sess.feed(long_pcm[:10])
+
+
+def test_logmel_is_reentrant_across_threads(golden_dir):
+    """SURVEY 8(b) conventions / round-1 review: wis_logmel called from 32 threads at once with DIFFERENT audio (the three
+    reference clips, batches of 1 and 2 windows interleaved so workspaces of different sizes are recycled) - every caller must
+    get exactly (bit for bit) what a lone call gets.  The round-1 entry point shared one staging buffer and one stream per
+    device and failed this."""
+    from wis_hip import audio
+    clips = [audio.pad_or_trim(audio.load_audio(os.path.join(golden_dir, "clips", c + ".flac"))[0]) for c in ("3sec", "10sec", "30sec")]
+    serial = [audio.log_mel_spectrogram(c, device=0).numpy() for c in clips]
+    assert not np.array_equal(serial[0], serial[1]) and not np.array_equal(serial[1], serial[2])
+    bad, start = [], threading.Barrier(32)
+
+    def client(i):
+        start.wait()
+        for rep in range(6):
+            k = (i + rep) % 3
+            if (i + rep) % 4 == 0:        # a two-window call: grows / recycles workspaces under the other callers
+                got = audio.log_mel_spectrogram(np.stack([clips[k], clips[(k + 1) % 3]]), device=0).numpy()
+                ok = np.array_equal(got[0], serial[k]) and np.array_equal(got[1], serial[(k + 1) % 3])
+            else:
+                ok = np.array_equal(audio.log_mel_spectrogram(clips[k], device=0).numpy(), serial[k])
+            if not ok:
+                bad.append((i, rep, k))
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(32)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_rest_interleaved_clips_from_32_clients(golden_dir, fuse):
+    """32 concurrent POSTs of the 3 s / 10 s / 30 s clips interleaved: each response must be the answer of ITS OWN clip (the
+    serial answer; batch composition may flip a near-tie of the seeded random weights, a mix-up of requests would flip nearly all).
+    fuse=False takes the reference's two-step form (wis_logmel from the request threads, then generate on host features)."""
+    import httpx
+    from wis_hip.server import create_app
+    from wis_hip.settings import APISettings
+    from wis_hip.whisper import WhisperModels, do_whisper
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.max_batch, s.fuse_logmel = 8, fuse
+    models = WhisperModels(s, device_index=[0])
+    app = create_app(models=models)
+    names = ("3sec", "10sec", "30sec")
+    blobs = {c: open(os.path.join(golden_dir, "clips", c + ".flac"), "rb").read() for c in names}
+    serial = {c: do_whisper(os.path.join(golden_dir, "clips", c + ".flac"), "tiny", 1, "transcribe", False, None, models=models) for c in names}
+    assert len({serial[c][1] for c in names}) == 3 and [serial[c][5] for c in names] == [3840, 10688, 29248]
+
+    async def go():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis", timeout=300) as c:
+            reqs = []
+            for i in range(32):
+                body, hdr = _multipart(blobs[names[i % 3]])
+                reqs.append(c.post("/api/asr?model=tiny&beam_size=1&detect_language=False", content=body, headers=hdr))
+            return await asyncio.gather(*reqs)
+
+    rs = asyncio.run(go())
+    assert all(r.status_code == 200 for r in rs), [r.text for r in rs if r.status_code != 200][:2]
+    wrong = 0
+    for i, r in enumerate(rs):
+        j, exp = r.json(), serial[names[i % 3]]
+        assert j["audio_duration"] == exp[5]
+        if j["text"] != exp[1]:
+            wrong += 1
+            own = sum(a == b for a, b in zip(j["text"].split(), exp[1].split()))
+            other = max(sum(a == b for a, b in zip(j["text"].split(), serial[o][1].split())) for o in names if o != names[i % 3])
+            assert own > other, (i, names[i % 3])         # a near-tie flip keeps the common prefix of its own clip
+    print(f"interleaved REST (fuse_logmel={fuse}): {wrong} of 32 responses differ from their serial answer")
+    assert wrong <= 3
+
+
+def test_translate_and_tokenizer_branches(tmp_path, golden_dir):
+    """do_whisper's translate branch (reference main.py:729-748: a second generate with the <|translate|> prompt) and the
+    text path through a real `tokenizer.json` in the model directory (main.py:329-334, 714), on a CTranslate2-layout model
+    directory written here (tiny architecture, seeded weights, a word-level vocabulary covering every id)."""
+    import json
+    from tokenizers import Tokenizer, decoders, models as tk_models
+    from wis_hip import ctranslate2 as ct2, weights as W
+    from wis_hip.settings import APISettings
+    from wis_hip.whisper import WhisperModels, do_whisper
+    mdir = tmp_path / "tovera-wis-whisper-tiny"
+    os.makedirs(mdir)
+    w = W.synthetic_weights("tiny", seed=77, emb_std=0.06, ln_jitter=0.1)
+    W.write_ct2_model_bin(str(mdir / "model.bin"), w, aliases={"decoder/projection/weight": "decoder/embeddings/weight"})
+    with open(mdir / "config.json", "w") as f:
+        json.dump(dict(suppress_ids=W.SUPPRESS_IDS, suppress_ids_begin=W.SUPPRESS_IDS_BEGIN, lang_ids=W.LANG_IDS), f)
+    s = APISettings()
+    s.whisper_model_path = str(tmp_path / "tovera-wis-whisper-{size}")
+    models = WhisperModels(s, device_index=[0])
+    with pytest.raises(FileNotFoundError, match="tokenizer"):       # a real checkpoint without its tokenizer is refused
+        models.get("tiny")
+    tok = Tokenizer(tk_models.WordLevel({f"w{i}": i for i in range(W.N_VOCAB)}, unk_token="w0"))
+    tok.decoder = decoders.Fuse()
+    tok.save(str(mdir / "tokenizer.json"))
+    models = WhisperModels(s, device_index=[0])
+    clip = os.path.join(golden_dir, "clips", "3sec.flac")
+    res = do_whisper(clip, "tiny", 5, "transcribe", False, "en", translate=True, models=models, fixed_new_tokens=7)
+    language, text, _, translation, _, duration = res
+    assert language == "en" and duration == 3840 and len(res.tokens) == 7 and len(res.translation_tokens) == 7
+    assert text == "".join(f"w{t}" for t in res.tokens)                       # decoded by the directory's tokenizer.json, not id strings
+    assert translation == "".join(f"w{t}" for t in res.translation_tokens)
+    # the translation is what generate returns for the <|translate|> prompt, and differs from the transcription prompt's result
+    from wis_hip import audio
+    x = np.ascontiguousarray(audio.pad_or_trim(audio.load_audio(clip)[0])[None])
+    direct = models.get("tiny").generate(ct2.StorageView.from_array(x), [[W.SOT, W.LANG_IDS[0], W.TRANSLATE, W.NO_TIMESTAMPS]], beam_size=5,
+                                         fixed_new_tokens=7, input_kind=ct2._lib.WIS_IN_PCM_HOST)[0]
+    assert direct.sequences_ids[0] == res.translation_tokens and res.translation_tokens != res.tokens
+    # task="translate" puts the translate token into the main prompt (main.py:656-663)
+    t2 = do_whisper(clip, "tiny", 5, "translate", False, "en", models=models, fixed_new_tokens=7)
+    assert t2.tokens == res.translation_tokens and t2[3] is None
+    # the two-step (host features) form gives the same ids as the fused form
+    s.fuse_logmel = False
+    again = do_whisper(clip, "tiny", 5, "transcribe", False, "en", models=models, fixed_new_tokens=7)
+    assert again.tokens == res.tokens and again[1] == text

@@ -3,6 +3,7 @@ declares, container decode (FLAC MD5 known-answer tests), the wis.audio-compatib
 arena, and loud failure without a GPU."""
 import hashlib
 import io
+import math
 import json
 import os
 import re
@@ -68,11 +69,38 @@ def test_wav_decode_roundtrip():
         pcm, sr = audio.load_audio(buf.getvalue())
         exp = (x[:, :ch].astype(np.float32) / 32768.0).mean(axis=1)
         assert sr == 16000 and np.allclose(pcm, exp, atol=1e-7)
-    with pytest.raises(ValueError):
+    # any other rate is resampled to 16 kHz, as librosa.load(sr=16000) does (reference main.py:579)
+    for sr_in in (8000, 44100, 48000):
+        t = np.arange(sr_in) / sr_in
+        tone = (0.4 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
         buf = io.BytesIO()
         with wave.open(buf, "wb") as w:
-            w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000); w.writeframes(b"\0\0" * 80)
-        audio.load_audio(buf.getvalue())
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr_in); w.writeframes((tone * 32767).astype("<i2").tobytes())
+        pcm, sr = audio.load_audio(buf.getvalue())
+        assert sr == 16000 and pcm.shape[0] == 16000 and pcm.dtype == np.float32
+        exp = 0.4 * np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000)
+        assert np.abs(pcm[500:-500] - exp[500:-500]).max() < 1e-3          # 16-bit quantisation of the input dominates
+
+
+def test_resampler_against_analytic_and_scipy():
+    import scipy.signal as ss
+    from wis_hip import audio
+    for sr_in in (8000, 11025, 22050, 32000, 44100, 48000):
+        n = 2 * sr_in
+        t = np.arange(n) / sr_in
+        x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t + 0.3)).astype(np.float32)
+        y = audio.resample(x, sr_in, 16000)
+        assert y.shape[0] == -(-n * 16000 // sr_in) and y.dtype == np.float32
+        to = np.arange(y.shape[0]) / 16000
+        exp = 0.5 * np.sin(2 * np.pi * 440 * to) + 0.2 * np.sin(2 * np.pi * 3000 * to + 0.3)
+        assert np.abs(y[400:-400] - exp[400:-400]).max() < 1e-6, sr_in
+        g = math.gcd(sr_in, 16000)
+        z = ss.resample_poly(x.astype(np.float64), 16000 // g, sr_in // g)       # an independent polyphase resampler (different filter)
+        assert np.abs(y[400:-400] - z[:y.shape[0]][400:-400]).max() < 5e-3, sr_in
+    t = np.arange(48000) / 48000
+    assert np.sqrt((audio.resample(np.sin(2 * np.pi * 10000 * t), 48000)[400:-400] ** 2).mean()) < 1e-5     # above the new Nyquist: rejected
+    assert audio.resample(np.zeros(0, np.float32), 44100).shape == (0,)
+    assert np.array_equal(audio.resample(np.arange(5, dtype=np.float32), 16000), np.arange(5, dtype=np.float32))
 
 
 def test_audio_host_logic_matches_reference_golden(golden_dir):

@@ -118,3 +118,67 @@ def test_int8_quantiser_restatement_properties():
     assert all(k.startswith("decoder/layer_") and k.endswith("/weight") for k in changed)
     assert len(changed) == 6 * 4 and "decoder/projection/weight" in qd and "decoder/layer_0/attention/linear_1/weight" not in changed
     assert np.array_equal(qd["decoder/embeddings/weight"], ws["decoder/embeddings/weight"])     # the lookup table stays f16
+
+
+def test_ct2_model_bin_with_converter_attributes(tmp_path):
+    """A real CTranslate2 WhisperSpec `model.bin` carries, besides the float tensors, integer ATTRIBUTE variables (rank-0
+    int16 `num_heads`, int16 `alignment_layer` / `alignment_heads`, int8 `activation`, int8 flags).  They must be skipped -
+    not rejected - and `num_heads` must reach the architecture; an int8 weight MATRIX (a quantised export) is still an error."""
+    from wis_hip import weights as W
+    d, L, H = 128, 2, 2
+    base = {k: np.zeros(s, np.float32 if kind == "pos" else np.float16) for k, (s, kind) in W.tensor_shapes(d, L, 300, 448).items()}
+    rng = np.random.default_rng(1)
+    for k in base:
+        base[k] = rng.standard_normal(base[k].shape).astype(base[k].dtype)
+    extra = dict(base)
+    extra["encoder/num_heads"] = np.array(H, np.int16)                  # rank 0
+    extra["decoder/num_heads"] = np.array(H, np.int16)
+    extra["decoder/alignment_layer"] = np.array(1, np.int16)
+    extra["decoder/alignment_heads"] = np.array([[1, 0], [1, 1]], np.int16)
+    extra["decoder/activation"] = np.array(1, np.int8)
+    extra["decoder/pre_norm"] = np.array(1, np.int8)
+    extra["decoder/scale_embeddings"] = np.array(0, np.int8)
+    extra["encoder/layer_0/self_attention/queries_scale"] = np.array(0.125, np.float32)
+    os.makedirs(tmp_path / "m")
+    W.write_ct2_model_bin(str(tmp_path / "m" / "model.bin"), extra, aliases={"decoder/projection/weight": "decoder/embeddings/weight"})
+    w, attrs = W.read_ct2_model_bin(str(tmp_path / "m" / "model.bin"), return_attrs=True)
+    assert int(attrs["decoder/num_heads"]) == H and attrs["decoder/alignment_heads"].shape == (2, 2) and "decoder/activation" in attrs
+    assert not any(v.dtype.kind == "i" for v in w.values())
+    w2, a, cfg = W.load_model_dir(str(tmp_path / "m"))
+    assert (a["d_model"], a["n_layers"], a["n_heads"]) == (d, L, H)
+    assert all(np.array_equal(w2[k], base[k].astype(w2[k].dtype)) for k in base)
+    arena, index = W.build_arena({k: w2[k] for k in base})      # what wis_model_create consumes: tensors only
+    assert {e["name"] for e in index} == set(base)
+    # a quantised export is refused with a message that says what to do
+    q = dict(base)
+    q["decoder/layer_0/ffn/linear_0/weight"] = np.zeros((4 * d, d), np.int8)
+    q["decoder/layer_0/ffn/linear_0/weight_scale"] = np.ones(4 * d, np.float32)
+    W.write_ct2_model_bin(str(tmp_path / "q.bin"), q)
+    with pytest.raises(ValueError, match="float16"):
+        W.read_ct2_model_bin(str(tmp_path / "q.bin"))
+
+
+def test_settings_default_is_the_reference_layout_and_fails_loudly(tmp_path, monkeypatch):
+    """a server started with default settings must not silently serve seeded random weights."""
+    from wis_hip import whisper
+    from wis_hip.settings import APISettings
+    s = APISettings()
+    assert s.whisper_model_path == "models/tovera-wis-whisper-{size}" and not s.allow_token_id_text
+    monkeypatch.setattr(whisper.ctranslate2._lib, "device_count", lambda: 1)
+    models = whisper.WhisperModels(settings=s, device_index=[0])
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError, match="synthetic"):
+        models.get("tiny")
+    os.makedirs(tmp_path / "models" / "tovera-wis-whisper-tiny")       # a directory without tokenizer.json: refuse to serve ids as text
+    with pytest.raises(FileNotFoundError, match="tokenizer"):
+        models.get("tiny")
+
+
+def test_batch_capacity_uses_the_prefill_row_count():
+    """wis_generate prefills all P prompt rows (B * P <= 48); the batcher's capacity must use the same bound."""
+    from wis_hip.ctranslate2 import MAX_DECODER_ROWS, _capacity
+    assert MAX_DECODER_ROWS == 48
+    assert _capacity(16, (4, 1)) == 12 and _capacity(16, (4, 3)) == 12 and _capacity(16, (4, 5)) == 9 and _capacity(8, (4, 5)) == 8
+    assert _capacity(48, (1, 1)) == 48 and _capacity(16, (16, 1)) == 3
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "willow-inference-server_amd", "csrc", "kernels.hpp")).read()
+    assert "constexpr int MAX_ROWS = 48;" in src

@@ -93,6 +93,9 @@ class _FakeModels:
         self.settings = APISettings()
         self.tokenizer = _Tokenizer(None)
 
+    def tokenizer_for(self, size):
+        return self.tokenizer
+
     def get(self, size):
         if size not in ("tiny", "base", "small", "medium", "large"):
             raise ValueError(f"unknown model {size!r}")
@@ -219,10 +222,17 @@ def test_streaming_session_schedule_without_gpu():
             import threading
             from concurrent.futures import ThreadPoolExecutor
             self._lock, self._pool = threading.Lock(), ThreadPoolExecutor(max_workers=2)
-            self._windows, self._language, self._closed, self.eager_windows = {}, "en", False, 0
-            self.calls = []
+            self._windows, self._language_job, self._closed, self.eager_windows = {}, None, False, 0
+            self.calls, self.detect_calls = [], []
 
-        def _window_tokens(self, piece, beam):
+        def _detect(self, first_window):
+            self.detect_calls.append(first_window.shape[0])
+            return "en"
+
+        def _window_tokens(self, piece, beam, language):
+            if hasattr(language, "result"):
+                language = language.result()
+            assert language == "en"
             self.calls.append((piece.shape[0], beam))
             return fake_ids(piece)
 
@@ -238,6 +248,7 @@ def test_streaming_session_schedule_without_gpu():
     expect = audio.find_longest_common_sequence([(fake_ids(p), st) for p, st in audio.chunk_iter(pcm)], models.tokenizer)
     assert out.tokens == [int(t) for t in expect] and out[5] == 75000
     assert len(s.calls) == 6                   # the two tail windows were transcribed at stop(), nothing twice
+    assert s.detect_calls == [audio.chunk_len]  # the language was resolved ONCE, from window 0 (no race between windows)
     # short recording: no eager work, one window, request beam below the long-audio threshold
     s2 = Sess(models)
     s2.feed((pcm[:5 * 16000] * 32768 * 0.01).astype("<i2").tobytes(), 2)

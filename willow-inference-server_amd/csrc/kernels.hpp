@@ -27,7 +27,7 @@ int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* 
 int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H);
 
 // ---- decoder ---------------------------------------------------------------------------
-constexpr int MAX_ROWS = 48;      // decoder rows per step: B*beam (decode) or B*(P-1) (prefill)
+constexpr int MAX_ROWS = 48;      // decoder rows per pass: B*beam (decode) or B*P (merged prefill + first step); wis_hip/ctranslate2.py MAX_DECODER_ROWS
 constexpr int MAX_R = 8;          // rows per utterance (beam or prompt prefix length)
 constexpr int MAX_CAND = 2 * MAX_R;
 

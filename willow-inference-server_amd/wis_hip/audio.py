@@ -7,9 +7,10 @@ arithmetic moved to the GPU:
 (`wis_logmel`); it raises if libwis_hip.so or a GPU is missing (no CPU fallback).  `pad_or_trim`,
 `chunk_iter` and `find_longest_common_sequence` are integer/host logic and keep the reference's
 semantics exactly (wis/audio.py:28-51, 119-134, 139-159).  `load_audio` replaces the
-`librosa.load(audio_file, sr=16000, mono=True)` call of main.py:579.
+`librosa.load(audio_file, sr=16000, mono=True)` call of main.py:579 (container decode in C, channel mix, resampling to 16 kHz).
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -50,9 +51,57 @@ def load_audio(audio_file):
         pcm = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
     finally:
         lib.wis_audio_free(p)
-    if sr.value != SAMPLE_RATE:
-        raise ValueError(f"audio is {sr.value} Hz; the ASR path takes {SAMPLE_RATE} Hz input (resampling is out of scope)")
-    return pcm, sr.value
+    if sr.value != SAMPLE_RATE:         # librosa.load(..., sr=16000) resamples whatever the container holds (main.py:579)
+        pcm = resample(pcm, sr.value, SAMPLE_RATE)
+    return pcm, SAMPLE_RATE
+
+
+def _resample_filter(up, down, half_width=32, beta=14.769656459379492, rolloff=0.945):
+    """Kaiser-windowed sinc prototype low-pass of a polyphase up/down resampler, designed at the `up`-times oversampled
+    rate: cut-off at rolloff x the lower Nyquist, `half_width` zero crossings each side (at the lower rate), fp64."""
+    q = max(up, down)
+    n = half_width * q
+    t = np.arange(-n, n + 1, dtype=np.float64)
+    fc = rolloff / q                                     # cycles per oversampled sample, relative to Nyquist = 1
+    h = fc * np.sinc(fc * t) * np.kaiser(2 * n + 1, beta)
+    return h * (up / h.sum())
+
+
+def resample(pcm, sr_in, sr_out=SAMPLE_RATE):
+    """Band-limited sample-rate conversion sr_in -> sr_out (host, numpy fp64 accumulation; polyphase Kaiser-windowed sinc,
+    64 zero crossings, stop band below -100 dB).  Replaces the resampling half of `librosa.load(audio_file, sr=16000)`
+    (main.py:579; librosa's default there is soxr_hq - a different filter of the same class, so the result agrees with it to
+    pass-band ripple / transition-band shape, not bit for bit: the reference fixtures are all 16 kHz and never take this path).
+    Output length = ceil(n * sr_out / sr_in), as librosa."""
+    x = np.ascontiguousarray(pcm, np.float64).reshape(-1)
+    sr_in, sr_out = int(sr_in), int(sr_out)
+    if sr_in <= 0 or sr_out <= 0:
+        raise ValueError(f"bad sample rate {sr_in} -> {sr_out}")
+    if sr_in == sr_out or x.shape[0] == 0:
+        return x.astype(np.float32)
+    g = math.gcd(sr_in, sr_out)
+    up, down = sr_out // g, sr_in // g
+    h = _resample_filter(up, down)
+    half = (h.shape[0] - 1) // 2
+    n_out = -(-x.shape[0] * up // down)
+    # output m sits at oversampled index m * down; y[m] = sum_k x[k] h[m * down - k * up + half]
+    # per output phase r = m mod up:  m = r + j * up  ->  (m * down) = r * down + j * up * down:
+    #   k ranges over a window that advances by `down` input samples per j, taps = h[(r * down - k0 * up + half) :: -up]
+    taps_per_phase = -(-h.shape[0] // up)
+    pad = taps_per_phase + down + 2
+    xp = np.concatenate([np.zeros(pad), x, np.zeros(pad + taps_per_phase * 2)])
+    out = np.zeros(n_out, np.float64)
+    for r in range(min(up, n_out)):
+        c = r * down                                          # oversampled position of the phase's first output
+        k_hi = (c + half) // up                               # last input index with a tap for j = 0
+        t0 = c + half - k_hi * up                             # tap index for k_hi (0 <= t0 < up)
+        taps = h[t0::up]                                      # taps for k = k_hi, k_hi - 1, ...
+        nt = taps.shape[0]
+        n_r = (n_out - r + up - 1) // up                      # outputs of this phase
+        start = k_hi - (nt - 1) + pad                         # window start in xp for j = 0 (ascending k)
+        win = np.lib.stride_tricks.as_strided(xp[start:], shape=(n_r, nt), strides=(xp.strides[0] * down, xp.strides[0]))
+        out[r::up] = win @ taps[::-1]
+    return out.astype(np.float32)
 
 
 def pad_or_trim(array, length: int = N_SAMPLES, *, axis: int = -1):
@@ -85,8 +134,13 @@ class MelFeatures:
         return self._arr if dtype is None else self._arr.astype(dtype)
 
 
-def log_mel_spectrogram(audio, n_mels: int = N_MELS, device: int = 0):
-    """float32 [480000] (or [n, 480000]) -> MelFeatures wrapping float32 [80, 3000] (or [n, 80, 3000])."""
+_rr = [0]
+
+
+def log_mel_spectrogram(audio, n_mels: int = N_MELS, device=None):
+    """float32 [480000] (or [n, 480000]) -> MelFeatures wrapping float32 [80, 3000] (or [n, 80, 3000]).
+    `device`: the GPU to run on (a replica's device index); None = round-robin over the visible GPUs.  Re-entrant: concurrent
+    calls never share a stream or a buffer (csrc/logmel.hip)."""
     assert n_mels == 80, f"Unsupported n_mels: {n_mels}"
     x = np.ascontiguousarray(np.asarray(audio, dtype=np.float32))
     single = x.ndim == 1
@@ -94,7 +148,10 @@ def log_mel_spectrogram(audio, n_mels: int = N_MELS, device: int = 0):
         x = x[None]
     if x.ndim != 2 or x.shape[1] != N_SAMPLES:
         raise ValueError(f"log_mel_spectrogram expects pad_or_trim'ed audio of {N_SAMPLES} samples, got {x.shape}")
-    _lib.require_gpu()
+    n_dev = _lib.require_gpu()
+    if device is None:
+        _rr[0] = (_rr[0] + 1) % n_dev          # a benign race: any device is a correct answer
+        device = _rr[0]
     n = x.shape[0]
     out = np.empty((n, N_MELS, N_FRAMES), np.float32)
     ns = (C.c_int64 * n)(*([N_SAMPLES] * n))

@@ -129,11 +129,14 @@ def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_bl
 
 
 
+MAX_DECODER_ROWS = 48      # csrc/kernels.hpp MAX_ROWS: decoder rows per device pass
+
+
 def _capacity(max_batch, key):
-    """Utterances per device batch: the decoder handles <= 48 rows per pass (rows = utterances x beam while decoding,
-    utterances x (prompt - 1) in the prefill)."""
+    """Utterances per device batch: the decoder handles <= MAX_DECODER_ROWS rows per pass - utterances x beam while decoding,
+    utterances x P in the merged prefill + first step (wis_generate enforces B * P <= MAX_ROWS and B * beam <= MAX_ROWS)."""
     P, beam = key[0], key[1]
-    return max(1, min(max_batch, 48 // max(beam, 1), 48 // max(P - 1, 1)))
+    return max(1, min(max_batch, MAX_DECODER_ROWS // max(beam, 1), MAX_DECODER_ROWS // max(P, 1)))
 
 
 def _run_batch(replica, key, rows):
@@ -166,6 +169,8 @@ class Whisper:
             weights, arch, cfg = self._load(model_path)
         self.arch, self.decode_config = arch, cfg
         devs = list(device_index) if isinstance(device_index, (list, tuple)) else [int(device_index)]
+        if not 1 <= int(max_batch) <= MAX_DECODER_ROWS:
+            raise ValueError(f"max_batch={max_batch}: a device batch holds 1..{MAX_DECODER_ROWS} utterances")
         arena, index = W.build_arena(weights)
         kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"),
                   weight_bits=8 if self.compute_type == "int8_float16" else 16)
@@ -227,13 +232,19 @@ class Whisper:
             r.inflight -= 1
 
     @staticmethod
-    def _features(features):
+    def _features(features, input_kind=_lib.WIS_IN_MEL_HOST):
         a = features.array if isinstance(features, StorageView) else np.asarray(features)
         if a.dtype != np.float32:
             a = a.astype(np.float32)
         a = np.ascontiguousarray(a)
-        if a.ndim != 3 or a.shape[1:] != (80, 3000):
-            raise ValueError(f"features must be [batch, 80, 3000] float32, got {a.shape}")
+        if input_kind == _lib.WIS_IN_PCM_HOST:
+            if a.ndim != 2 or a.shape[1] != _lib.N_SAMPLES:
+                raise ValueError(f"PCM input must be [batch, {_lib.N_SAMPLES}] float32 (pad_or_trim'ed 30 s windows), got {a.shape}")
+        elif input_kind == _lib.WIS_IN_MEL_HOST:
+            if a.ndim != 3 or a.shape[1:] != (80, 3000):
+                raise ValueError(f"features must be [batch, 80, 3000] float32, got {a.shape}")
+        else:
+            raise ValueError("the Python face takes host arrays (WIS_IN_MEL_HOST or WIS_IN_PCM_HOST)")
         return a
 
     def generate(self, features, prompts, *, asynchronous=False, beam_size=5, patience=1, num_hypotheses=1, length_penalty=1,
@@ -242,7 +253,7 @@ class Whisper:
                  sampling_temperature=1, fixed_new_tokens=0, input_kind=_lib.WIS_IN_MEL_HOST):
         if num_hypotheses != 1 or repetition_penalty != 1 or no_repeat_ngram_size != 0 or sampling_topk != 1:
             raise NotImplementedError("only the decoding options WIS uses are implemented (defaults of CTranslate2 4.1.0)")
-        mel = self._features(features)
+        mel = self._features(features, input_kind)
         B = mel.shape[0]
         if len(prompts) != B:
             raise ValueError("one prompt per batch item")
@@ -259,8 +270,8 @@ class Whisper:
         """One `wis_generate` call on replica r (the caller serialises access to r)."""
         return _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind)
 
-    def detect_language(self, features):
-        mel = self._features(features)
+    def detect_language(self, features, input_kind=_lib.WIS_IN_MEL_HOST):
+        mel = self._features(features, input_kind)
         B = mel.shape[0]
         n_lang = len(W.LANG_IDS)
         out = []
@@ -270,7 +281,8 @@ class Whisper:
                 for s in range(0, B, self.max_batch):
                     m = mel[s:s + self.max_batch]
                     probs = np.zeros((m.shape[0], n_lang), np.float32)
-                    _lib.check(_lib.load().wis_detect_language(r.handle, _lib.ptr(m), _lib.WIS_IN_MEL_HOST, m.shape[0],
+                    m = np.ascontiguousarray(m)
+                    _lib.check(_lib.load().wis_detect_language(r.handle, _lib.ptr(m), input_kind, m.shape[0],
                                                                probs.ctypes.data_as(C.POINTER(C.c_float))))
                     for row in probs:
                         order = np.argsort(-row, kind="stable")

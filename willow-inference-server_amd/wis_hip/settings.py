@@ -34,9 +34,17 @@ class APISettings:
     whisper_model_default: str = "medium"
     cors_allowed_origins: List[str] = field(default_factory=list)
     aiortc_debug: bool = False
-    # --- not in the reference: where the weights come from.  "{size}" is substituted; a directory path selects a
-    # CTranslate2 model dir (models/tovera-wis-whisper-*, utils.sh:99-108), "synthetic:{size}" seeded synthetic weights.
-    whisper_model_path: str = "synthetic:{size}"
+    # --- not in the reference: where the weights come from.  "{size}" is substituted.  The default is the reference's own
+    # model directory layout (models/tovera-wis-whisper-{size}, utils.sh:99-108, main.py:341-444): a CTranslate2 or Hugging
+    # Face checkpoint directory with its tokenizer files; a missing directory is an ERROR at first use.  Seeded synthetic
+    # weights ("synthetic:{size}": benchmarks and tests, no checkpoint exists offline) must be asked for explicitly.
+    whisper_model_path: str = "models/tovera-wis-whisper-{size}"
+    # text output needs the checkpoint's tokenizer (tokenizer.json); without one a real model refuses to load unless this is
+    # set, in which case `text` is the space-joined token ids (synthetic weights always behave that way: ids are the result)
+    allow_token_id_text: bool = False
+    # log-mel on the replica's GPU inside generate (PCM in, mel never leaves HBM) instead of the reference's
+    # mel -> host -> StorageView round trip; results are identical (same kernels)
+    fuse_logmel: bool = True
     max_batch: int = 8
     # "float16" or "int8_float16" (the reference picks int8_float16 on GPUs, main.py:242: here it quantises the decoder weights)
     compute_type: str = "float16"

@@ -43,7 +43,7 @@ class StreamingSession:
         self._lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="wis-stream")
         self._windows = {}            # (start, length) -> Future[list[int]]   window token ids, computed eagerly
-        self._language = None
+        self._language_job = None     # Future: language of the chunked recording (from window 0), resolved exactly once
         self._closed = False
         self.eager_windows = 0        # windows transcribed before stop() (stats / tests)
 
@@ -70,26 +70,28 @@ class StreamingSession:
         task_id = W.TRANSLATE if self.task == "translate" else W.TRANSCRIBE
         return [W.SOT, _Tokenizer.language_token_id(language), task_id, W.NO_TIMESTAMPS]
 
-    def _resolve_language(self, first_window):
-        if self._language is None:
-            s = self.models.settings
-            language = s.language
-            if self.detect_language and not self.force_language:
-                mel = audio.log_mel_spectrogram(audio.pad_or_trim(first_window)).numpy()[None]
-                res = self._whisper.detect_language(ctranslate2.StorageView.from_array(np.ascontiguousarray(mel)))
-                language = res[0][0][0].strip("<|>")
-            elif self.force_language:
-                language = self.force_language
-            if not check_language(language):
-                raise ValueError(f"unsupported language {language!r}")
-            self._language = language
-        return self._language
+    def _detect(self, first_window):
+        """What do_whisper does on `mel_features[0:1]` (main.py:637-643): language of the FIRST window only."""
+        s = self.models.settings
+        language = s.language
+        if self.detect_language and not self.force_language:
+            x = np.ascontiguousarray(audio.pad_or_trim(first_window)[None], np.float32)
+            res = self._whisper.detect_language(ctranslate2.StorageView.from_array(x), input_kind=ctranslate2._lib.WIS_IN_PCM_HOST)
+            language = res[0][0][0].strip("<|>")
+        elif self.force_language:
+            language = self.force_language
+        if not check_language(language):
+            raise ValueError(f"unsupported language {language!r}")
+        return language
 
-    def _window_tokens(self, piece, beam):
-        language = self._resolve_language(piece)
-        mel = audio.log_mel_spectrogram(audio.pad_or_trim(piece)).numpy()[None]
-        r = self._whisper.generate(ctranslate2.StorageView.from_array(np.ascontiguousarray(mel)), [self._prompt(language)], beam_size=beam,
-                                   return_scores=False, fixed_new_tokens=self.fixed_new_tokens)
+    def _window_tokens(self, piece, beam, language):
+        """`language`: a code, or a Future resolving to one (the session-wide language job of window 0: every eager window
+        waits for THAT result, so a later window can never decide the language - do_whisper always detects on window 0)."""
+        if hasattr(language, "result"):
+            language = language.result()
+        x = np.ascontiguousarray(audio.pad_or_trim(piece)[None], np.float32)
+        r = self._whisper.generate(ctranslate2.StorageView.from_array(x), [self._prompt(language)], beam_size=beam,
+                                   return_scores=False, fixed_new_tokens=self.fixed_new_tokens, input_kind=ctranslate2._lib.WIS_IN_PCM_HOST)
         return r[0].sequences_ids[0]
 
     def _schedule_complete_windows(self):
@@ -104,7 +106,9 @@ class StreamingSession:
             key = (start, audio.chunk_len)
             if key not in self._windows:
                 piece = self._pcm[start:start + audio.chunk_len].copy()
-                self._windows[key] = self._pool.submit(self._window_tokens, piece, s.long_beam_size)
+                if self._language_job is None:         # start == 0 here: the chunked call detects on exactly this window
+                    self._language_job = self._pool.submit(self._detect, piece)
+                self._windows[key] = self._pool.submit(self._window_tokens, piece, s.long_beam_size, self._language_job)
                 self.eager_windows += 1
             start += _STEP
 
@@ -118,19 +122,25 @@ class StreamingSession:
         s = self.models.settings
         duration_ms = int(pcm.shape[0] / audio.SAMPLE_RATE * 1000)
         beam = s.long_beam_size if duration_ms >= s.long_beam_size_threshold else self.beam_size
+        tokenizer = self.models.tokenizer_for(self.model_name)
         if duration_ms > 30 * 1000 and s.support_chunking:
+            with self._lock:
+                if self._language_job is None:     # chunking disabled while feeding, or a burst longer than 30 s fed at once
+                    self._language_job = self._pool.submit(self._detect, pcm[:audio.chunk_len].copy())
+            language = self._language_job.result()
             seqs = []
             for piece, stride in audio.chunk_iter(pcm):
                 start = len(seqs) * _STEP
                 fut = self._windows.get((start, piece.shape[0]))
-                ids = fut.result() if fut is not None else self._window_tokens(piece, beam)
+                ids = fut.result() if fut is not None else self._window_tokens(piece, beam, language)
                 seqs.append((ids, stride))
-            tokens = [int(t) for t in audio.find_longest_common_sequence(seqs, self.models.tokenizer)]
+            tokens = [int(t) for t in audio.find_longest_common_sequence(seqs, tokenizer)]
         else:
-            tokens = self._window_tokens(pcm, beam)
-        text = self.models.tokenizer.decode(tokens).strip()
+            language = self._detect(pcm)           # short recording: one window = the whole audio; nothing is cached, a later
+            tokens = self._window_tokens(pcm, beam, language)      # (longer) call detects again on its own first window
+        text = tokenizer.decode(tokens).strip()
         ms = (time.perf_counter() - t0) * 1000
-        out = WhisperResult((self._language, text, ms, None, math.floor(duration_ms / ms) if ms > 0 else 0, duration_ms))
+        out = WhisperResult((language, text, ms, None, math.floor(duration_ms / ms) if ms > 0 else 0, duration_ms))
         out.tokens = tokens
         return out
 

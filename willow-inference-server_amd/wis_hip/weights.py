@@ -162,12 +162,19 @@ def build_arena(weights):
     return arena, index
 
 
-def read_ct2_model_bin(path):
+def read_ct2_model_bin(path, return_attrs=False):
     """Reader for a CTranslate2 `model.bin` (binary version 6, WhisperSpec; layout per SURVEY Appendix C — written from
-    recall of CTranslate2 4.1.0, unverified offline).  Returns name -> ndarray.  int8 variables are rejected: WIS's models
-    were exported with --quantization float16 (utils.sh:71,104)."""
-    dtypes = {0: np.float32, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.float16}
-    out, aliases = {}, {}
+    recall of CTranslate2 4.1.0, unverified offline).  Returns name -> float ndarray (and, with return_attrs, the integer
+    attribute variables).
+
+    A real WhisperSpec file also carries non-tensor variables: rank-0 scalars such as `encoder/num_heads`,
+    `decoder/num_heads` (int16), `decoder/alignment_layer` / `alignment_heads` (int16), `decoder/activation` (int8) and int8
+    flags (`pre_norm`, `scale_embeddings`, ...).  They are attributes, not weights: they are collected separately and never
+    reach the arena.  What IS rejected is a quantised weight MATRIX (int8 / int16 of rank >= 1 with a companion
+    `weight_scale`): WIS's models are exported with --quantization float16 (utils.sh:71,104); this engine quantises the
+    decoder itself for compute_type int8_float16."""
+    dtypes = {0: np.float32, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.float16, 5: "bfloat16"}
+    out, attrs, aliases = {}, {}, {}
     with open(path, "rb") as f:
         def rd(fmt):
             return struct.unpack("<" + fmt, f.read(struct.calcsize("<" + fmt)))
@@ -182,6 +189,7 @@ def read_ct2_model_bin(path):
         if "Whisper" not in spec:
             raise ValueError(f"{path}: spec {spec!r} is not a Whisper model")
         (nvar,) = rd("I")
+        scaled = set()
         for _ in range(nvar):
             name = rstr()
             (rank,) = rd("B")
@@ -189,16 +197,35 @@ def read_ct2_model_bin(path):
             (dt,) = rd("B")
             (nb,) = rd("I")
             raw = f.read(nb)
-            if dt not in dtypes or dtypes[dt] in (np.int8, np.int16):
-                raise ValueError(f"{name}: quantised dtype id {dt} not supported (need float16/float32 export)")
-            out[name] = np.frombuffer(raw, dtype=dtypes[dt]).reshape(dims).copy()
+            if dt not in dtypes:
+                raise ValueError(f"{name}: unknown dtype id {dt}")
+            if dtypes[dt] == "bfloat16":
+                v = (np.frombuffer(raw, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(dims).copy()
+            else:
+                v = np.frombuffer(raw, dtype=dtypes[dt]).reshape(dims).copy()
+            if name.endswith("weight_scale"):
+                scaled.add(name[:-len("_scale")])
+                continue
+            if v.dtype.kind == "i":
+                if v.size <= 64 and not name.endswith("/weight"):          # scalar / small integer attribute
+                    attrs[name] = v
+                    continue
+                raise ValueError(f"{name}: int{8 * v.dtype.itemsize} weight matrix {tuple(dims)} - quantised exports are not supported "
+                                 "(re-export with --quantization float16, utils.sh:104)")
+            out[name] = v
+        for n in scaled:
+            if n in out and out[n].dtype.kind != "f":
+                raise ValueError(f"{n}: quantised export")
         (nal,) = rd("I")
         for _ in range(nal):
             al = rstr()
             aliases[al] = rstr()
     for al, tgt in aliases.items():
-        out.setdefault(al, out[tgt])
-    return out
+        if tgt in out:
+            out.setdefault(al, out[tgt])
+        elif tgt in attrs:
+            attrs.setdefault(al, attrs[tgt])
+    return (out, attrs) if return_attrs else out
 
 
 def write_ct2_model_bin(path, weights, spec="WhisperSpec", revision=3, aliases=None):
@@ -214,7 +241,9 @@ def write_ct2_model_bin(path, weights, spec="WhisperSpec", revision=3, aliases=N
         wstr(f, spec)
         f.write(struct.pack("<II", revision, len(weights)))
         for name, v in weights.items():
-            v = np.ascontiguousarray(v)
+            v = np.asarray(v)
+            if v.ndim and not v.flags["C_CONTIGUOUS"]:
+                v = np.ascontiguousarray(v)          # (ascontiguousarray would promote a rank-0 attribute to rank 1)
             wstr(f, name)
             f.write(struct.pack("<B", v.ndim) + struct.pack("<" + "I" * v.ndim, *v.shape))
             f.write(struct.pack("<BI", ids[v.dtype], v.nbytes))
@@ -381,7 +410,7 @@ def load_model_dir(path):
     (`model.bin` + `config.json` with suppress_ids / suppress_ids_begin / lang_ids; utils.sh:99-108, main.py:341-444) and a
     Hugging Face checkpoint (`model.safetensors`)."""
     if os.path.exists(os.path.join(path, "model.bin")):
-        w = read_ct2_model_bin(os.path.join(path, "model.bin"))
+        w, attrs = read_ct2_model_bin(os.path.join(path, "model.bin"), return_attrs=True)
         if "encoder/position_encodings/encodings" not in w:
             w["encoder/position_encodings/encodings"] = sinusoids(N_AUDIO_CTX, w["decoder/embeddings/weight"].shape[1])
         w["encoder/position_encodings/encodings"] = np.ascontiguousarray(w["encoder/position_encodings/encodings"], np.float32)
@@ -394,7 +423,8 @@ def load_model_dir(path):
             with open(cj) as f:
                 cj = json.load(f)
             cfg = {k: cj[k] for k in ("suppress_ids", "suppress_ids_begin", "lang_ids") if k in cj}
-        return w, arch_from_weights(w), cfg
+        heads = attrs.get("decoder/num_heads", attrs.get("encoder/num_heads"))
+        return w, arch_from_weights(w, int(np.asarray(heads).reshape(-1)[0]) if heads is not None else None), cfg
     if os.path.exists(os.path.join(path, "model.safetensors")) or os.path.exists(os.path.join(path, "model.safetensors.index.json")):
         return load_hf_dir(path)
     raise FileNotFoundError(f"{path}: neither a CTranslate2 (model.bin) nor a Hugging Face (model.safetensors) Whisper directory")

@@ -30,6 +30,7 @@ SPECIAL_IDS = list(range(W.EOT, W.N_VOCAB))     # <|endoftext|> ... timestamps: 
 class WhisperResult(tuple):
     """6-tuple like the reference's return value, plus the raw token ids."""
     tokens = None
+    translation_tokens = None
 
 
 class _Tokenizer:
@@ -41,7 +42,13 @@ class _Tokenizer:
             from tokenizers import Tokenizer
             self._tok = Tokenizer.from_file(os.path.join(path, "tokenizer.json"))
 
+    @property
+    def has_vocabulary(self):
+        return self._tok is not None
+
     def decode(self, ids):
+        """`WhisperProcessor.decode(tokens)` (main.py:714): the ids generate returns carry no special tokens besides what the
+        model emitted itself; they are kept (skip_special_tokens defaults to False there too)."""
         ids = [int(t) for t in ids]
         if self._tok is not None:
             return self._tok.decode(ids, skip_special_tokens=False)
@@ -61,7 +68,8 @@ class WhisperModels:
         self._models, self._lock = {}, threading.Lock()
         n = ctranslate2._lib.device_count()
         self.device_index = list(range(n)) if device_index is None else list(device_index)
-        self.tokenizer = _Tokenizer(None)
+        self.tokenizer = _Tokenizer(None)      # id-only tokenizer (synthetic weights); real checkpoints get their own below
+        self.tokenizers = {}
 
     def path_for(self, size):
         return self.settings.whisper_model_path.format(size=size)
@@ -72,12 +80,26 @@ class WhisperModels:
         with self._lock:
             if size not in self._models:
                 path = self.path_for(size)
+                synthetic = path.startswith("synthetic:")
+                if not synthetic:
+                    if not os.path.isdir(path):
+                        raise FileNotFoundError(
+                            f"Whisper model directory {path!r} not found (setting whisper_model_path; the reference layout is "
+                            "models/tovera-wis-whisper-<size>).  Seeded synthetic weights are only served when asked for explicitly: "
+                            "whisper_model_path=synthetic:{size}")
+                    tok = _Tokenizer(path)
+                    if not tok.has_vocabulary and not self.settings.allow_token_id_text:
+                        raise FileNotFoundError(f"{path}: no tokenizer.json - text output needs the checkpoint's tokenizer (the reference "
+                                                "loads WhisperProcessor from the model dir, main.py:329-334); set allow_token_id_text=1 to serve "
+                                                "token ids as text")
+                    self.tokenizers[size] = tok
                 self._models[size] = ctranslate2.models.Whisper(path, device="cuda", compute_type=self.settings.compute_type,
                                                                 inter_threads=self.settings.ctranslate2_threads,
                                                                 device_index=self.device_index, max_batch=self.settings.max_batch)
-                if os.path.isdir(path):
-                    self.tokenizer = _Tokenizer(path)
             return self._models[size]
+
+    def tokenizer_for(self, size):
+        return self.tokenizers.get(size, self.tokenizer)
 
     def preload(self):
         s = self.settings
@@ -142,15 +164,23 @@ def do_whisper(audio_file, model, beam_size=None, task="transcribe", detect_lang
         for chunk, stride in audio.chunk_iter(pcm):
             windows.append(audio.pad_or_trim(chunk))
             strides.append(stride)
-        mel_features = audio.log_mel_spectrogram(np.stack(windows)).numpy()
+        windows = np.stack(windows)
     else:
-        mel_features = audio.log_mel_spectrogram(audio.pad_or_trim(pcm)).numpy()[None]
-    total_chunk_count = mel_features.shape[0]
+        windows = audio.pad_or_trim(pcm)[None]
+    if s.fuse_logmel:
+        # the 30 s PCM windows go to the replica as they are: log-mel runs on THAT replica's GPU inside generate and the
+        # features never leave HBM (WIS_IN_PCM_HOST) - same kernels, same results as the two-step form below
+        features, kind = np.ascontiguousarray(windows, np.float32), ctranslate2._lib.WIS_IN_PCM_HOST
+    else:
+        # the reference's two-step form (main.py:606-614, 685): features to the host, then StorageView.from_array
+        features, kind = audio.log_mel_spectrogram(windows).numpy(), ctranslate2._lib.WIS_IN_MEL_HOST
+    total_chunk_count = features.shape[0]
+    tokenizer = models.tokenizer_for(model)
 
     # STEP 2 — language
     language = s.language
     if detect_language and not force_language:
-        results = whisper_model.detect_language(ctranslate2.StorageView.from_array(np.ascontiguousarray(mel_features[0:1])))
+        results = whisper_model.detect_language(ctranslate2.StorageView.from_array(np.ascontiguousarray(features[0:1])), input_kind=kind)
         lang_token, _probability = results[0][0]
         language = lang_token.strip("<|>")
     elif force_language:
@@ -162,28 +192,32 @@ def do_whisper(audio_file, model, beam_size=None, task="transcribe", detect_lang
 
     # STEP 3 — run the model, `concurrent_gpu_chunks` windows per generate call
     results = []
-    for batch in chunkit(mel_features, s.concurrent_gpu_chunks):
+    for batch in chunkit(features, s.concurrent_gpu_chunks):
         feats = ctranslate2.StorageView.from_array(np.ascontiguousarray(batch))
         results.extend(whisper_model.generate(feats, [prompt] * len(batch), beam_size=beam_size, return_scores=False,
-                                              fixed_new_tokens=fixed_new_tokens))
+                                              fixed_new_tokens=fixed_new_tokens, input_kind=kind))
     assert len(results) == total_chunk_count, "Result length doesn't match expected total_chunk_count"
     if use_chunking:
         tokens = audio.find_longest_common_sequence([(results[i].sequences_ids[0], strides[i]) for i in range(total_chunk_count)],
-                                                    models.tokenizer)
+                                                    tokenizer)
         tokens = [int(t) for t in tokens]
     else:
         tokens = results[0].sequences_ids[0]
-    text = models.tokenizer.decode(tokens).strip()
+    text = tokenizer.decode(tokens).strip()
 
     translation = None
-    if translate and total_chunk_count <= s.concurrent_gpu_chunks:
+    if translate and total_chunk_count <= s.concurrent_gpu_chunks:       # main.py:729-748 (its `len(int)` bug aside: short audio only)
         tprompt = [W.SOT, _Tokenizer.language_token_id(language), W.TRANSLATE, W.NO_TIMESTAMPS]
-        feats = ctranslate2.StorageView.from_array(np.ascontiguousarray(mel_features))
-        tres = whisper_model.generate(feats, [tprompt] * total_chunk_count, beam_size=beam_size)
-        translation = models.tokenizer.decode(tres[0].sequences_ids[0]).strip()
+        feats = ctranslate2.StorageView.from_array(np.ascontiguousarray(features))
+        tres = whisper_model.generate(feats, [tprompt] * total_chunk_count, beam_size=beam_size, fixed_new_tokens=fixed_new_tokens, input_kind=kind)
+        translation = tokenizer.decode(tres[0].sequences_ids[0]).strip()
+        out_translation_tokens = tres[0].sequences_ids[0]
+    else:
+        out_translation_tokens = None
 
     infer_time_milliseconds = (time.perf_counter() - first_time_start) * 1000
     infer_speedup = math.floor(audio_duration / infer_time_milliseconds)
     out = WhisperResult((language, text, infer_time_milliseconds, translation, infer_speedup, audio_duration))
     out.tokens = tokens
+    out.translation_tokens = out_translation_tokens
     return out
