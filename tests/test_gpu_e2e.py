@@ -87,6 +87,7 @@ def test_teacher_forced_logits(which, request, mels, lib):
 
 
 def _check_generate(model, ref, mel, beam, fixed_new, max_new=0):
+    """-> number of utterances whose ids are IDENTICAL to the oracle's (asserted wherever the margin rule forces them)."""
     from wis_hip import ctranslate2 as ct2, weights as W
     feats = ct2.StorageView.from_array(mel)
     kw = dict(beam_size=beam, fixed_new_tokens=fixed_new)
@@ -97,10 +98,11 @@ def _check_generate(model, ref, mel, beam, fixed_new, max_new=0):
                                          fixed_new=fixed_new, max_new_tokens=max_new, return_trace=True)
         got, gscore = res[b].sequences_ids[0], res[b].scores[0]
         margin = min(trace) if trace else 1.0
-        print(f"  utt {b} beam {beam}: oracle len {len(ids)} score {score:.5f} min-margin {margin:.4f} | hip len {len(got)} score {gscore:.5f}")
-        if margin > MARGIN:
-            assert got == ids, (got, ids)
-            n_exact += 1
+        print(f"  utt {b} beam {beam}: oracle len {len(ids)} score {score:.5f} decision margin {margin:.4f} (all-gaps {min(ref.last_trace_full):.4f}) | "
+              f"hip len {len(got)} score {gscore:.5f} | identical {got == ids}")
+        if margin > MARGIN or min(ref.last_trace_full) > MARGIN:
+            assert got == ids, (got, ids)          # every decision of the oracle's search is forced: ids must be identical
+        n_exact += got == ids
         assert abs(gscore - score) <= 1e-2
         assert all(0 <= t < 51865 for t in got) and W.EOT not in got
     return n_exact

@@ -212,9 +212,8 @@ def test_rest_interleaved_clips_from_32_clients(golden_dir, fuse):
         assert j["audio_duration"] == exp[5]
         if j["text"] != exp[1]:
             wrong += 1
-            own = sum(a == b for a, b in zip(j["text"].split(), exp[1].split()))
-            other = max(sum(a == b for a, b in zip(j["text"].split(), serial[o][1].split())) for o in names if o != names[i % 3])
-            assert own > other, (i, names[i % 3])         # a near-tie flip keeps the common prefix of its own clip
+            # a request that received another request's audio / features would return THAT clip's answer
+            assert all(j["text"] != serial[o][1] for o in names if o != names[i % 3]), (i, names[i % 3])
     print(f"interleaved REST (fuse_logmel={fuse}): {wrong} of 32 responses differ from their serial answer")
     assert wrong <= 3
 
@@ -254,7 +253,17 @@ def test_translate_and_tokenizer_branches(tmp_path, golden_dir):
     x = np.ascontiguousarray(audio.pad_or_trim(audio.load_audio(clip)[0])[None])
     direct = models.get("tiny").generate(ct2.StorageView.from_array(x), [[W.SOT, W.LANG_IDS[0], W.TRANSLATE, W.NO_TIMESTAMPS]], beam_size=5,
                                          fixed_new_tokens=7, input_kind=ct2._lib.WIS_IN_PCM_HOST)[0]
-    assert direct.sequences_ids[0] == res.translation_tokens and res.translation_tokens != res.tokens
+    assert direct.sequences_ids[0] == res.translation_tokens
+    # (the seeded random model barely listens to its prompt, so the ids of the two tasks may coincide: check the prompts themselves)
+    seen = []
+    mdl = models.get("tiny")
+    real_generate = mdl.generate
+    mdl.generate = lambda f, prompts, **kw: (seen.append([list(p) for p in prompts]), real_generate(f, prompts, **kw))[1]
+    try:
+        do_whisper(clip, "tiny", 5, "transcribe", False, "en", translate=True, models=models, fixed_new_tokens=3)
+    finally:
+        mdl.generate = real_generate
+    assert seen == [[[W.SOT, W.LANG_IDS[0], W.TRANSCRIBE, W.NO_TIMESTAMPS]], [[W.SOT, W.LANG_IDS[0], W.TRANSLATE, W.NO_TIMESTAMPS]]]
     # task="translate" puts the translate token into the main prompt (main.py:656-663)
     t2 = do_whisper(clip, "tiny", 5, "translate", False, "en", models=models, fixed_new_tokens=7)
     assert t2.tokens == res.translation_tokens and t2[3] is None

@@ -774,8 +774,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // one round: thread = (row r, dh pair); plain (pipelined) loads, made safe by the agent-scope acquire that lane 0
   // executed after winning the ticket (guide §6 G16 consumer form: relaxed ticket -> ONE acquire -> barrier -> plain loads;
   // 8-byte sc1 buffer loads were measured 4x slower than this on MI355X)
-  if (tid < R * 32) {
-    const int r = tid >> 5, dp = tid & 31;
+  // (R <= 16 rows x 32 dh pairs = up to 512 items over the 256 threads: the merged prefill pass of a long prompt has more than 8
+  // rows per utterance - the op-level test at R = 16 found rows 8..15 uncombined when this was a single `if (tid < R * 32)`)
+  for (int item = tid; item < R * 32; item += 256) {
+    const int r = item >> 5, dp = item & 31;
     float2 ml[16], ov[16];
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
