@@ -44,33 +44,41 @@ def _run(cmd):
         sys.stderr.write(r.stderr)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, extra_flags=()):
+    """variant: tuning builds next to the product library (lib/libwis_hip_<variant>.so, selected at run time with
+    WIS_LIB_PATH; objects under build/<variant>/) compiled with `extra_flags` on top of the product flags."""
+    objdir = os.path.join(OBJDIR, variant) if variant else OBJDIR
+    lib = os.path.join(LIBDIR, f"libwis_hip_{variant}.so") if variant else LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     objs = []
+    hip_flags = HIP_FLAGS + list(extra_flags)
     for src in HIP_SOURCES + C_SOURCES:
         path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJDIR, src + ".o")
+        obj = os.path.join(objdir, src + ".o")
         stamp = obj + ".sha"
-        dig = _digest([path] + hdrs)
+        dig = _digest([path] + hdrs) + "|" + " ".join(extra_flags)
         if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dig:
             if verbose:
                 print("[build] compiling", src, flush=True)
             if src.endswith(".c"):
                 _run(["gcc"] + C_FLAGS + ["-c", path, "-o", obj])
             else:
-                _run([HIPCC] + HIP_FLAGS + ["-c", path, "-o", obj])
+                _run([HIPCC] + hip_flags + ["-c", path, "-o", obj])
             with open(stamp, "w") as f:
                 f.write(dig)
         objs.append(obj)
     newest = max(os.path.getmtime(o) for o in objs)
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
         if verbose:
-            print("[build] linking", os.path.relpath(LIB, ROOT), flush=True)
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
-    return LIB
+            print("[build] linking", os.path.relpath(lib, ROOT), flush=True)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    # python build.py [--force] [--variant NAME -DFLAG ...]
+    argv = sys.argv[1:]
+    var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
+    print(build(force="--force" in argv, variant=var, extra_flags=[a for a in argv if a.startswith("-D") or a.startswith("-m")]))

@@ -190,6 +190,14 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 // the MFMA loop are straight-line code (every runtime `u < S` guard would be a scalar branch around one load); SC = 0 is the
 // generic ring of 16 fragments with refill.
 
+// WIS_EP_EARLY (build flag, default 0): request the epilogue operands (bias, folded column sums, row scales, residual / KV-cache
+// slot) right BEHIND the weight prefetch instead of after the last MFMA (vmcnt retires in order, so they cannot delay the
+// activations or a weight fragment).  Measured on MI355X (round 2, build.py --variant, tools/run_r2c.sh): 33.12 vs 32.82 ms per
+// utterance at B = 1, 97.8 vs 97.7 ms at B = 8 - no gain: the epilogue round trip is already hidden behind the cross-wave
+// reduction, and the extra 15-18 live VGPRs cost as much as they save.  The late form stays the product default.
+#ifndef WIS_EP_EARLY
+#define WIS_EP_EARLY 0
+#endif
 // MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
 template <int MB, int MODE, int SC, int RM, bool W8>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
@@ -262,6 +270,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     for (int u = 0; u < GV_PF; ++u) { wf[u] = wzero; if ((SC > 0 || u < S) && wact) wf[u] = __builtin_nontemporal_load(wq + (size_t)u * wstep); }
   }
 
+  // epilogue operands (bias, folded column sums, row scales, residual, KV-cache row)
+  const bool ep_act = tid < MB * 64;
+  const int ep_m = (tid >> 6) * 16 + (lane & 15), ep_n = rows * nt + 4 * (lane >> 4);
+  const bool ep_ok = ep_act && ep_m < M && ep_n < p.N && 4 * (lane >> 4) < rows;
+  float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+  int ep_slot = 0, ep_pos = 0;
+#define WIS_EP_LOADS()                                                                                              \
+  if (ep_ok) {                                                                                                      \
+    if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);                                          \
+    if (fast) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);                                              \
+    if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);                                              \
+    if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }                    \
+    else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n); \
+  }
+  constexpr bool ep_early = WIS_EP_EARLY && MB == 1 && SC > 0;    // single chunk, every weight fragment already requested
+  if (ep_early) { WIS_EP_LOADS() }
   stamp(pf, 1);
   float sa[RMAX], sb[RMAX];
   if (fast) {
@@ -358,21 +382,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
     }
   }
   stamp(pf, 4);
-  // epilogue operands (bias, folded column sums, row scales, residual, KV-cache row): requested NOW - every weight fragment has
-  // been consumed, so they cannot hold up the in-order vmcnt queue - and covered by the reductions and the barrier below
-  // (requested at kernel start they delayed the activation / weight loads and cost more than they saved)
-  const bool ep_act = tid < MB * 64;
-  const int ep_m = (tid >> 6) * 16 + (lane & 15), ep_n = rows * nt + 4 * (lane >> 4);
-  const bool ep_ok = ep_act && ep_m < M && ep_n < p.N && 4 * (lane >> 4) < rows;
-  float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
-  int ep_slot = 0, ep_pos = 0;
-  if (ep_ok) {
-    if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
-    if (fast) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);
-    if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);
-    if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }
-    else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n);
-  }
+  // (late form: requested NOW - every weight fragment has been consumed, so they cannot hold up the in-order vmcnt queue - and
+  // covered by the reductions and the barrier below; requested BEFORE the activations they delayed them and cost more than they saved)
+  if (!ep_early) { WIS_EP_LOADS() }
+#undef WIS_EP_LOADS
   if (fast) {   // LayerNorm statistics of the folded form: reduced here, behind the MFMAs, published with the accumulators
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -501,6 +514,196 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 }
 
 // =======================================================================================
+// Batched decode rows (8 < M <= 48): skinny GEMM on activation FRAGMENT images.  grid = Npad/16 workgroups of 4 waves; wave w owns
+// the k-steps [w*S, (w+1)*S), S = K/128.  Per k-step a wave issues ONE 1 KiB weight fragment load (HBM, non-temporal) and MB
+// 1 KiB activation fragment loads (L2: the image is 40-120 KiB and every workgroup reads it), PF k-steps ahead of the MFMAs -
+// no LDS staging of the activations, no staging barrier, 12 KiB of LDS (the cross-wave reduction) so several workgroups share a CU
+// (the LDS-staged form held 103 KiB per workgroup: one workgroup per CU, two dispatch rounds for the 320-tile FFN1).
+// LayerNorm (GV_LN): the projection is stored folded (W o gamma, b + W.beta, column sums c); mean / rstd of a row come from the
+// per-16-column partial sums the producing residual epilogue left in stat_in (summed in a fixed order: deterministic):
+//   y = rs * (W'x - mu * c) + b'.
+// Residual epilogues (GV_RESID) write the fp32 rows in place, their f16 fragment image for the next projection and the partials.
+template <int MB, int PF, bool W8>
+__global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
+  typedef typename WFrag<W8>::T WT;
+  __shared__ __attribute__((aligned(16))) float red[4 * MB * 64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockIdx.x;
+  const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps >> 2;
+  const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * ksteps + (size_t)wave * S) * 64 + lane;
+  const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)wave * S * MB * 64 + lane;
+  WT a[PF]; u32x4 b[PF][MB];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    if (u < S) {
+      a[u] = __builtin_nontemporal_load(wq + (size_t)u * 64);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(u * MB + mb) * 64];
+    }
+  }
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < S; base += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (base + u < S) {
+        const f16x8 av = WFrag<W8>::cvt(a[u]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, *reinterpret_cast<const f16x8*>(&b[u][mb]), acc[mb], 0, 0, 0);
+        const int nx = base + u + PF;
+        if (nx < S) {
+          a[u] = __builtin_nontemporal_load(wq + (size_t)nx * 64);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(nx * MB + mb) * 64];
+        }
+      }
+    }
+  }
+  // epilogue operands: requested behind the whole stream, covered by the reduction barrier
+  const int ep_mb = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const bool ep_act = tid < MB * 64;
+  const int ep_m = ep_mb * 16 + l15, ep_n = 16 * nt + 4 * kq;
+  const bool ep_ok = ep_act && ep_m < M && ep_n < p.N;
+  const bool ln = p.flags & GV_LN;
+  float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+  int ep_slot = 0, ep_pos = 0;
+  float s1 = 0.f, s2 = 0.f;
+  if (ep_act) {
+    const int mm = ep_m < M ? ep_m : M - 1;
+    if (ln) {       // this lane sums a quarter of the row's partials (rows >= M: a clamped duplicate, discarded)
+      const int nq = K >> 6;                                  // (K/16) partial pairs per row, a quarter per lane
+      const float2* sp = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4) + (size_t)kq * nq;
+#pragma unroll 4
+      for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; s1 += v.x; s2 += v.y; }
+    }
+    if (ep_ok) {
+      if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
+      if (ln) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);
+      if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);
+      if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }
+      else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    *reinterpret_cast<float4*>(red + ((size_t)(wave * MB + mb) * 64 + lane) * 4) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
+  __syncthreads();
+  if (!ep_act) return;                                        // whole waves: MB * 64 is a multiple of the wave size
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + ep_mb) * 64 + lane) * 4);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
+  if (ln) {     // the four lanes of a row (kq = 0..3) hold a quarter of its sums each: ((q0 + q1) + (q2 + q3)) on every lane
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float invK = 1.0f / (float)K;
+    const float mu = s1 * invK;
+    const float rs = 1.0f / sqrtf(fmaxf(s2 * invK - mu * mu, 0.f) + 1e-5f);
+    s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
+  }
+  s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
+  const int m = ep_m, n = ep_n;
+  if (p.flags & GV_QKV) {
+    if (ep_ok) {
+      const int d = p.d;
+      if (n < d) {
+        *reinterpret_cast<float4*>(p.q + (size_t)m * d + n) = s;
+      } else {
+        const bool isk = n < 2 * d;
+        f16* dst = (isk ? p.kc : p.vc) + ((size_t)ep_slot * p.ctx + ep_pos) * d + (n - (isk ? d : 2 * d));
+        const f16x4 o = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
+        *reinterpret_cast<f16x4*>(dst) = o;
+      }
+    }
+    return;
+  }
+  if (p.flags & GV_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
+  if (p.flags & GV_RESID) {
+    const float4 r = make_float4(ep_res.x + s.x, ep_res.y + s.y, ep_res.z + s.z, ep_res.w + s.w);
+    float t1 = 0.f, t2 = 0.f;
+    if (ep_ok) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = r;
+      if (p.y_xf) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y_xf + xf_index(m, n, p.ymb)) = h; }
+      t1 = (r.x + r.y) + (r.z + r.w); t2 = (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+    }
+    if (p.stat_out) {      // partial sums of this workgroup's 16 columns of row m (all four kq lanes take part in the shuffles)
+      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      if (kq == 0 && ep_m < M && 16 * nt < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt) * 2) = make_float2(t1, t2);
+    }
+    return;
+  }
+  if (!ep_ok) return;
+  if (p.flags & GV_OUT_F32) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = s;
+  } else {
+    const f16x4 h = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
+    f16* yo = reinterpret_cast<f16*>(p.y);
+    *reinterpret_cast<f16x4*>(yo + (p.ymb ? xf_index(m, n, p.ymb) : (size_t)m * p.N + n)) = h;
+  }
+}
+
+int launch_gemv_frag(hipStream_t st, const GemvP& p) {
+  if (p.M < 1 || p.M > MAX_ROWS || p.K % 128 || p.N % 4 || p.xmb != cdiv(p.M, 16)) { set_error("gemv_frag: M=%d N=%d K=%d xmb=%d unsupported", p.M, p.N, p.K, p.xmb); return WIS_E_UNSUPPORTED; }
+  if ((p.flags & GV_LN) && (!p.csum || !p.stat_in)) { set_error("gemv_frag: the folded LayerNorm needs column sums and row partials"); return WIS_E_ARG; }
+  if ((p.flags & GV_RESID) && (p.N % 16)) { set_error("gemv_frag: residual rows need N %% 16 == 0"); return WIS_E_UNSUPPORTED; }
+  const int npad = cdiv(p.N, 16) * 16;
+  dim3 grid(npad / 16), block(256);
+  const bool s10 = p.K == 1280;          // ten k-steps per wave: the whole stream of a wave is requested up front
+#define WIS_GF(MBv) do { \
+    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, 10, true>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, 8, true>), grid, block, 0, st, p); } \
+    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, 10, false>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, 8, false>), grid, block, 0, st, p); } } while (0)
+  if (p.xmb == 1) WIS_GF(1); else if (p.xmb == 2) WIS_GF(2); else WIS_GF(3);
+#undef WIS_GF
+  return WIS_OK;
+}
+
+// rows (fp32 or f16, row-major) -> fragment image + per-16-column partial sums.  grid M, block 256: a thread owns 4 consecutive
+// columns; the partials of a 16-column tile are the sums over 4 adjacent threads, in the same (a+b)+(c+d) order everywhere.
+__device__ __forceinline__ void xf_emit4(float4 v, int m, int col, f16* xf, float* stat, int K, int MB) {
+  if (xf) { const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w}; *reinterpret_cast<f16x4*>(xf + xf_index(m, col, MB)) = h; }
+  if (stat) {
+    float t1 = (v.x + v.y) + (v.z + v.w), t2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    t1 += dpp_f<0xB1>(t1); t2 += dpp_f<0xB1>(t2);       // quad: lanes 4j .. 4j+3 = the four column quads of one 16-column tile
+    t1 += dpp_f<0x4E>(t1); t2 += dpp_f<0x4E>(t2);
+    if ((threadIdx.x & 3) == 0) *reinterpret_cast<float2*>(stat + ((size_t)m * (K >> 4) + (col >> 4)) * 2) = make_float2(t1, t2);
+  }
+}
+__global__ __launch_bounds__(256) void xf_pack_kernel(const void* __restrict__ x, int x_f16, f16* __restrict__ xf, float* __restrict__ stat, int K, int MB) {
+  const int m = blockIdx.x;
+  for (int c4 = threadIdx.x; c4 < (K >> 2); c4 += 256) {     // K % 16 == 0: whole quads of threads stay together
+    float4 v;
+    if (x_f16) { const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(x) + (size_t)m * K + 4 * c4); v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+    else v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)m * K + 4 * c4);
+    xf_emit4(v, m, 4 * c4, xf, stat, K, MB);
+  }
+}
+int launch_xf_pack(hipStream_t st, const void* x, int x_f16, f16* xf, float* stat, int M, int K, int MB) {
+  if (K % 16 || MB < cdiv(M, 16)) { set_error("xf_pack: K=%d MB=%d unsupported", K, MB); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(xf_pack_kernel, dim3(M), dim3(256), 0, st, x, x_f16, xf, stat, K, MB);
+  return WIS_OK;
+}
+__global__ __launch_bounds__(256) void dec_embed_xf_kernel(const f16* __restrict__ emb, const f16* __restrict__ pos_emb, const int* __restrict__ tok,
+                                                           const int* __restrict__ pos, float* __restrict__ x, f16* __restrict__ xf, float* __restrict__ stat, int d, int MB) {
+  const int m = blockIdx.x;
+  const f16* e = emb + (size_t)tok[m] * d;
+  const f16* pe = pos_emb + (size_t)pos[m] * d;
+  for (int c4 = threadIdx.x; c4 < (d >> 2); c4 += 256) {
+    const f16x4 a = *reinterpret_cast<const f16x4*>(e + 4 * c4), b = *reinterpret_cast<const f16x4*>(pe + 4 * c4);
+    const float4 v = make_float4((float)a[0] + (float)b[0], (float)a[1] + (float)b[1], (float)a[2] + (float)b[2], (float)a[3] + (float)b[3]);
+    *reinterpret_cast<float4*>(x + (size_t)m * d + 4 * c4) = v;
+    xf_emit4(v, m, 4 * c4, xf, stat, d, MB);
+  }
+}
+int launch_dec_embed_xf(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, f16* xf, float* stat, int M, int d, int MB) {
+  hipLaunchKernelGGL(dec_embed_xf_kernel, dim3(M), dim3(256), 0, st, emb, pos_emb, tok, pos, x, xf, stat, d, MB);
+  return WIS_OK;
+}
+
+// =======================================================================================
 // x[m] = E[tok[m]] + pos_emb[pos[m]]   (no embedding scale; learned positions) -> fp32
 __global__ void dec_embed_kernel(const f16* __restrict__ emb, const f16* __restrict__ pos_emb, const int* __restrict__ tok,
                                  const int* __restrict__ pos, float* __restrict__ x, int d) {
@@ -524,7 +727,7 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
                                                            const int* __restrict__ pos,
                                                            f16* __restrict__ out, int d, int ctx, int rpu, int sstride, int rmul,
-                                                           unsigned long long* prof) {
+                                                           unsigned long long* prof, int out_mb) {
   __shared__ float red[4][64];
   const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, pl = lane >> 3, c = lane & 7;
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
@@ -606,14 +809,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   __syncthreads();
   stamp(pf, 3);
   const float o = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-  out[(size_t)m * d + h * 64 + lane] = (f16)(o / l_run);
+  out[out_mb ? xf_index(m, h * 64 + lane, out_mb) : (size_t)m * d + h * 64 + lane] = (f16)(o / l_run);
   stamp(pf, 4);
   if (lane == 0) tl_end(prof);
 }
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
-                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof) {
+                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof, int out_mb) {
   if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, out, d, ctx, rpu, sstride, rmul, prof);
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, out, d, ctx, rpu, sstride, rmul, prof, out_mb);
   return WIS_OK;
 }
 
@@ -641,7 +844,7 @@ constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16
 template <int TPW>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
-                                                             int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof) {
+                                                             int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb) {
   __shared__ float ssc[16][257];
   __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
   __shared__ float smax[16][16];
@@ -743,7 +946,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     if (l15 < R) {
       const float inv = 1.0f / ssum[l15];
       const f16x4 o = {(f16)(oacc[0] * inv), (f16)(oacc[1] * inv), (f16)(oacc[2] * inv), (f16)(oacc[3] * inv)};
-      *reinterpret_cast<f16x4*>(out + (size_t)(b * R + l15) * d + h * 64 + dh0) = o;
+      *reinterpret_cast<f16x4*>(out + (out_mb ? xf_index(b * R + l15, h * 64 + dh0, out_mb) : (size_t)(b * R + l15) * d + h * 64 + dh0)) = o;
     }
     return;
   }
@@ -801,20 +1004,20 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     const float inv = 1.0f / L;
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const f16x2 o2 = {(f16)(O0 * inv), (f16)(O1 * inv)};
-    *reinterpret_cast<f16x2*>(out + (size_t)(b * R + r) * d + h * 64 + 2 * dp) = o2;
+    *reinterpret_cast<f16x2*>(out + (out_mb ? xf_index(b * R + r, h * 64 + 2 * dp, out_mb) : (size_t)(b * R + r) * d + h * 64 + 2 * dp)) = o2;
   }
   stamp(pf, 7);
   if (tid == 0) tl_end(prof);
 }
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof) {
+                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb) {
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
-  if (CL <= 128) hipLaunchKernelGGL(dec_cross_attn_kernel<2>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof);
-  else hipLaunchKernelGGL(dec_cross_attn_kernel<4>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof);
+  if (CL <= 128) hipLaunchKernelGGL(dec_cross_attn_kernel<2>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
+  else hipLaunchKernelGGL(dec_cross_attn_kernel<4>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
   return WIS_OK;
 }
 

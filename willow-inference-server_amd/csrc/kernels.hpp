@@ -53,8 +53,27 @@ struct GemvP {
   float* q; f16* kc; f16* vc; const int* slot; const int* pos; int d; int ctx;   // cache [slots][ctx][d]
   unsigned long long* prof;      // optional phase stamps (workgroup 0)
   int rows;                      // weight rows per workgroup tile (16 / 8 / 4; 0 => 16): must match the packing
+  // ---- batched rows (launch_gemv_frag, M > 8): activations live in HBM in MFMA B-fragment order ("xf", xf_index below)
+  int xmb;                       // 16-row blocks of the x fragment image (= ceil(M / 16))
+  const float* stat_in;          // GV_LN: per-row partial sums of the raw fp32 rows, [M][K/16][2] = (sum x, sum x^2) per 16 columns
+  float* stat_out;               // GV_RESID: the same partials of the rows this launch produces, [M][N/16][2]
+  f16* y_xf;                     // GV_RESID: f16 fragment image of the produced rows (next projection's input); f16 output: the output itself
+  int ymb;                       // 16-row blocks of y_xf (0: f16 output stays row-major [M][N])
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
+// Batched decode rows (8 < M <= 48).  The skinny GEMM reads its activations as ready-made MFMA B fragments straight from L2
+// (written in that order by the producing kernel: no per-workgroup LDS staging, no staging barrier, many workgroups per CU), and
+// the pre-LN LayerNorm needs no launch of its own: every residual epilogue leaves per-16-column partial sums of the rows it
+// produced, the folded projection that follows (W o gamma, b + W.beta, column sums) turns them into mean / rstd in its epilogue.
+int launch_gemv_frag(hipStream_t st, const GemvP& p);
+// activation fragment image: element (row m, column k) of an [M][K] matrix, MB = ceil(M / 16) row blocks:
+//   [k / 32][m / 16][lane = (m % 16) + 16 * ((k / 8) % 4)][k % 8]      (one 1 KiB wave load per (k-step, row block))
+__host__ __device__ static inline size_t xf_index(int m, int k, int MB) {
+  return ((size_t)((k >> 5) * MB + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
+}
+// x (fp32 or f16, row-major [M][K]) -> fragment image (+ optional per-16-column partial sums): test taps and the weight-stream tap
+int launch_xf_pack(hipStream_t st, const void* x, int x_f16, f16* xf, float* stat, int M, int K, int MB);
+int launch_dec_embed_xf(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, f16* xf, float* stat, int M, int d, int MB);
 int launch_fold_ln(hipStream_t st, f16* W, const float* gamma, const float* beta, float* bias, float* csum, int N, int K, int n_scale, float qscale);
 int launch_csum8(hipStream_t st, const f16* W, const float* scale, float* csum, int N, int K, int n_scale, float qscale);
 int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* scale, int N, int Npad, int K, int n_scale, float qscale);
@@ -65,12 +84,13 @@ int gemv_rows_for(int N, int K);     // tile height used for an [N][K] decoder m
 
 int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d);
 // logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
+// out_mb: 0 = out is row-major f16 [M][d]; > 0 = fragment image with that many 16-row blocks (batched decode)
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
-                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr);
+                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr, int out_mb = 0);
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr);
+                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0);
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

@@ -116,6 +116,7 @@ struct wis_model {
   size_t kx_lstride = 0, vx_lstride = 0;
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
+  f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
@@ -365,6 +366,13 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->dao, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dh, (size_t)MAX_ROWS * 4 * d));
   WIS_RET(dalloc(m, &m->dln, (size_t)MAX_ROWS * d));
+  {  // fragment images (kernels.hpp xf_index): [K/32][3 row blocks][64][8] f16; zeroed once (rows >= M are never written)
+    const size_t blk = (size_t)(MAX_ROWS / 16) * 64 * 8;
+    WIS_RET(dalloc(m, &m->dxf, (size_t)(d / 32) * blk)); WIS_RET(dalloc(m, &m->daoxf, (size_t)(d / 32) * blk)); WIS_RET(dalloc(m, &m->dhxf, (size_t)(4 * d / 32) * blk));
+    WIS_RET(dalloc(m, &m->dstat, (size_t)MAX_ROWS * (d / 16) * 2));
+    WIS_HIP_CHECK(hipMemsetAsync(m->dxf, 0, (size_t)(d / 32) * blk * 2, m->st)); WIS_HIP_CHECK(hipMemsetAsync(m->daoxf, 0, (size_t)(d / 32) * blk * 2, m->st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->dhxf, 0, (size_t)(4 * d / 32) * blk * 2, m->st));
+  }
   WIS_RET(dalloc(m, &m->logits, (size_t)MAX_ROWS * m->n_vocab_pad));
   WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * 66));
   WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
@@ -466,12 +474,57 @@ static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
 
 // ---- one decoder forward over the current row metadata ---------------------------------
 // sstride / rmul: logical-slot mapping of the rows (decode rows: beam, 1; prefill rows: beam, 0; single rows: 1, 0)
+// Batched rows (8 < M <= 48): every activation a projection reads lives in HBM as an MFMA fragment image, LayerNorm statistics
+// travel as per-16-column partial sums from the residual epilogues (kernels.hpp launch_gemv_frag): 8 launches per layer, no
+// LayerNorm launch, no per-workgroup LDS staging of the activations.
+static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, int chunks) {
+  const wis_config_t& c = m->cfg; hipStream_t st = m->st;
+  const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx, MB = cdiv(M, 16);
+  WIS_RET(launch_dec_embed_xf(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, m->dxf, m->dstat, M, d, MB));
+  auto base = [&](const void* x, const f16* Wp, const float* wscale, const float* bias, int N, int K, int flags) {
+    GemvP g; memset(&g, 0, sizeof(g));
+    g.x = x; g.Wp = Wp; g.wscale = wscale; g.bias = bias; g.M = M; g.N = N; g.K = K; g.flags = flags; g.xmb = MB; g.rows = 16;
+    return g;
+  };
+  for (int l = 0; l < c.n_dec_layers; ++l) {
+    const DecLayerW& w = m->dec[l];
+    GemvP g = base(m->dxf, w.p_qkv, w.s_qkv, w.b_qkv, 3 * d, d, GV_LN | GV_QKV);
+    g.csum = w.c_qkv; g.stat_in = m->dstat; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
+    WIS_RET(launch_gemv_frag(st, g));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB));
+    g = base(m->daoxf, w.p_out, w.s_out, w.b_out, d, d, GV_RESID);
+    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
+    WIS_RET(launch_gemv_frag(st, g));
+    g = base(m->dxf, w.p_cq, w.s_cq, w.b_cq, d, d, GV_LN | GV_OUT_F32);
+    g.csum = w.c_cq; g.stat_in = m->dstat; g.y = m->dq;
+    WIS_RET(launch_gemv_frag(st, g));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB));
+    g = base(m->daoxf, w.p_cout, w.s_cout, w.b_cout, d, d, GV_RESID);
+    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
+    WIS_RET(launch_gemv_frag(st, g));
+    g = base(m->dxf, w.p_f1, w.s_f1, w.b_f1, 4 * d, d, GV_LN | GV_GELU);
+    g.csum = w.c_f1; g.stat_in = m->dstat; g.y = m->dhxf; g.ymb = MB;
+    WIS_RET(launch_gemv_frag(st, g));
+    g = base(m->dhxf, w.p_f2, w.s_f2, w.b_f2, d, 4 * d, GV_RESID);
+    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
+    WIS_RET(launch_gemv_frag(st, g));
+  }
+  if (want_logits) {
+    GemvP g = base(m->dxf, m->p_proj, m->s_proj, m->b_proj, m->n_vocab_pad, d, GV_LN | GV_OUT_F32);
+    g.csum = m->c_proj; g.stat_in = m->dstat; g.y = m->logits;
+    WIS_RET(launch_gemv_frag(st, g));
+  }
+  return WIS_OK;
+}
+
 int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
   static const int env_chunks = getenv("WIS_CROSS_CHUNKS") ? atoi(getenv("WIS_CROSS_CHUNKS")) : 0;
   // 256-key chunks (6 per utterance-head): measured faster than 128-key chunks at every batch size (fewer partials to publish and combine)
   const int chunks = env_chunks ? env_chunks : 6;
+  static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;      // A/B switch: the round-1 batched path (LayerNorm launches + LDS-staged rows)
+  if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
@@ -890,6 +943,9 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   WIS_HIP_CHECK(hipSetDevice(m->device));
   const int d = m->cfg.d_model; hipStream_t st = m->st;
   int launches = 0; double bytes = 0;
+  static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;
+  const bool frag = M > 8 && !no_frag;          // the route dec_forward takes at this row count
+  const int MBf = cdiv(M, 16);
   auto pass = [&](bool count) -> int {
     for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
       const DecLayerW& w = m->dec[l];
@@ -899,20 +955,27 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
         {w.p_f1, w.s_f1, w.b_f1, w.c_f1, 4 * d, d, true},    {w.p_f2, w.s_f2, w.b_f2, nullptr, d, 4 * d, false}};
       for (auto& t : mats) {
         GemvP g; memset(&g, 0, sizeof(g));
-        g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; g.csum = t.cs; g.Wp = t.wp; g.wscale = t.sc; g.bias = t.b;
+        g.csum = t.cs; g.Wp = t.wp; g.wscale = t.sc; g.bias = t.b;
         g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
         g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
-        WIS_RET(launch_ln_gemv(m, st, g));   // (more than 8 rows: LayerNorm runs as its own launch, as in dec_forward)
+        if (frag) { g.x = t.K == d ? (const void*)m->dxf : (const void*)m->dhxf; g.xmb = MBf; g.stat_in = m->dstat; WIS_RET(launch_gemv_frag(st, g)); }
+        else { g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; WIS_RET(launch_ln_gemv(m, st, g)); }   // (more than 8 rows, round-1 route: LayerNorm runs as its own launch)
         if (count) { ++launches; bytes += (double)t.N * t.K * (m->w8 ? 1 : 2); }
       }
     }
     GemvP g; memset(&g, 0, sizeof(g));
-    g.x = m->dx; g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(m->cfg.n_vocab, g.K);
-    WIS_RET(launch_ln_gemv(m, st, g));   // (more than 8 rows: LayerNorm runs as its own launch, as in dec_forward)
+    if (frag) { g.x = m->dxf; g.xmb = MBf; g.stat_in = m->dstat; WIS_RET(launch_gemv_frag(st, g)); }
+    else { g.x = m->dx; WIS_RET(launch_ln_gemv(m, st, g)); }
     if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * (m->w8 ? 1 : 2); }
     return WIS_OK;
   };
+  if (frag) {       // zero rows: fragment image of zeros (allocation state), partial sums of zeros
+    WIS_HIP_CHECK(hipMemsetAsync(m->dxf, 0, (size_t)(d / 32) * (MAX_ROWS / 16) * 64 * 8 * 2, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->dhxf, 0, (size_t)(4 * d / 32) * (MAX_ROWS / 16) * 64 * 8 * 2, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->dstat, 0, (size_t)MAX_ROWS * (d / 16) * 2 * 4, st));
+  }
   WIS_HIP_CHECK(hipMemsetAsync(m->dx, 0, (size_t)MAX_ROWS * d * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->dh, 0, (size_t)MAX_ROWS * 4 * d * 2, st));
   WIS_RET(pass(true));   // warm-up pass (also counts launches / bytes)
@@ -983,13 +1046,12 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
   flags &= ~32;
   if (ln && (!gamma || !beta)) { set_error("wis_op_gemv: flag 8 needs gamma and beta"); return WIS_E_ARG; }
   // the same preparation the model loader does: optional LayerNorm fold into a private copy of W / bias, then packing
-  f16 *wp = nullptr, *wtmp = nullptr, *xn = nullptr; float *wsc = nullptr, *b2 = nullptr, *cs = nullptr;
+  f16 *wp = nullptr, *wtmp = nullptr, *xn = nullptr, *xfr = nullptr; float *wsc = nullptr, *b2 = nullptr, *cs = nullptr, *stt = nullptr;
   int rc = WIS_OK;
   do {
     if (hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Npad * K * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&wtmp), (size_t)N * K * 2) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&b2), (size_t)Npad * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&cs), (size_t)Npad * 4) != hipSuccess ||
-        (w8 && hipMalloc(reinterpret_cast<void**>(&wsc), (size_t)Npad * 4) != hipSuccess) ||
-        (ln && M > 8 && hipMalloc(reinterpret_cast<void**>(&xn), (size_t)M * K * 2) != hipSuccess)) { set_error("wis_op_gemv: out of device memory"); rc = WIS_E_NOMEM; break; }
+        (w8 && hipMalloc(reinterpret_cast<void**>(&wsc), (size_t)Npad * 4) != hipSuccess)) { set_error("wis_op_gemv: out of device memory"); rc = WIS_E_NOMEM; break; }
     hipMemcpyAsync(wtmp, W, (size_t)N * K * 2, hipMemcpyDeviceToDevice, st);
     hipMemsetAsync(b2, 0, (size_t)Npad * 4, st); hipMemsetAsync(cs, 0, (size_t)Npad * 4, st);
     if (bias) hipMemcpyAsync(b2, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, st);
@@ -1000,14 +1062,27 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
     if (w8 && ln && (rc = launch_csum8(st, wtmp, wsc, cs, N, K, 0, 1.f))) break;
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = x; g.csum = ln ? cs : nullptr; g.Wp = wp; g.wscale = wsc; g.bias = (bias || ln) ? b2 : nullptr; g.y = y; g.M = M; g.N = N; g.K = K; g.flags = flags; g.rows = rows;
-    if (ln && M > 8) {      // the product's split path (launch_ln_gemv): plain normalisation, then f16 activations against the folded weights
+    static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;
+    if (M > 8 && !no_frag) {
+      // the product's batched route (dec_forward_frag): activations as a fragment image, LayerNorm statistics as row partials
+      const int MBf = cdiv(M, 16);
+      if (hipMalloc(reinterpret_cast<void**>(&xfr), (size_t)(K / 32) * MBf * 64 * 8 * 2) != hipSuccess ||
+          (ln && hipMalloc(reinterpret_cast<void**>(&stt), (size_t)M * (K / 16) * 2 * 4) != hipSuccess)) { set_error("wis_op_gemv: out of device memory"); rc = WIS_E_NOMEM; break; }
+      hipMemsetAsync(xfr, 0, (size_t)(K / 32) * MBf * 64 * 8 * 2, st);
+      if ((rc = launch_xf_pack(st, x, ln ? 0 : 1, xfr, ln ? stt : nullptr, M, K, MBf))) break;
+      g.x = xfr; g.xmb = MBf; g.stat_in = stt;
+      rc = launch_gemv_frag(st, g);
+      break;
+    }
+    if (ln && M > 8) {      // the round-1 split path (WIS_NO_FRAG): plain normalisation, then f16 activations against the folded weights
+      if (hipMalloc(reinterpret_cast<void**>(&xn), (size_t)M * K * 2) != hipSuccess) { set_error("wis_op_gemv: out of device memory"); rc = WIS_E_NOMEM; break; }
       if ((rc = launch_layernorm(st, reinterpret_cast<const float*>(x), nullptr, nullptr, xn, M, K))) break;
       g.x = xn; g.csum = nullptr; g.flags &= ~GV_LN;
     }
     rc = launch_gemv(st, g);
   } while (0);
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(wp); hipFree(wtmp); hipFree(b2); hipFree(cs); hipFree(wsc); hipFree(xn);
+  hipFree(wp); hipFree(wtmp); hipFree(b2); hipFree(cs); hipFree(wsc); hipFree(xn); hipFree(xfr); hipFree(stt);
   if (rc) return rc;
   if (e != hipSuccess) { set_error("wis_op_gemv: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;

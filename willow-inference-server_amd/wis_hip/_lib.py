@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libwis_hip.so")
+LIB_PATH = os.environ.get("WIS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libwis_hip.so")     # WIS_LIB_PATH: a tuning build (build.py --variant)
 
 WIS_OK = 0
 WIS_IN_MEL_HOST, WIS_IN_MEL_DEV, WIS_IN_PCM_HOST, WIS_IN_PCM_DEV = 0, 1, 2, 3
