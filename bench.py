@@ -94,10 +94,76 @@ def cpu_baseline(size, weights, pcm, beam, fixed_new, audio_ms):
                        f"published CT2-int8 CPU figure: large beam1 3.84 s clip 3344 ms on Threadripper 5955WX (README.md:103)")}
 
 
+def p50(xs):
+    return float(np.median(np.asarray(xs, np.float64)))
+
+
+def decode_step_bytes(a, B, beam, P, steps, w8=False):
+    """Algorithmic HBM bytes of ONE decode step, averaged over the `steps` steps of a run: the decoder weight stream
+    W (6 matrices per layer + the vocabulary projection, read once per step whatever the row count), the cross-attention K/V of
+    every utterance (B * C) and the self-attention cache rows read so far (B * beam * t * s)."""
+    d, L, V = a["d_model"], a["n_layers"], a["n_vocab"]
+    wbytes = 1 if w8 else 2
+    W = (L * 14 * d * d + V * d) * wbytes
+    C = L * 2 * a["n_audio_ctx"] * d * 2
+    s_row = L * 2 * d * 2
+    t_avg = (P - 1) + (steps + 1) / 2.0
+    return W + B * C + B * beam * t_avg * s_row
+
+
+def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms):
+    """The reference's own load shape, client/jmeter-asr.jmx:53-90: `clients` threads, each looping
+    POST /api/asr?task=transcribe&output=json&model=large&beam_size=5&detect_language=False with the 3.84 s clip as the
+    multipart field `audio_file`.  Served by the re-hosted endpoint (wis_hip/server.py) in this process over the ASGI transport
+    (no socket): container decode, micro-batching and the HIP path are all inside the measurement."""
+    import asyncio
+    import httpx
+    from wis_hip import ctranslate2 as ct2
+    from wis_hip.server import create_app
+    from wis_hip.settings import APISettings
+    from wis_hip.whisper import WhisperModels
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.max_batch, s.fixed_new_tokens = 8, fixed_new
+    models = WhisperModels(s, device_index=[dev])
+    model = ct2.Whisper.from_handles([(handle, dev)], a, max_batch=8, max_beam=5)
+    models._models["large"] = model
+    app = create_app(models=models, max_workers=max(64, clients))
+    b = "wisBenchBoundary"
+    body = (f"--{b}\r\nContent-Disposition: form-data; name=\"audio_file\"; filename=\"3sec.flac\"\r\nContent-Type: audio/flac\r\n\r\n").encode() + clip_bytes + f"\r\n--{b}--\r\n".encode()
+    hdr = {"content-type": f"multipart/form-data; boundary={b}"}
+    url = "/api/asr?task=transcribe&output=json&model=large&beam_size=5&detect_language=False"
+    lat = []
+
+    async def client(c):
+        for _ in range(iterations):
+            t = time.perf_counter()
+            r = await c.post(url, content=body, headers=hdr)
+            assert r.status_code == 200, r.text
+            lat.append(1e3 * (time.perf_counter() - t))
+
+    async def go():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis", timeout=600) as c:
+            await asyncio.gather(*[client(c) for _ in range(min(clients, 8))])        # warm-up: one device batch
+            lat.clear()
+            n0 = len(model._batcher.batches)
+            t0 = time.perf_counter()
+            await asyncio.gather(*[client(c) for _ in range(clients)])
+            return time.perf_counter() - t0, [n for _, n in model._batcher.batches[n0:]]
+
+    elapsed, sizes = asyncio.run(go())
+    n = clients * iterations
+    model.close()
+    model._replicas = []          # the handle belongs to the caller
+    return {"load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport",
+            "utterances_per_s": round(n / elapsed, 2), "aggregate_x_realtime": round(n * audio_ms / 1e3 / elapsed, 1),
+            "p50_request_ms": round(p50(lat), 2), "max_request_ms": round(max(lat), 2), "device_batches": sizes[:32], "mean_device_batch": round(float(np.mean(sizes)), 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="large")
     ap.add_argument("--beam", type=int, default=5)
@@ -107,6 +173,8 @@ def main():
                     help="decoder weight storage; the headline number is float16 (int8_float16 mirrors the reference's GPU default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configurations, the batch-8 line, the boundary variants and the REST load replay")
+    ap.add_argument("--rest-clients", type=int, default=64)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,44 +185,68 @@ def main():
     # One HIP runtime per process: torch bundles its own libamdhip64; when torch.cuda is needed (distributed branch) torch must
     # be imported BEFORE libwis_hip.so so that the library's libamdhip64.so.7 dependency resolves to the runtime torch loaded.
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    backend = os.environ.get("WIS_DIST_BACKEND", "nccl")          # "gloo": CPU dry-run of this branch (tests/test_dist_cpu.py)
+    dry = use_dist and backend == "gloo"
     if use_dist:
         import torch  # noqa: F401
     from wis_hip import _lib, audio, ctranslate2 as ct2, weights as W
-    lib = _lib.load()
-    _lib.require_gpu()
-    dev = local_rank
-
-    # launched by torch.distributed.run (RANK set) -> always take the distributed branch, even with one rank, so that the
-    # RCCL init / weight broadcast / device-arena hand-off is the same code at every N
+    from wis_hip import dist as wdist
+    extras = world == 1 and not args.no_extras and not dry and (args.model, args.beam, args.clip, args.batch) == ("large", 5, "3sec", 1)
     dist = torch = None
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    if not dry:
+        lib = _lib.load()
+        _lib.require_gpu()
+    dev = local_rank
+
+    # launched by torch.distributed.run (RANK set) -> always take the distributed branch, even with one rank, so that the
+    # RCCL init / weight broadcast / device-arena hand-off is the same code at every N
+    if use_dist:
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     a = W.arch(args.model)
+    max_batch = max(args.batch, 8 if extras else 1)
     t0 = time.perf_counter()
     weights = None
     if not use_dist:
         weights = W.synthetic_weights(args.model, seed=1234)
         arena, index = W.build_arena(weights)
-        handle = ct2.create_handle(a, arena, index, dev, max_batch=max(args.batch, 1), max_beam=max(args.beam, 1),
+        handle = ct2.create_handle(a, arena, index, dev, max_batch=max_batch, max_beam=max(args.beam, 1),
                                    weight_bits=8 if args.compute_type == "int8_float16" else 16)
         del arena
     else:
-        # one-time RCCL broadcast of the weight arena from rank 0 over xGMI; no collective at request time
+        # one-time broadcast of the weight arena from rank 0 (RCCL over xGMI; no collective at request time): only rank 0
+        # generates / holds the weights, every other rank computes the layout from the shapes alone
         index, total = W.synthetic_layout(args.model)
-        buf = torch.empty(total, dtype=torch.uint8, device=f"cuda:{dev}")
+        arena = None
         if rank == 0:
             weights = W.synthetic_weights(args.model, seed=1234)
             arena, index0 = W.build_arena(weights)
             assert index0 == index
-            buf.copy_(torch.from_numpy(arena))
-            del arena
-        dist.broadcast(buf, src=0)
+        buf = wdist.broadcast_arena(arena, total, src=0, device=None if dry else f"cuda:{dev}")
+        del arena
+        if dry:
+            # CPU dry-run: everything up to the device hand-off ran (layout, broadcast, sharding); there is no GPU to continue on
+            chk = int(buf[::4099].to(torch.int64).sum().item())
+            sums = [None] * world
+            dist.all_gather_object(sums, chk)
+            assert len(set(sums)) == 1, "arena differs between ranks"
+            lo, hi = wdist.shard_range(world * args.batch * args.steps, world, rank)
+            t = torch.tensor([float(hi - lo)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                print(json.dumps({"dry_run": True, "backend": "gloo", "n_ranks": world, "arena_bytes": int(total), "arena_checksum": chk,
+                                  "utterances_per_rank_max": int(t.item()), "scaling": "weak"}), flush=True)
+            dist.destroy_process_group()
+            return
         torch.cuda.synchronize()
-        handle = ct2.create_handle(a, None, index, dev, max_batch=max(args.batch, 1), max_beam=max(args.beam, 1),
+        handle = ct2.create_handle(a, None, index, dev, max_batch=max_batch, max_beam=max(args.beam, 1),
                                    weight_bits=8 if args.compute_type == "int8_float16" else 16,
                                    arena_device_ptr=(buf.data_ptr(), total))
         del buf
@@ -162,21 +254,45 @@ def main():
     log(f"[rank {rank}] model '{args.model}' ready on device {dev} in {time.perf_counter() - t0:.1f} s "
         f"({lib.wis_model_device_bytes(handle) / 1e9:.2f} GB resident)")
 
-    clip_path = os.path.join(ROOT, "tests", "golden", "clips", args.clip + ".flac")
-    pcm, _sr = audio.load_audio(clip_path)
-    audio_ms = 1000.0 * pcm.shape[0] / 16000.0
-    B = args.batch
-    win = np.ascontiguousarray(np.tile(audio.pad_or_trim(pcm)[None], (B, 1)).astype(np.float32))
-    d_pcm = _lib.DevBuf.from_numpy(win, dev)                     # inputs resident in HBM before the timed region
-    fixed_new = FIXED_NEW.get(args.clip, 16)
-    opts = _lib.GenOpts(_lib.WIS_IN_PCM_DEV, args.beam, 0, 1.0, 1.0, 1, 1, fixed_new, 0)
-    prompt = np.ascontiguousarray(np.tile(np.array(PROMPT, np.int32), (B, 1)))
-    ids = np.zeros((B, 224), np.int32); lens = np.zeros(B, np.int32); scores = np.zeros(B, np.float32)
+    def clip_pcm(clip):
+        path = os.path.join(ROOT, "tests", "golden", "clips", clip + ".flac")
+        pcm, _sr = audio.load_audio(path)
+        return pcm, 1000.0 * pcm.shape[0] / 16000.0, path
 
-    def step():
-        _lib.check(lib.wis_generate(handle, d_pcm.ptr, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), len(PROMPT), C.byref(opts),
-                                    ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
-                                    scores.ctypes.data_as(C.POINTER(C.c_float))))
+    def make_step(h, pcm, beam, B, fixed_new, kind):
+        """-> (step(), out buffers).  kind: WIS_IN_PCM_DEV (HBM-resident windows), WIS_IN_PCM_HOST (host windows)."""
+        win = np.ascontiguousarray(np.tile(audio.pad_or_trim(pcm)[None], (B, 1)).astype(np.float32))
+        keep = _lib.DevBuf.from_numpy(win, dev) if kind == _lib.WIS_IN_PCM_DEV else win
+        src = keep.ptr if kind == _lib.WIS_IN_PCM_DEV else _lib.ptr(win)
+        opts = _lib.GenOpts(kind, beam, 0, 1.0, 1.0, 1, 1, fixed_new, 0)
+        prompt = np.ascontiguousarray(np.tile(np.array(PROMPT, np.int32), (B, 1)))
+        ids = np.zeros((B, 224), np.int32); lens = np.zeros(B, np.int32); scores = np.zeros(B, np.float32)
+
+        def step():
+            _lib.check(lib.wis_generate(h, src, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), len(PROMPT), C.byref(opts),
+                                        ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        scores.ctypes.data_as(C.POINTER(C.c_float))))
+        return step, (keep, lens)
+
+    def timed(step, n, warm):
+        for _ in range(warm):
+            step()
+        _lib.check(lib.wis_dev_sync(dev))
+        lat = []
+        for _ in range(n):
+            ts = time.perf_counter()
+            step()
+            lat.append(1e3 * (time.perf_counter() - ts))
+        return lat
+
+    def last_timing(h):
+        t = _lib.Timing(); _lib.check(lib.wis_last_timing(h, C.byref(t)))
+        return {k: round(v, 3) for k, v in t.as_dict().items()}
+
+    pcm, audio_ms, clip_path = clip_pcm(args.clip)
+    B = args.batch
+    fixed_new = FIXED_NEW.get(args.clip, 16)
+    step, (d_pcm, lens) = make_step(handle, pcm, args.beam, B, fixed_new, _lib.WIS_IN_PCM_DEV)      # inputs resident in HBM before the timed region
 
     def fence():
         if use_dist:
@@ -197,7 +313,7 @@ def main():
         lat.append(1e3 * (time.perf_counter() - ts))
     fence()
     elapsed = time.perf_counter() - t_start
-    timing = _lib.Timing(); _lib.check(lib.wis_last_timing(handle, C.byref(timing)))
+    timing = last_timing(handle)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -212,16 +328,83 @@ def main():
         per_launch_us = 1e3 * ms.value / (passes * nl.value)
         achieved = nb.value / nl.value / (per_launch_us * 1e-6) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")      # filled from the separate --pmc rocprofv3 passes
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        for name in ("r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/pmc_gemv.sh)
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    break
+                except Exception:
+                    traffic = None
+        steps_dec = max(timing["decode_steps"] - 1, 1)
+        step_bytes = decode_step_bytes(a, B, args.beam, len(PROMPT), steps_dec, args.compute_type != "float16")
+        step_ms = timing["decode_ms"] / steps_dec
         roofline = {"bound": "hbm", "kernel": "gemv_kernel (decoder skinny GEMM, weight streaming)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "bytes_per_launch": round(nb.value / nl.value), "avg_launch_us": round(per_launch_us, 3),
-                    "launches_per_decode_step": nl.value}
+                    "launches_per_decode_step": nl.value,
+                    "decode_step": {"ms": round(step_ms, 4), "algorithmic_bytes": round(step_bytes), "achieved_GBps": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
+                                    "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "encoder": {"bound": "mfma", "gflop": 2587.3 if args.model == "large" else None,
+                                "achieved_TFLOPs": round(B * 2587.3 / (timing["encoder_ms"] + timing["crosskv_ms"]), 1) if args.model == "large" else None,
+                                "peak_TFLOPs": 2500.0}}
+
+    extra = {}
+    if rank == 0 and extras:
+        # ---- the boundary the survey states (8d): PCM in HOST memory -> ids on host, and the container-decode-inclusive figure
+        # (what the reference's infer_time spans, main.py:576-581,756-760).  `value` above stays the HBM-resident number.
+        try:
+            st_host, _k = make_step(handle, pcm, args.beam, 1, fixed_new, _lib.WIS_IN_PCM_HOST)
+            l_host = timed(st_host, 20, 2)
+            flac = open(clip_path, "rb").read()
+
+            def from_bytes():
+                x, _ = audio.load_audio(flac)
+                s2, _k2 = make_step(handle, x, args.beam, 1, fixed_new, _lib.WIS_IN_PCM_HOST)
+                s2()
+            l_flac = timed(from_bytes, 20, 2)
+            extra["boundary_ms_p50"] = {"pcm_resident_in_hbm (value)": round(p50(lat), 3), "pcm_in_host_memory": round(p50(l_host), 3),
+                                        "flac_bytes_in_host_memory (container decode + H2D)": round(p50(l_flac), 3)}
+        except Exception as e:
+            extra["boundary_ms_p50"] = {"failed": repr(e)}
+        # ---- the other BASELINE.json configurations, same handle where the model is the same (SURVEY 8d conventions)
+        cfgs = []
+        for name, clip, beam, Bc in (("large-v2 beam 5, 10sec.flac (configs[2], README row)", "10sec", 5, 1), ("large-v2 beam 5, 30sec.flac (S=96)", "30sec", 5, 1),
+                                     ("large-v2 beam 3, 30sec.flac (the reference's long-audio beam, main.py:582-586)", "30sec", 3, 1),
+                                     ("large-v2 beam 5, 8 x 3sec.flac per device batch (configs[3] shape on one GPU)", "3sec", 5, 8)):
+            try:
+                pc, ams, _p = clip_pcm(clip)
+                S = FIXED_NEW[clip]
+                stc, _k = make_step(handle, pc, beam, Bc, S, _lib.WIS_IN_PCM_DEV)
+                lc = timed(stc, 10, 2)
+                tm = last_timing(handle)
+                row = {"config": name, "p50_ms": round(p50(lc), 3), "x_realtime": round(Bc * ams / p50(lc), 1), "stage_ms": tm}
+                if Bc > 1:
+                    sd = max(tm["decode_steps"] - 1, 1)
+                    sb = decode_step_bytes(a, Bc, beam, len(PROMPT), sd)
+                    row["utterances_per_s"] = round(1e3 * Bc / p50(lc), 1)
+                    row["decode_step"] = {"ms": round(tm["decode_ms"] / sd, 4), "algorithmic_bytes": round(sb),
+                                          "frac_of_hbm_peak": round(sb / (tm["decode_ms"] / sd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                cfgs.append(row)
+            except Exception as e:
+                cfgs.append({"config": name, "failed": repr(e)})
+        try:    # configs[1]: Whisper medium beam 1, 3sec.flac (a second replica, 1.5 GB)
+            am = W.arch("medium")
+            wm = W.synthetic_weights("medium", seed=1234)
+            arm, ixm = W.build_arena(wm)
+            hm = ct2.create_handle(am, arm, ixm, dev, max_batch=1, max_beam=1)
+            del arm, wm
+            stm, _k = make_step(hm, pcm, 1, 1, FIXED_NEW["3sec"], _lib.WIS_IN_PCM_DEV)
+            lm = timed(stm, 20, 3)
+            cfgs.append({"config": "medium beam 1, 3sec.flac (configs[1])", "p50_ms": round(p50(lm), 3), "x_realtime": round(audio_ms / p50(lm), 1), "stage_ms": last_timing(hm)})
+            lib.wis_model_destroy(hm)
+        except Exception as e:
+            cfgs.append({"config": "medium beam 1, 3sec.flac (configs[1])", "failed": repr(e)})
+        extra["other_baseline_configs"] = cfgs
+        try:
+            extra["rest_load"] = rest_load(handle, a, dev, args.rest_clients, 2, fixed_new, open(clip_path, "rb").read(), audio_ms)
+        except Exception as e:
+            extra["rest_load"] = {"failed": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -239,15 +422,17 @@ def main():
             "metric": "realtime_multiple (audio_ms / infer_ms), Whisper large-v2 beam=5, 3.84 s clip" if (args.model, args.beam, args.clip) == ("large", 5, "3sec")
                       else f"realtime_multiple (audio_ms / infer_ms), Whisper {args.model} beam={args.beam}, {args.clip} clip",
             "value": round(total_audio_s / elapsed, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "p50_ms": round(float(np.median(lat)), 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 3), "p50_ms": round(p50(lat), 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if args.compute_type == "float16" else "f16 (int8 decoder weights, f16 activations)", "data": "synthetic weights (seeded, true large-v2 shapes); audio = reference clip client/3sec.flac; "
                                                           f"fixed decode length S={fixed_new} (SURVEY 8d convention)",
             "config": {"workload": f"whisper-{args.model} beam={args.beam} clip={args.clip} ({audio_ms:.0f} ms) batch={B}/GPU, PCM resident in HBM -> ids on host",
                        "utterances_per_step_per_gpu": B, "parallelism": f"{world} independent replicas (utterance sharding, no data-path collective)"},
-            "stage_ms_last_step": {k: round(v, 3) for k, v in timing.as_dict().items()},
+            "utterances_per_s": round(world * B * args.steps / elapsed, 2),
+            "stage_ms_last_step": timing,
             "reference_published": "RTX 4090: 140 ms / 27x; H100: 294 ms / 12x (README.md:71,73; CT2 int8_float16, real weights, other hardware)",
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out.update(extra)
         print(json.dumps(out), flush=True)
     lib.wis_model_destroy(handle)
     if use_dist:

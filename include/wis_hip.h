@@ -179,6 +179,10 @@ int wis_dev_free(int device, void* p);
 int wis_dev_h2d(int device, void* dst, const void* src, size_t bytes);
 int wis_dev_d2h(int device, void* dst, const void* src, size_t bytes);
 int wis_dev_sync(int device);
+/* device-to-device copy between two GPUs of the node (hipMemcpyPeer: over xGMI where the devices are peers).  The replica pool
+ * (ctranslate2.models.Whisper(device_index=[0..n-1]), reference main.py:295) uploads the weight arena from the host ONCE and
+ * fans it out to the other replicas with this, in a doubling tree. */
+int wis_dev_copy_peer(int dst_device, void* dst, int src_device, const void* src, size_t bytes);
 
 /* C[M][N] = epilogue(A[M][K](lda) . W[N][K]^T + bias): the encoder MFMA GEMM.
  * flags: 1 = GELU, 2 = add residual (f32, [M][N]) , 4 = output f32 (else f16), 8 = split-K x2 variant (with 2|4 only) */

@@ -72,3 +72,24 @@ def test_shard_range_properties():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_distributed_branch_dry_run_two_gloo_ranks():
+    """bench.py's N > 1 code (rank-0-only weight generation, layout from shapes on the other ranks, arena broadcast, utterance
+    sharding, max-over-ranks reduction) launched exactly the way the driver launches it - torch.distributed.run, one process per
+    rank, 127.0.0.1 - with WIS_DIST_BACKEND=gloo: everything up to the device hand-off runs on the CPU (there is no GPU here to
+    continue on), so the branch is exercised before a driver ever runs it on 8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--model", "tiny"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dry_run"] and out["n_ranks"] == 2 and out["scaling"] == "weak" and out["utterances_per_rank_max"] == 5
+    from wis_hip import weights as W
+    assert out["arena_bytes"] == W.synthetic_layout("tiny")[1]

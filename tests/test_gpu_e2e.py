@@ -338,3 +338,39 @@ def test_roofline_tap_runs_at_every_row_count(tiny, lib):
         ms, nl, nb = C.c_float(), C.c_int(), C.c_double()
         _lib.check(lib.wis_bench_weight_stream(_handle(model), rows, 1, C.byref(ms), C.byref(nl), C.byref(nb)))
         assert nl.value == 6 * a["n_layers"] + 1 and nb.value > 0 and ms.value > 0
+
+
+def test_replica_pool_from_one_host_upload(mels):
+    """`Whisper(device_index=[...])` (reference main.py:295): ONE host upload, the other replicas are filled device-to-device
+    (wis_dev_copy_peer, doubling tree) and created from the device-resident arena.  A 1-GPU box can only list device 0 several
+    times - the same code path with the peer copy degenerating to a local one; every replica must return what a lone model returns,
+    and concurrent calls must spread over the replicas."""
+    import threading
+    from wis_hip import ctranslate2 as ct2, weights as W
+    w = W.synthetic_weights("tiny", seed=1234, emb_std=0.06, ln_jitter=0.1)
+    a = W.arch("tiny")
+    lone = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5)
+    pool = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5, device_index=[0, 0, 0])
+    assert len(pool._replicas) == 3
+    f = ct2.StorageView.from_array(mels)
+    exp = [r.sequences_ids for r in lone.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)]
+    for r in pool._replicas:                      # every replica, addressed directly
+        got = pool._generate_chunk(r, mels, [PROMPT] * 2, 4, 5, 224, 1.0, 1.0, True, True, 6, 0)
+        assert [x.sequences_ids for x in got] == exp
+    out = {}
+
+    def client(i):
+        out[i] = pool.generate(ct2.StorageView.from_array(mels[i % 2:i % 2 + 1]), [PROMPT], beam_size=5, fixed_new_tokens=6)[0].sequences_ids
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(12)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    used = {idx for idx, _ in pool._batcher.batches}
+    print("replicas used:", sorted(used))
+    assert len(used) >= 2
+    single = [lone.generate(ct2.StorageView.from_array(mels[k:k + 1]), [PROMPT], beam_size=5, fixed_new_tokens=6)[0].sequences_ids for k in range(2)]
+    flips = sum(out[i] != single[i % 2] for i in range(12))
+    assert flips <= 2
+    pool.close(); lone.close()

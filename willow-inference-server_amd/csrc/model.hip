@@ -998,6 +998,19 @@ int wis_dev_free(int device, void* p) { DeviceCtx* c; WIS_RET(get_ctx(device, &c
 int wis_dev_h2d(int device, void* dst, const void* src, size_t bytes) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return WIS_OK; }
 int wis_dev_d2h(int device, void* dst, const void* src, size_t bytes) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return WIS_OK; }
 int wis_dev_sync(int device) { DeviceCtx* c; WIS_RET(get_ctx(device, &c)); WIS_HIP_CHECK(hipDeviceSynchronize()); return WIS_OK; }
+int wis_dev_copy_peer(int dst_device, void* dst, int src_device, const void* src, size_t bytes) {
+  if (!dst || !src) { set_error("wis_dev_copy_peer: bad argument"); return WIS_E_ARG; }
+  DeviceCtx* c; WIS_RET(get_ctx(src_device, &c)); WIS_RET(get_ctx(dst_device, &c));      // both devices exist; current = dst
+  if (src_device != dst_device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst_device, src_device) == hipSuccess && can) {
+      hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);                            // direct xGMI path; already-enabled is fine
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    }
+  }
+  WIS_HIP_CHECK(hipMemcpyPeer(dst, dst_device, src, src_device, bytes));
+  return WIS_OK;
+}
 
 int wis_op_gemm(int device, const void* A, int lda, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K, int flags) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("wis_dev_h2d", _i, [_i, _vp, _vp, _sz]),
     ("wis_dev_d2h", _i, [_i, _vp, _vp, _sz]),
     ("wis_dev_sync", _i, [_i]),
+    ("wis_dev_copy_peer", _i, [_i, _vp, _i, _vp, _sz]),
     ("wis_op_gemm", _i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("wis_op_layernorm", _i, [_i, _vp, _vp, _vp, _vp, _i, _i]),
     ("wis_op_enc_attention", _i, [_i, _vp, _vp, _vp, _i, _i, _i, _i]),

@@ -115,6 +115,37 @@ def create_handle(a, arena, index, device, max_batch=8, max_beam=5, arena_device
     return h
 
 
+def create_replicas(a, arena, index, devices, max_batch=8, max_beam=5, **cfgkw):
+    """One replica per entry of `devices` from ONE host upload: the arena goes to the first device over PCIe, every other
+    replica receives it device-to-device (wis_dev_copy_peer: xGMI between peers) in a doubling tree - 0 -> 1, then {0 -> 2,
+    1 -> 3}, ... - and is created from the device-resident copy (wis_model_create(arena_on_device=1)).  This is the
+    single-process form of the one-time weight broadcast (the one-process-per-GPU form is wis_hip.dist.broadcast_arena over
+    RCCL); nothing crosses GPUs at request time.  Returns the handles in `devices` order."""
+    if len(devices) == 1:
+        return [create_handle(a, arena, index, devices[0], max_batch, max_beam, **cfgkw)]
+    lib = _lib.load()
+    bufs = [None] * len(devices)
+    bufs[0] = _lib.DevBuf.from_numpy(arena, devices[0])
+    have = 1
+    while have < len(devices):          # doubling: every device that holds the arena feeds one that does not
+        for src in range(have):
+            dst = have + src
+            if dst >= len(devices):
+                break
+            bufs[dst] = _lib.DevBuf(arena.nbytes, devices[dst])
+            _lib.check(lib.wis_dev_copy_peer(devices[dst], bufs[dst].ptr, devices[src], bufs[src].ptr, arena.nbytes))
+        have *= 2
+    handles = []
+    try:
+        for d, b in zip(devices, bufs):
+            handles.append(create_handle(a, None, index, d, max_batch, max_beam, arena_device_ptr=(b.ptr.value, arena.nbytes), **cfgkw))
+    finally:
+        for b in bufs:
+            if b is not None:
+                b.free()
+    return handles
+
+
 def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
     B = mel.shape[0]
     o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
@@ -174,7 +205,7 @@ class Whisper:
         arena, index = W.build_arena(weights)
         kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"),
                   weight_bits=8 if self.compute_type == "int8_float16" else 16)
-        self._replicas = [_Replica(create_handle(arch, arena, index, d, max_batch, max_beam, **kw), d) for d in devs]
+        self._replicas = [_Replica(h, d) for h, d in zip(create_replicas(arch, arena, index, devs, max_batch, max_beam, **kw), devs)]
         self.max_batch, self.max_beam = max_batch, max_beam
         self._pick = threading.Lock()
         # concurrent generate() calls coalesce into device batches, one worker per GPU replica (wis_hip/batching.py)

@@ -46,6 +46,9 @@ class APISettings:
     # mel -> host -> StorageView round trip; results are identical (same kernels)
     fuse_logmel: bool = True
     max_batch: int = 8
+    # measurement convention for seeded synthetic weights, which never emit EOT: decode exactly this many tokens
+    # (EOT masked until then, then forced).  0 = off: the product default, natural termination
+    fixed_new_tokens: int = 0
     # "float16" or "int8_float16" (the reference picks int8_float16 on GPUs, main.py:242: here it quantises the decoder weights)
     compute_type: str = "float16"
 

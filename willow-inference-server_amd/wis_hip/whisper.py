@@ -137,9 +137,11 @@ def chunkit(lst, num):
 
 
 def do_whisper(audio_file, model, beam_size=None, task="transcribe", detect_language=False, force_language=None, translate=False,
-               models=None, fixed_new_tokens=0):
+               models=None, fixed_new_tokens=None):
     models = models or default_models()
     s = models.settings
+    if fixed_new_tokens is None:
+        fixed_new_tokens = s.fixed_new_tokens
     beam_size = s.beam_size if beam_size is None else beam_size
     whisper_model = models.get(model)
     first_time_start = time.perf_counter()
