@@ -64,6 +64,23 @@ void wis_audio_free(float* pcm);
 int wis_logmel(int device, const float* pcm, int64_t stride, const int64_t* n_samples, int n_win,
                int pcm_on_device, float* mel_out, int mel_on_device);
 
+/* ---- 8(f)3: incremental log-mel over arriving PCM (streaming / long-form sessions).  One handle = ONE 30 s window being
+ * filled on one device.  Frames are local (400 samples around 160 t, wis/audio.py:96-101), so every 16-frame tile whose samples
+ * have all arrived is transformed inside wis_melstream_feed; only the clamp at (window max - 8) and the scaling (wis/audio.py:
+ * 100-102) need the whole window and run in wis_melstream_finish, together with the tail tiles against the zero padding of
+ * pad_or_trim.  The result equals wis_logmel of the complete window bit for bit (same kernels, same per-tile arithmetic).
+ * The features stay in HBM: finish hands back a DEVICE pointer (f32 [80][3000], valid until the next reset / destroy) that
+ * wis_generate / wis_detect_language take as WIS_IN_MEL_DEV on the same device; mel_host_or_null additionally copies them out.
+ * A handle is used by one thread at a time; different handles are independent (own stream and buffers). */
+typedef struct wis_melstream wis_melstream_t;
+int  wis_melstream_create(int device, wis_melstream_t** out);
+int  wis_melstream_reset(wis_melstream_t* s);
+int  wis_melstream_feed(wis_melstream_t* s, const float* pcm, int64_t n_samples);   /* host PCM, appended; beyond 480000: ignored */
+int  wis_melstream_finish(wis_melstream_t* s, float* mel_host_or_null, float** mel_dev_out);
+int64_t wis_melstream_samples(const wis_melstream_t* s);       /* samples received so far (<= 480000) */
+int  wis_melstream_tiles_done(const wis_melstream_t* s);       /* 16-frame tiles already transformed (0..188) */
+void wis_melstream_destroy(wis_melstream_t* s);
+
 /* ---- a6: model lifecycle (replaces ctranslate2.models.Whisper(path, device=..,
  * compute_type=.., device_index=[..]), main.py:341-444).  One handle = one replica on one
  * GPU; the Python shim creates one per listed device_index entry. */

@@ -229,7 +229,7 @@ def test_concurrent_pcm_requests_keep_their_own_audio(golden_dir):
     lone = {c: model.generate(ct2.StorageView.from_array(pcm[c]), [PROMPT], **kw)[0] for c in names}
     gaps = [abs(lone[a].scores[0] - lone[b].scores[0]) for a in names for b in names if a < b]
     print("lone scores", {c: round(lone[c].scores[0], 5) for c in names})
-    assert min(gaps) > 2e-2
+    assert min(gaps) > 4e-3                     # (measured: 6.5e-3 .. 1.4e-2 between the three clips; the batch-composition rounding is < 1e-3)
     out, start = {}, threading.Barrier(24)
     n0 = len(model._batcher.batches)
 
@@ -246,7 +246,9 @@ def test_concurrent_pcm_requests_keep_their_own_audio(golden_dir):
     print("device batches formed:", sizes)
     assert sum(sizes) == 24 and max(sizes) > 1
     for i, r in out.items():
-        assert abs(r.scores[0] - lone[names[i % 3]].scores[0]) <= 2e-3, (i, names[i % 3], r.scores[0], {c: lone[c].scores[0] for c in names})
+        own = abs(r.scores[0] - lone[names[i % 3]].scores[0])
+        other = min(abs(r.scores[0] - lone[c].scores[0]) for c in names if c != names[i % 3])
+        assert own <= 2e-3 and own < other, (i, names[i % 3], r.scores[0], {c: lone[c].scores[0] for c in names})
     model.close()
 
 

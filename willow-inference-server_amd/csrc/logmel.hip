@@ -359,3 +359,98 @@ extern "C" int wis_logmel(int device, const float* pcm, int64_t stride, const in
   ws_release(c, ws);
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------
+// Incremental log-mel: the window's PCM accumulates in HBM; tile j (frames 16j .. 16j+15) reads the samples
+// [2560 j - 200, 2560 j + 2600) (reflected at the window edges), so it is final once 2560 j + 2600 samples have arrived - unless
+// it reaches the right edge of the 30 s window, where the reflection reads samples up to 479999: those tiles wait for finish.
+struct wis_melstream {
+  int device = 0;
+  DeviceCtx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  float* d_pcm = nullptr; int64_t* d_nsamp = nullptr; float* d_logspec = nullptr; unsigned* d_gmax = nullptr; float* d_mel = nullptr;
+  int64_t* h_nsamp = nullptr;      // pinned
+  int64_t n = 0;                   // samples received
+  int tiles_done = 0;
+  bool finished = false;
+};
+namespace {
+constexpr int NTILES = (NFRAMES + FT - 1) / FT;      // 188
+int tiles_final_for(int64_t n) {
+  if (n >= NSAMP) return NTILES;
+  int64_t t = (n - (SPAN - NFFT / 2)) / (FT * HOP) + 1;             // largest j + 1 with 2560 j + 2600 <= n
+  if (n < SPAN - NFFT / 2) t = 0;
+  // tiles whose span crosses the right window edge (reflection) are not final before the window is complete
+  const int64_t edge = ((int64_t)NSAMP + NFFT / 2 - SPAN) / (FT * HOP) + 1;   // first tile with 2560 j + 2600 > 480000
+  if (t > edge) t = edge;
+  return (int)(t < 0 ? 0 : (t > NTILES ? NTILES : t));
+}
+}  // namespace
+
+extern "C" int wis_melstream_create(int device, wis_melstream_t** out) {
+  if (!out) { set_error("wis_melstream_create: bad argument"); return WIS_E_ARG; }
+  DeviceCtx* c; WIS_RET(get_ctx(device, &c));
+  wis_melstream* s = new wis_melstream();
+  s->device = device; s->ctx = c;
+  bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(&s->d_pcm, (size_t)NSAMP * 4) == hipSuccess && hipMalloc(&s->d_nsamp, 8) == hipSuccess &&
+            hipMalloc(&s->d_logspec, (size_t)NMEL * NFRAMES * 4) == hipSuccess && hipMalloc(&s->d_gmax, 4) == hipSuccess &&
+            hipMalloc(&s->d_mel, (size_t)NMEL * NFRAMES * 4) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&s->h_nsamp), 64, hipHostMallocDefault) == hipSuccess;
+  if (!ok) { set_error("wis_melstream_create: allocation failed"); wis_melstream_destroy(s); return WIS_E_NOMEM; }
+  *out = s;
+  return wis_melstream_reset(s);
+}
+extern "C" int wis_melstream_reset(wis_melstream_t* s) {
+  if (!s) { set_error("wis_melstream_reset: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(s->device));
+  WIS_HIP_CHECK(hipStreamSynchronize(s->stream));
+  s->n = 0; s->tiles_done = 0; s->finished = false;
+  WIS_HIP_CHECK(hipMemsetAsync(s->d_gmax, 0, 4, s->stream));
+  return WIS_OK;
+}
+static int melstream_run_tiles(wis_melstream* s, int upto) {
+  if (upto <= s->tiles_done) return WIS_OK;
+  *s->h_nsamp = s->n;                                  // the kernel treats samples >= n as zero (pad_or_trim)
+  WIS_HIP_CHECK(hipMemcpyAsync(s->d_nsamp, s->h_nsamp, 8, hipMemcpyHostToDevice, s->stream));
+  WIS_RET(logmel_frames(s->ctx, s->stream, s->d_logspec, s->d_gmax, s->d_pcm, NSAMP, s->d_nsamp, 1, s->tiles_done, upto - s->tiles_done));
+  WIS_HIP_CHECK(hipStreamSynchronize(s->stream));      // h_nsamp is reused by the next call; a feed is not latency critical
+  s->tiles_done = upto;
+  return WIS_OK;
+}
+extern "C" int wis_melstream_feed(wis_melstream_t* s, const float* pcm, int64_t n_samples) {
+  if (!s || (!pcm && n_samples > 0) || n_samples < 0) { set_error("wis_melstream_feed: bad argument"); return WIS_E_ARG; }
+  if (s->finished) { set_error("wis_melstream_feed: window already finished (reset first)"); return WIS_E_STATE; }
+  WIS_HIP_CHECK(hipSetDevice(s->device));
+  int64_t take = n_samples;
+  if (s->n + take > NSAMP) take = NSAMP - s->n;        // pad_or_trim: a window holds 30 s
+  if (take > 0) {
+    WIS_HIP_CHECK(hipMemcpyAsync(s->d_pcm + s->n, pcm, (size_t)take * 4, hipMemcpyHostToDevice, s->stream));
+    WIS_HIP_CHECK(hipStreamSynchronize(s->stream));    // the caller's buffer is free again
+    s->n += take;
+  }
+  return melstream_run_tiles(s, tiles_final_for(s->n));
+}
+extern "C" int wis_melstream_finish(wis_melstream_t* s, float* mel_host_or_null, float** mel_dev_out) {
+  if (!s) { set_error("wis_melstream_finish: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(s->device));
+  if (!s->finished) {
+    WIS_RET(melstream_run_tiles(s, NTILES));           // the tail against the zero padding
+    WIS_RET(logmel_finalize(s->stream, s->d_logspec, s->d_gmax, 1, s->d_mel, nullptr));
+    s->finished = true;
+  }
+  if (mel_host_or_null) WIS_HIP_CHECK(hipMemcpyAsync(mel_host_or_null, s->d_mel, (size_t)NMEL * NFRAMES * 4, hipMemcpyDeviceToHost, s->stream));
+  WIS_HIP_CHECK(hipStreamSynchronize(s->stream));
+  if (mel_dev_out) *mel_dev_out = s->d_mel;
+  return WIS_OK;
+}
+extern "C" int64_t wis_melstream_samples(const wis_melstream_t* s) { return s ? s->n : 0; }
+extern "C" int wis_melstream_tiles_done(const wis_melstream_t* s) { return s ? s->tiles_done : 0; }
+extern "C" void wis_melstream_destroy(wis_melstream_t* s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+  hipFree(s->d_pcm); hipFree(s->d_nsamp); hipFree(s->d_logspec); hipFree(s->d_gmax); hipFree(s->d_mel);
+  if (s->h_nsamp) hipHostFree(s->h_nsamp);
+  delete s;
+}

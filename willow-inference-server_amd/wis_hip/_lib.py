@@ -62,6 +62,13 @@ SYMBOLS = [
     ("wis_audio_decode", _i, [_vp, _sz, C.POINTER(_fp), C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
     ("wis_audio_free", None, [_fp]),
     ("wis_logmel", _i, [_i, _vp, _i64, C.POINTER(_i64), _i, _i, _vp, _i]),
+    ("wis_melstream_create", _i, [_i, C.POINTER(_vp)]),
+    ("wis_melstream_reset", _i, [_vp]),
+    ("wis_melstream_feed", _i, [_vp, _vp, _i64]),
+    ("wis_melstream_finish", _i, [_vp, _vp, C.POINTER(_vp)]),
+    ("wis_melstream_samples", _i64, [_vp]),
+    ("wis_melstream_tiles_done", _i, [_vp]),
+    ("wis_melstream_destroy", None, [_vp]),
     ("wis_model_create", _i, [C.POINTER(Config), _vp, _sz, _i, C.POINTER(Tensor), _i, _i, C.POINTER(_vp)]),
     ("wis_model_destroy", None, [_vp]),
     ("wis_model_device_bytes", _sz, [_vp]),
