@@ -132,6 +132,7 @@ def test_streaming_session_equals_offline(golden_dir):
     assert mid[5] == off[5] == 29248 and mid.tokens == off.tokens
     fin = sess.stop()
     assert fin.tokens == off.tokens and fin[1] == off[1] and sess.eager_windows == 0
+    assert sess.front_windows == 1        # the final decode took its features from the incremental front-end (HBM), not from host PCM
     # (2) 64 s of seeded noise: 5 windows, the first three complete (and get transcribed) before the recording ends
     rng = np.random.default_rng(11)
     long_pcm = (0.05 * rng.standard_normal(64 * 16000)).astype(np.float32)
@@ -142,6 +143,7 @@ def test_streaming_session_equals_offline(golden_dir):
     assert sess.eager_windows == 4        # starts 0, 14, 28, 42 s have their 22 s; the tail window (56 s) does not
     fin = sess.stop()
     assert fin.tokens == off.tokens and fin[5] == off[5] == 64000
+    assert sess.front_windows == 5        # every window (4 eager + the tail) was decoded from incrementally computed features
     with pytest.raises(RuntimeError):
         sess.feed(long_pcm[:10])
 
@@ -305,3 +307,38 @@ def test_translate_and_tokenizer_branches(tmp_path, golden_dir):
     s.fuse_logmel = False
     again = do_whisper(clip, "tiny", 5, "transcribe", False, "en", models=models, fixed_new_tokens=7)
     assert again.tokens == res.tokens and again[1] == text
+
+
+def test_melstream_incremental_equals_batch_logmel(golden_dir):
+    """wis_melstream_* (SURVEY 8(f)3): PCM fed in ragged pieces - single samples, pieces shorter than a frame, pieces spanning many
+    tiles - must give, bit for bit, the log-mel of the complete padded window; tiles are transformed as soon as their samples are
+    complete (tiles_done follows 2560 j + 2600 <= n), the right window edge waits for finish, 30 s windows are trimmed."""
+    from wis_hip import audio
+    rng = np.random.default_rng(21)
+    st = audio.MelStream(0)
+    for clip in ("3sec", "10sec", "30sec", "noise31"):
+        if clip == "noise31":
+            pcm = (0.1 * rng.standard_normal(31 * 16000)).astype(np.float32)       # longer than the window: trimmed (pad_or_trim)
+        else:
+            pcm = audio.load_audio(os.path.join(golden_dir, "clips", clip + ".flac"))[0]
+        want = audio.log_mel_spectrogram(audio.pad_or_trim(pcm), device=0).numpy()
+        st.reset()
+        i, seen = 0, []
+        sizes = [1, 199, 200, 2400, 1, 159, 7001]
+        while i < pcm.shape[0]:
+            k = sizes[len(seen) % len(sizes)] if len(seen) < 40 else int(rng.integers(1, 40000))
+            st.feed(pcm[i:i + k])
+            i += k
+            n = min(i, pcm.shape[0], 480000)
+            exp_tiles = 188 if n >= 480000 else max(0, min((n - 2600) // 2560 + 1 if n >= 2600 else 0, (480000 + 200 - 2800) // 2560 + 1))
+            assert st.samples == n and st.tiles_done == exp_tiles, (clip, n, st.tiles_done, exp_tiles)
+            seen.append(st.tiles_done)
+        got = st.finish()
+        assert st.device_ptr and np.array_equal(got, want), (clip, float(np.abs(got - want).max()))
+        assert np.array_equal(st.finish(), want)          # idempotent
+        with pytest.raises(Exception):
+            st.feed(pcm[:10])                             # a finished window takes no more audio
+    # an empty window is the log-mel of silence
+    st.reset()
+    assert np.array_equal(st.finish(), audio.log_mel_spectrogram(np.zeros(480000, np.float32), device=0).numpy())
+    st.close()

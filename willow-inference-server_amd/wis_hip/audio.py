@@ -159,6 +159,56 @@ def log_mel_spectrogram(audio, n_mels: int = N_MELS, device=None):
     return MelFeatures(out[0] if single else out)
 
 
+class MelStream:
+    """Incremental log-mel of ONE 30 s window on one GPU (C-ABI wis_melstream_*): `feed` PCM as it arrives - every
+    16-frame tile whose samples are complete is transformed right away - and `finish` clamps / scales (the only step that needs
+    the whole window).  Bit-identical to `log_mel_spectrogram(pad_or_trim(everything fed))`.  After `finish`, `device_ptr` is
+    the address of the f32 [80, 3000] features in HBM (valid until reset / close): `Whisper.generate_from_device` consumes it
+    without the features ever visiting the host."""
+
+    def __init__(self, device=0):
+        _lib.require_gpu()
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().wis_melstream_create(self.device, C.byref(self._h)))
+        self.device_ptr = None
+
+    def feed(self, samples):
+        x = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        if x.shape[0]:
+            _lib.check(_lib.load().wis_melstream_feed(self._h, _lib.ptr(x), x.shape[0]))
+
+    def finish(self, to_host=True):
+        out = np.empty((N_MELS, N_FRAMES), np.float32) if to_host else None
+        dev = C.c_void_p()
+        _lib.check(_lib.load().wis_melstream_finish(self._h, _lib.ptr(out) if to_host else None, C.byref(dev)))
+        self.device_ptr = dev.value
+        return out
+
+    def reset(self):
+        _lib.check(_lib.load().wis_melstream_reset(self._h))
+        self.device_ptr = None
+
+    @property
+    def samples(self):
+        return int(_lib.load().wis_melstream_samples(self._h))
+
+    @property
+    def tiles_done(self):
+        return int(_lib.load().wis_melstream_tiles_done(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.load().wis_melstream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def chunk_iter(inputs):
     """22 s windows with 4 s of context each side, stepping 14 s; yields (chunk, (len, left, right))."""
     assert isinstance(inputs, np.ndarray), "chunk_iter only takes numpy array"

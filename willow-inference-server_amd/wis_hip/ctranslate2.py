@@ -146,14 +146,15 @@ def create_replicas(a, arena, index, devices, max_batch=8, max_beam=5, **cfgkw):
     return handles
 
 
-def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
-    B = mel.shape[0]
+def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=None):
+    """mel: host ndarray [B, ...] - or, with device_ptr, just the batch size B of features already resident on r.device."""
+    B = int(mel) if device_ptr is not None else mel.shape[0]
     o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
     pr = np.ascontiguousarray(np.asarray(prompts, np.int32).reshape(B, P))
     ids = np.zeros((B, max_new), np.int32)
     lens = np.zeros(B, np.int32)
     scores = np.zeros(B, np.float32)
-    _lib.check(_lib.load().wis_generate(r.handle, _lib.ptr(mel), B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
+    _lib.check(_lib.load().wis_generate(r.handle, C.c_void_p(device_ptr) if device_ptr is not None else _lib.ptr(mel), B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
                                         ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
                                         scores.ctypes.data_as(C.POINTER(C.c_float))))
     return [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
@@ -296,6 +297,24 @@ class Whisper:
                int(fixed_new_tokens), int(input_kind))
         rows = [(np.ascontiguousarray(mel[b]), [int(t) for t in prompts[b]]) for b in range(B)]
         return self._batcher.submit(key, rows)
+
+    def replica_on(self, device):
+        """A replica that lives on `device` (streaming sessions keep their features on one GPU)."""
+        for r in self._replicas:
+            if r.device == device:
+                return r
+        raise ValueError(f"no replica on device {device}")
+
+    def generate_from_device(self, device, mel_device_ptr, prompt, *, beam_size=5, max_length=448, length_penalty=1, patience=1,
+                             suppress_blank=True, fixed_new_tokens=0):
+        """One utterance whose log-mel features ALREADY live in HBM on `device` (f32 [80][3000] at `mel_device_ptr`, e.g. an
+        audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Runs on that device's replica."""
+        r = self.replica_on(device)
+        P = len(prompt)
+        max_new = min(max_length // 2, max_length - P)
+        with r.lock:
+            return _generate_chunk(r, 1, [prompt], P, int(beam_size), max_new, float(length_penalty), float(patience), suppress_blank, True,
+                                   int(fixed_new_tokens), _lib.WIS_IN_MEL_DEV, device_ptr=int(mel_device_ptr))[0]
 
     def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
         """One `wis_generate` call on replica r (the caller serialises access to r)."""

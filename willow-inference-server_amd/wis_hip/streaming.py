@@ -7,7 +7,9 @@ windows with 4 s of context either side, stepping 14 s.  A `StreamingSession` ac
 the audio is known to need chunking (> 30 s buffered), transcribes every window whose 22 s are complete on a worker thread
 (through the model's micro-batcher, so several sessions share device batches); `stop()` then only has the tail window left
 and returns exactly what `do_whisper` returns for the complete recording.  `interim()` gives the hypothesis for what has
-been heard so far (an extra decode; the final result never depends on it).
+been heard so far (an extra decode; the final result never depends on it).  The log-mel front-end is incremental
+(`_IncrementalFront`, C-ABI wis_melstream_*): each window's spectrogram tiles are computed while its audio arrives, only the
+clamp / scaling is left when the window completes, and the features go to the encoder straight from HBM.
 
 `DataChannelProtocol` is the reference's data-channel message protocol (`ping` / `start` / `stop` -> `pong` / `log` /
 `infer` / `error`, main.py:906-996) driven by such a session instead of `MediaRecorderLite` + `do_whisper`; the WebRTC
@@ -27,9 +29,52 @@ from .whisper import InvalidAudio, WhisperResult, _Tokenizer, check_language, de
 _STEP = audio.chunk_len - audio.stride_left - audio.stride_right     # 14 s between window starts
 
 
+class _IncrementalFront:
+    """The log-mel front-end of a session, fed as the audio arrives: one audio.MelStream per 30 s window in
+    progress - the "short" window [0 s, 30 s) that a recording of up to 30 s ends up using, and the 22 s windows of the chunk
+    schedule (starts 0, 14, 28, ... s).  When a window is complete only its tail tiles and the clamp are left to compute, and the
+    features are already in HBM on the replica's GPU (generate_from_device: nothing is staged through the host)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.short = audio.MelStream(device)
+        self.windows = {}             # window start (samples) -> MelStream
+        self.n = 0
+
+    def feed(self, x, chunking):
+        n0, n1 = self.n, self.n + x.shape[0]
+        if self.short is not None:
+            if n0 < audio.N_SAMPLES:
+                self.short.feed(x[:audio.N_SAMPLES - n0])
+            if n1 > audio.N_SAMPLES and chunking:          # the recording will be chunked: the short window is never used
+                self.short.close()
+                self.short = None
+        if chunking:
+            start = 0
+            while start < n1:
+                if start + audio.chunk_len > n0:           # window [start, start + 22 s) overlaps the new samples
+                    st = self.windows.get(start)
+                    if st is None:
+                        st = self.windows[start] = audio.MelStream(self.device)
+                        if n0 > start:                     # opened late (cannot happen when fed from the beginning)
+                            raise RuntimeError("incremental front-end must see the recording from its first sample")
+                    lo, hi = max(start, n0), min(start + audio.chunk_len, n1)
+                    st.feed(x[lo - n0:hi - n0])
+                start += _STEP
+        self.n = n1
+
+    def take(self, start):
+        return self.windows.pop(start, None)
+
+    def close(self):
+        for st in list(self.windows.values()) + ([self.short] if self.short is not None else []):
+            st.close()
+        self.windows, self.short = {}, None
+
+
 class StreamingSession:
     def __init__(self, model, beam_size=None, task="transcribe", detect_language=False, force_language=None, models=None,
-                 fixed_new_tokens=0):
+                 fixed_new_tokens=0, incremental=True):
         self.models = models or default_models()
         s = self.models.settings
         self.model_name, self.task = model, task
@@ -46,6 +91,8 @@ class StreamingSession:
         self._language_job = None     # Future: language of the chunked recording (from window 0), resolved exactly once
         self._closed = False
         self.eager_windows = 0        # windows transcribed before stop() (stats / tests)
+        self.front_windows = 0        # windows whose features came from the incremental front-end
+        self._front = _IncrementalFront(self._whisper._replicas[0].device) if incremental else None
 
     # ---- audio in ----------------------------------------------------------------------------------------------------
     def feed(self, samples, sample_width=None):
@@ -59,6 +106,9 @@ class StreamingSession:
         x = np.ascontiguousarray(samples, np.float32).reshape(-1)
         with self._lock:
             self._pcm = np.concatenate([self._pcm, x])
+            front = getattr(self, "_front", None)
+            if front is not None:
+                front.feed(x, self.models.settings.support_chunking)
             self._schedule_complete_windows()
 
     @property
@@ -84,11 +134,21 @@ class StreamingSession:
             raise ValueError(f"unsupported language {language!r}")
         return language
 
-    def _window_tokens(self, piece, beam, language):
+    def _window_tokens(self, piece, beam, language, stream=None):
         """`language`: a code, or a Future resolving to one (the session-wide language job of window 0: every eager window
-        waits for THAT result, so a later window can never decide the language - do_whisper always detects on window 0)."""
+        waits for THAT result, so a later window can never decide the language - do_whisper always detects on window 0).
+        `stream`: the window's MelStream (its samples are all fed): finish it and decode from the features in HBM."""
         if hasattr(language, "result"):
             language = language.result()
+        if stream is not None:
+            try:
+                stream.finish(to_host=False)
+                r = self._whisper.generate_from_device(stream.device, stream.device_ptr, self._prompt(language), beam_size=beam,
+                                                       fixed_new_tokens=self.fixed_new_tokens)
+                self.front_windows += 1
+                return r.sequences_ids[0]
+            finally:
+                stream.close()
         x = np.ascontiguousarray(audio.pad_or_trim(piece)[None], np.float32)
         r = self._whisper.generate(ctranslate2.StorageView.from_array(x), [self._prompt(language)], beam_size=beam,
                                    return_scores=False, fixed_new_tokens=self.fixed_new_tokens, input_kind=ctranslate2._lib.WIS_IN_PCM_HOST)
@@ -108,7 +168,9 @@ class StreamingSession:
                 piece = self._pcm[start:start + audio.chunk_len].copy()
                 if self._language_job is None:         # start == 0 here: the chunked call detects on exactly this window
                     self._language_job = self._pool.submit(self._detect, piece)
-                self._windows[key] = self._pool.submit(self._window_tokens, piece, s.long_beam_size, self._language_job)
+                front = getattr(self, "_front", None)
+                args = (piece, s.long_beam_size, self._language_job) + ((front.take(start),) if front is not None else ())
+                self._windows[key] = self._pool.submit(self._window_tokens, *args)
                 self.eager_windows += 1
             start += _STEP
 
@@ -123,6 +185,7 @@ class StreamingSession:
         duration_ms = int(pcm.shape[0] / audio.SAMPLE_RATE * 1000)
         beam = s.long_beam_size if duration_ms >= s.long_beam_size_threshold else self.beam_size
         tokenizer = self.models.tokenizer_for(self.model_name)
+        front = getattr(self, "_front", None)
         if duration_ms > 30 * 1000 and s.support_chunking:
             with self._lock:
                 if self._language_job is None:     # chunking disabled while feeding, or a burst longer than 30 s fed at once
@@ -132,12 +195,19 @@ class StreamingSession:
             for piece, stride in audio.chunk_iter(pcm):
                 start = len(seqs) * _STEP
                 fut = self._windows.get((start, piece.shape[0]))
-                ids = fut.result() if fut is not None else self._window_tokens(piece, beam, language)
+                if fut is not None:
+                    ids = fut.result()
+                else:      # a tail window: at stop() its stream holds everything but the last tiles
+                    st = front.take(start) if (final and front is not None and front.n == pcm.shape[0]) else None
+                    ids = self._window_tokens(piece, beam, language, st) if st is not None else self._window_tokens(piece, beam, language)
                 seqs.append((ids, stride))
             tokens = [int(t) for t in audio.find_longest_common_sequence(seqs, tokenizer)]
         else:
             language = self._detect(pcm)           # short recording: one window = the whole audio; nothing is cached, a later
-            tokens = self._window_tokens(pcm, beam, language)      # (longer) call detects again on its own first window
+            st = None                              # (longer) call detects again on its own first window
+            if final and front is not None and front.short is not None and front.n == pcm.shape[0]:
+                st, front.short = front.short, None
+            tokens = self._window_tokens(pcm, beam, language, st) if st is not None else self._window_tokens(pcm, beam, language)
         text = tokenizer.decode(tokens).strip()
         ms = (time.perf_counter() - t0) * 1000
         out = WhisperResult((language, text, ms, None, math.floor(duration_ms / ms) if ms > 0 else 0, duration_ms))
@@ -159,6 +229,9 @@ class StreamingSession:
     def close(self):
         self._closed = True
         self._pool.shutdown(wait=False, cancel_futures=True)
+        front = getattr(self, "_front", None)
+        if front is not None:
+            front.close()
 
 
 class DataChannelProtocol:
