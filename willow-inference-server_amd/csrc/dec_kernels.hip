@@ -841,7 +841,10 @@ constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16
 
 // TPW = key tiles per wave (CL / 64): 2 for 128-key chunks, 4 for 256-key chunks; loads are unconditional with clamped
 // addresses (masked by `kl < n` below), so the issue phase is straight-line code.
-template <int TPW>
+// CM = the most chunks the combine handles (its partial buffers are register arrays of that size): 6 for the default 256-key
+// chunking, 16 otherwise.  With [16] arrays at every chunking the kernel needed 218 VGPRs - two workgroups per CU, so the 960
+// workgroups of an 8-utterance batch ran in two rounds; with CM = 6 it needs 88 (five per CU).
+template <int TPW, int CM>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
                                                              int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb) {
@@ -981,9 +984,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // rows per utterance - the op-level test at R = 16 found rows 8..15 uncombined when this was a single `if (tid < R * 32)`)
   for (int item = tid; item < R * 32; item += 256) {
     const int r = item >> 5, dp = item & 31;
-    float2 ml[16], ov[16];
+    float2 ml[CM], ov[CM];
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
+    for (int cc = 0; cc < CM; ++cc) {
       if (cc < C) {
         const float* pp = pbase + ((size_t)cc * R + r) * 66;
         ml[cc] = *reinterpret_cast<const float2*>(pp + 64);
@@ -992,10 +995,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     }
     float M_ = -INFINITY;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) if (cc < C) M_ = fmaxf(M_, ml[cc].x);
+    for (int cc = 0; cc < CM; ++cc) if (cc < C) M_ = fmaxf(M_, ml[cc].x);
     float L = 0.f, O0 = 0.f, O1 = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
+    for (int cc = 0; cc < CM; ++cc) {
       if (cc < C) {
         const float w = __expf(ml[cc].x - M_);
         L = fmaf(ml[cc].y, w, L); O0 = fmaf(ov[cc].x, w, O0); O1 = fmaf(ov[cc].y, w, O1);
@@ -1016,8 +1019,9 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
-  if (CL <= 128) hipLaunchKernelGGL(dec_cross_attn_kernel<2>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
-  else hipLaunchKernelGGL(dec_cross_attn_kernel<4>, dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
+  if (CL <= 128) hipLaunchKernelGGL((dec_cross_attn_kernel<2, 16>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
+  else if (used <= 6) hipLaunchKernelGGL((dec_cross_attn_kernel<4, 6>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
+  else hipLaunchKernelGGL((dec_cross_attn_kernel<4, 16>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
   return WIS_OK;
 }
 
