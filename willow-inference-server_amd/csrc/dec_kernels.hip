@@ -200,11 +200,10 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 #endif
 // MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
 template <int MB, int MODE, int SC, int RM, bool W8>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
+__device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const int nt, char* smem) {
   typedef typename WFrag<W8>::T WT;
   constexpr int GV_PF = SC > 0 ? SC : 16;
   constexpr int rows = 16;   // full MFMA A fragments (4/8-row tiles were measured: more workgroups only add prologue work)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = p.M, K = p.K;
   const int xstr = KC + 8;
   f16* xs = reinterpret_cast<f16*>(smem);
@@ -212,7 +211,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   float* stats = red + 4 * MB * 64 * 4;
   float* sred = stats + 2 * MAX_ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = blockIdx.x;
   const int ksteps = K / 32;
   const int S = SC > 0 ? SC : KC / 128;          // k-steps per wave per chunk
   const int ksl0 = wave * S;                     // first chunk-local k-step of this wave
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   constexpr int RMAX = fast ? RM : 1;        // RM in {3, 5, 8}: smallest that holds M (rows >= M are clamped duplicates)
   float4 xv[RMAX][2];
   float cshift[RMAX];
-  unsigned long long* pf = (blockIdx.x == 0 && tid == 0) ? p.prof : nullptr;
+  unsigned long long* pf = (nt == 0 && tid == 0) ? p.prof : nullptr;
   if (tid == 0) tl_begin(p.prof);
   stamp(pf, 0);
   if (fast) {
@@ -254,7 +252,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   const int c8 = KC >> 3, k8n = K >> 3, nx = M * c8;     // 16-byte pieces per chunk row / per full row / per chunk
   if (fastx) {
     const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
-    if (MB == 1 || KC == K) {   // MB == 1: the launcher only selects this mode for a single chunk
+    if (p.x2) {                 // columns >= xsplit come from a second row-major matrix (the fused out-proj + cross-Q stage)
+      const u32x4* y8 = reinterpret_cast<const u32x4*>(p.x2);
+      const int s8 = p.xsplit >> 3, r8 = c8 - s8;
+#pragma unroll
+      for (int i = 0; i < NXH; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < nx) { const int row = idx / c8, col = idx - row * c8; xh[i] = col < s8 ? x8[(size_t)row * s8 + col] : y8[(size_t)row * r8 + (col - s8)]; }
+      }
+    } else if (MB == 1 || KC == K) {   // MB == 1: the launcher only selects this mode for a single chunk
 #pragma unroll
       for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) xh[i] = x8[idx]; }
     } else {
@@ -437,7 +443,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
         if (p.flags & GV_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
         const size_t o = (size_t)m * p.N + n;
         if (p.flags & GV_RESID) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(ep_res.x + s.x, ep_res.y + s.y, ep_res.z + s.z, ep_res.w + s.w);
+          const float4 r = make_float4(ep_res.x + s.x, ep_res.y + s.y, ep_res.z + s.z, ep_res.w + s.w);
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = r;
+          if (p.y16) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y16 + o) = h; }   // f16 copy: next layer's folded cross-Q input
         } else if (p.flags & GV_OUT_F32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = s;
         } else {
@@ -449,6 +457,39 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
   }
   stamp(pf, 6);
   if (tid == 0) tl_end(p.prof);
+}
+template <int MB, int MODE, int SC, int RM, bool W8>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemv_body<MB, MODE, SC, RM, W8>(p, KC, blockIdx.x, smem);
+}
+// Two skinny GEMMs in ONE launch (workgroups [0, nA) run problem A, the rest problem B; both f16-activation, single-chunk,
+// <= 16 rows): the decoder's attention output projection together with the cross-attention query projection folded THROUGH it
+// (model.hip fused_out_cq): one dependent stage instead of two.
+template <int SCA, int SCB>
+__global__ __launch_bounds__(256) void gemv_dual_kernel(GemvP pa, GemvP pb, int nA) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < nA) gemv_body<1, 2, SCA, 1, false>(pa, pa.K, blockIdx.x, smem);
+  else gemv_body<1, 2, SCB, 1, false>(pb, pb.K, (int)blockIdx.x - nA, smem);
+}
+int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
+  if (pa.M != pb.M || pa.M < 1 || pa.M > 16 || pa.wscale || pb.wscale || (pa.flags & (GV_LN | GV_QKV)) || (pb.flags & (GV_LN | GV_QKV))) { set_error("gemv_dual: unsupported pair"); return WIS_E_UNSUPPORTED; }
+  if (pa.M * (pa.K / 8) > 13 * 256 || pb.M * (pb.K / 8) > 13 * 256 || pa.K % 128 || pb.K % 128) { set_error("gemv_dual: rows do not fit the register staging (M=%d K=%d/%d)", pa.M, pa.K, pb.K); return WIS_E_UNSUPPORTED; }
+  const int sa = pa.K / 128, sb = pb.K / 128;
+  const size_t aux = (size_t)4 * 64 * 16 + MAX_ROWS * 8 + 4 * 16 * 4 + 16;
+  const int Kmax = pa.K > pb.K ? pa.K : pb.K;
+  const size_t lds = (((size_t)pa.M * (Kmax + 8) * 2 + 15) & ~(size_t)15) + aux;
+  if (lds > 65536) { set_error("gemv_dual: LDS"); return WIS_E_UNSUPPORTED; }
+  const int nA = cdiv(pa.N, 16), nB = cdiv(pb.N, 16);
+  dim3 grid(nA + nB), block(256);
+  GemvP a = pa, b = pb; a.rows = 16; b.rows = 16;
+  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, a, b, nA);
+  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, a, b, nA);
+  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, a, b, nA);
+  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, a, b, nA);
+  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, a, b, nA);
+  else { set_error("gemv_dual: K=%d/%d not instantiated", pa.K, pb.K); return WIS_E_UNSUPPORTED; }
+  return WIS_OK;
 }
 
 int launch_gemv(hipStream_t st, const GemvP& p) {
@@ -706,14 +747,18 @@ int launch_dec_embed_xf(hipStream_t st, const f16* emb, const f16* pos_emb, cons
 // =======================================================================================
 // x[m] = E[tok[m]] + pos_emb[pos[m]]   (no embedding scale; learned positions) -> fp32
 __global__ void dec_embed_kernel(const f16* __restrict__ emb, const f16* __restrict__ pos_emb, const int* __restrict__ tok,
-                                 const int* __restrict__ pos, float* __restrict__ x, int d) {
+                                 const int* __restrict__ pos, float* __restrict__ x, f16* __restrict__ xh, int d) {
   const int m = blockIdx.x;
   const f16* e = emb + (size_t)tok[m] * d;
   const f16* pe = pos_emb + (size_t)pos[m] * d;
-  for (int i = threadIdx.x; i < d; i += blockDim.x) x[(size_t)m * d + i] = (float)e[i] + (float)pe[i];
+  for (int i = threadIdx.x; i < d; i += blockDim.x) {
+    const float v = (float)e[i] + (float)pe[i];
+    x[(size_t)m * d + i] = v;
+    if (xh) xh[(size_t)m * d + i] = (f16)v;          // f16 copy of the layer input (fused out-proj + cross-Q stage)
+  }
 }
-int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d) {
-  hipLaunchKernelGGL(dec_embed_kernel, dim3(M), dim3(256), 0, st, emb, pos_emb, tok, pos, x, d);
+int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh) {
+  hipLaunchKernelGGL(dec_embed_kernel, dim3(M), dim3(256), 0, st, emb, pos_emb, tok, pos, x, xh, d);
   return WIS_OK;
 }
 
@@ -844,10 +889,13 @@ constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16
 // CM = the most chunks the combine handles (its partial buffers are register arrays of that size): 6 for the default 256-key
 // chunking, 16 otherwise.  With [16] arrays at every chunking the kernel needed 218 VGPRs - two workgroups per CU, so the 960
 // workgroups of an 8-utterance batch ran in two rounds; with CM = 6 it needs 88 (five per CU).
-template <int TPW, int CM>
+// FOLD: the folded-query prologue (B = 1-sized row counts only; its own instantiation so that the batched kernel keeps its
+// register budget).
+template <int TPW, int CM, bool FOLD>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
-                                                             int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb) {
+                                                             int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb,
+                                                             const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb) {
   __shared__ float ssc[16][257];
   __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
   __shared__ float smax[16][16];
@@ -864,8 +912,23 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // ---- loads: Q (B operand, lane = (row r, k-quarter)), K fragments, V^T fragments
   const int rq = l15 < R ? l15 : R - 1;
   const float* qp = q + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
-  const float4 qa0 = *reinterpret_cast<const float4*>(qp), qa1 = *reinterpret_cast<const float4*>(qp + 4);
-  const float4 qb0 = *reinterpret_cast<const float4*>(qp + 32), qb1 = *reinterpret_cast<const float4*>(qp + 36);
+  const float4 qa0_ = *reinterpret_cast<const float4*>(qp), qa1_ = *reinterpret_cast<const float4*>(qp + 4);
+  const float4 qb0_ = *reinterpret_cast<const float4*>(qp + 32), qb1_ = *reinterpret_cast<const float4*>(qp + 36);
+  // Folded query (model.hip fused_out_cq): `q` holds q_raw = W'x0 + (W'Wo) a + W'bo of the LayerNorm-folded cross-attention query
+  // projection, computed one stage early from the layer input and the self-attention output; the LayerNorm statistics belong
+  // to the rows the out-projection has produced SINCE (xres = x1, fp32 [B*R][d]).  Every workgroup reduces its utterance's R
+  // rows itself (R x d floats from L2, requested together with K and V) and finishes q = rs (q_raw - mu c) + b'.
+  constexpr int NXS = FOLD ? 10 : 1;                      // float4 per thread: R * d / 4 <= 2560 (R <= 8, d <= 1280)
+  float4 xs4[NXS]; float4 cs0, cs1, cs2, cs3, bq0, bq1, bq2, bq3;
+  const int d4 = d >> 2;
+  if (FOLD) {
+    const float4* xr = reinterpret_cast<const float4*>(xres) + (size_t)b * R * d4;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) { const int idx = tid + 256 * i; xs4[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (idx < R * d4) xs4[i] = xr[idx]; }
+    const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
+    cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
+    bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
+  }
   const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
   u32x4 kf[TPW][2];
 #pragma unroll
@@ -881,6 +944,42 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
   stamp(pf, 1);
 
+  float4 qa0 = qa0_, qa1 = qa1_, qb0 = qb0_, qb1 = qb1_;
+  if (FOLD) {
+    // row sums in a FIXED order (bit-reproducible): per-thread piece sums, then for every row a DPP wave reduction of the
+    // pieces that belong to it, one LDS slot per (wave, row), four-way sum below
+    __shared__ float srow[16][2];
+    float* sacc = &ssc[0][0];                             // [4 waves][16 rows][2], ssc is free until the scores are written
+    float p1[NXS], p2[NXS]; int prow[NXS];
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int idx = tid + 256 * i;
+      const float4 v = xs4[i];
+      p1[i] = (v.x + v.y) + (v.z + v.w); p2[i] = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      prow[i] = idx < R * d4 ? idx / d4 : -1;
+    }
+    for (int r = 0; r < R; ++r) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) if (prow[i] == r) { a1 += p1[i]; a2 += p2[i]; }
+      a1 = wave_sum(a1); a2 = wave_sum(a2);
+      if (lane == 0) { sacc[(wave * 16 + r) * 2] = a1; sacc[(wave * 16 + r) * 2 + 1] = a2; }
+    }
+    __syncthreads();
+    if (tid < R) {
+      const float s1 = (sacc[(0 * 16 + tid) * 2] + sacc[(1 * 16 + tid) * 2]) + (sacc[(2 * 16 + tid) * 2] + sacc[(3 * 16 + tid) * 2]);
+      const float s2 = (sacc[(0 * 16 + tid) * 2 + 1] + sacc[(1 * 16 + tid) * 2 + 1]) + (sacc[(2 * 16 + tid) * 2 + 1] + sacc[(3 * 16 + tid) * 2 + 1]);
+      const float mu = s1 / (float)d;
+      srow[tid][0] = mu; srow[tid][1] = 1.0f / sqrtf(fmaxf(s2 / (float)d - mu * mu, 0.f) + 1e-5f);
+    }
+    __syncthreads();
+    const float mu = srow[rq][0], rs = srow[rq][1];
+    qa0 = make_float4(rs * (qa0.x - mu * cs0.x) + bq0.x, rs * (qa0.y - mu * cs0.y) + bq0.y, rs * (qa0.z - mu * cs0.z) + bq0.z, rs * (qa0.w - mu * cs0.w) + bq0.w);
+    qa1 = make_float4(rs * (qa1.x - mu * cs1.x) + bq1.x, rs * (qa1.y - mu * cs1.y) + bq1.y, rs * (qa1.z - mu * cs1.z) + bq1.z, rs * (qa1.w - mu * cs1.w) + bq1.w);
+    qb0 = make_float4(rs * (qb0.x - mu * cs2.x) + bq2.x, rs * (qb0.y - mu * cs2.y) + bq2.y, rs * (qb0.z - mu * cs2.z) + bq2.z, rs * (qb0.w - mu * cs2.w) + bq2.w);
+    qb1 = make_float4(rs * (qb1.x - mu * cs3.x) + bq3.x, rs * (qb1.y - mu * cs3.y) + bq3.y, rs * (qb1.z - mu * cs3.z) + bq3.z, rs * (qb1.w - mu * cs3.w) + bq3.w);
+    __syncthreads();                                       // sacc aliases ssc: the scores are written next
+  }
   f16x8 qf0, qf1;
   qf0[0] = (f16)qa0.x; qf0[1] = (f16)qa0.y; qf0[2] = (f16)qa0.z; qf0[3] = (f16)qa0.w; qf0[4] = (f16)qa1.x; qf0[5] = (f16)qa1.y; qf0[6] = (f16)qa1.z; qf0[7] = (f16)qa1.w;
   qf1[0] = (f16)qb0.x; qf1[1] = (f16)qb0.y; qf1[2] = (f16)qb0.z; qf1[3] = (f16)qb0.w; qf1[4] = (f16)qb1.x; qf1[5] = (f16)qb1.y; qf1[6] = (f16)qb1.z; qf1[7] = (f16)qb1.w;
@@ -1014,14 +1113,18 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 }
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb) {
+                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
+                          const float* xres, const float* qcs, const float* qb) {
+  if (xres && (!qcs || !qb || R * (d >> 2) > 10 * 256)) { set_error("dec_cross_attn: folded query needs column sums, bias and R*d <= 10240"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
-  if (CL <= 128) hipLaunchKernelGGL((dec_cross_attn_kernel<2, 16>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
-  else if (used <= 6) hipLaunchKernelGGL((dec_cross_attn_kernel<4, 6>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
-  else hipLaunchKernelGGL((dec_cross_attn_kernel<4, 16>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, R, H, d, T, Tpad, used, CL, prof, out_mb);
+#define WIS_CA(TPWv, CMv, FOLDv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, \
+                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb)
+  if (xres) { if (CL <= 128) WIS_CA(2, 16, true); else if (used <= 6) WIS_CA(4, 6, true); else WIS_CA(4, 16, true); }
+  else { if (CL <= 128) WIS_CA(2, 16, false); else if (used <= 6) WIS_CA(4, 6, false); else WIS_CA(4, 16, false); }
+#undef WIS_CA
   return WIS_OK;
 }
 

@@ -438,9 +438,9 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float pv = exp2f(fmaf(st[t2][r], LOG2E, -m_new)); st[t2][r] = pv; rs += pv; }
+      for (int r = 0; r < 16; ++r) { const float pv = __builtin_amdgcn_exp2f(fmaf(st[t2][r], LOG2E, -m_new)); st[t2][r] = pv; rs += pv; }   // raw v_exp_f32: arguments are <= 0, a flushed denormal is an exact 0 weight (libm's exp2f wraps it in 5 range-fixup instructions)
     if (__any(grew)) {
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
       for (int a = 0; a < 2; ++a)

@@ -53,6 +53,8 @@ struct GemvP {
   float* q; f16* kc; f16* vc; const int* slot; const int* pos; int d; int ctx;   // cache [slots][ctx][d]
   unsigned long long* prof;      // optional phase stamps (workgroup 0)
   int rows;                      // weight rows per workgroup tile (16 / 8 / 4; 0 => 16): must match the packing
+  const void* x2; int xsplit;    // f16 activations only: columns >= xsplit are read from x2 (row-major [M][K - xsplit]); x then is [M][xsplit]
+  f16* y16;                      // GV_RESID: optional f16 row-major copy of the produced rows
   // ---- batched rows (launch_gemv_frag, M > 8): activations live in HBM in MFMA B-fragment order ("xf", xf_index below)
   int xmb;                       // 16-row blocks of the x fragment image (= ceil(M / 16))
   const float* stat_in;          // GV_LN: per-row partial sums of the raw fp32 rows, [M][K/16][2] = (sum x, sum x^2) per 16 columns
@@ -61,6 +63,7 @@ struct GemvP {
   int ymb;                       // 16-row blocks of y_xf (0: f16 output stays row-major [M][N])
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
+int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // two f16-activation skinny GEMMs in one launch
 // Batched decode rows (8 < M <= 48).  The skinny GEMM reads its activations as ready-made MFMA B fragments straight from L2
 // (written in that order by the producing kernel: no per-workgroup LDS staging, no staging barrier, many workgroups per CU), and
 // the pre-LN LayerNorm needs no launch of its own: every residual epilogue leaves per-16-column partial sums of the rows it
@@ -82,7 +85,7 @@ int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* sc
 int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale, int rows = 16);
 int gemv_rows_for(int N, int K);     // tile height used for an [N][K] decoder matrix
 
-int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d);
+int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh = nullptr);
 // logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
 // out_mb: 0 = out is row-major f16 [M][d]; > 0 = fragment image with that many 16-row blocks (batched decode)
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
@@ -90,7 +93,8 @@ int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f1
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
-                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0);
+                          int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0,
+                          const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr);   // folded query: see the kernel
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

@@ -65,6 +65,29 @@ __global__ void mel_to_image_kernel(const float* __restrict__ mel, f16* __restri
     if (f0 + f < 3000) img[((size_t)w * 3002 + f0 + f + 1) * 96 + c] = (c < 80) ? (f16)s_t[c][f] : (f16)0.f;
   }
 }
+// dst[c][r] = src[r][c] as f16 (src f16 or f32, [rows][cols])
+__global__ void transpose_to_f16_kernel(const void* __restrict__ src, int src_f16, f16* __restrict__ dst, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) t[i][tx] = src_f16 ? (float)reinterpret_cast<const f16*>(src)[(size_t)r * cols + c] : reinterpret_cast<const float*>(src)[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = (f16)t[tx][i];
+  }
+}
+// y[n] = sum_k W[n][k] x[k]  (W f16 rows of pitch ld, x fp32); one wave per row
+__global__ void matvec_rows_kernel(const f16* __restrict__ W, int ld, const float* __restrict__ x, float* __restrict__ y, int N, int K) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) a += (float)W[(size_t)n * ld + k] * x[k];
+  a = wave_sum(a);
+  if (lane == 0) y[n] = a;
+}
 __global__ void f16_to_f32_kernel(const f16* __restrict__ s, float* __restrict__ d, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
 }
@@ -83,6 +106,7 @@ struct DecLayerW {
   float *b_qkv, *b_out, *b_cq, *b_ckv, *b_cout, *b_f1, *b_f2;
   float *s_qkv = nullptr, *s_out = nullptr, *s_cq = nullptr, *s_cout = nullptr, *s_f1 = nullptr, *s_f2 = nullptr;   // int8_float16: row scales
   float *c_qkv = nullptr, *c_cq = nullptr, *c_f1 = nullptr;   // column sums of the LayerNorm-folded weights (dec_kernels.hip fold_ln_kernel)
+  f16* p_cqo = nullptr; float* b_cqo = nullptr;               // cross-Q folded THROUGH the out-projection: packed [W'q | W'q Wo] ([d][2d]) and W'q bo (fused_out_cq)
 };
 
 struct GraphKey {
@@ -129,6 +153,8 @@ struct wis_model {
   float* s_proj = nullptr;      // int8_float16: row scales of the vocabulary projection
   float* c_proj = nullptr; float* b_proj = nullptr;   // LayerNorm-folded vocabulary projection: column sums, W . beta
   bool w8 = false;              // decoder weights stored as 8-bit packed fragments
+  bool cq_fold = false;         // f16 decoder weights: the fused out-projection + cross-Q stage is available (p_cqo)
+  f16* dxh = nullptr;           // f16 row-major copy of the layer input rows (written by the embedding / FFN2 epilogues)
   unsigned long long* d_prof;   // [L*8][16] stamp rows, one per layer kernel (wis_debug_phase_cycles / wis_debug_timeline)
   bool prof_on; bool prof_all;
 };
@@ -228,9 +254,15 @@ int load_weights(wis_model* m, const Loader& L) {
   const int d = c.d_model, V = c.n_vocab;
   const float qs = 0.125f;   // 1/sqrt(64), folded into the query projections (exact: power of two)
   f16* tmp = nullptr;        // staging for packed conversions: largest matrix = embeddings [V][d]
+  f16 *fcat = nullptr, *fwot = nullptr, *fwqo = nullptr;      // cross-Q fold staging: [W'q | W'q Wo] [d][2d], Wo^T, W'q Wo
   {
     size_t big = (size_t)V * d; if ((size_t)4 * d * d > big) big = (size_t)4 * d * d;
     WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), big * 2));
+    if (m->cq_fold) {
+      WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fcat), (size_t)2 * d * d * 2));
+      WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fwot), (size_t)d * d * 2));
+      WIS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fwqo), (size_t)d * d * 2));
+    }
   }
   int rc = WIS_OK;
   do {
@@ -309,6 +341,23 @@ int load_weights(wis_model* m, const Loader& L) {
       if ((rc = to_f32(m, L, p + "attention/layer_norm/beta", d, &w.ln2_b))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_0/bias", d, &w.b_cq, d, qs))) break;
       if ((rc = to_packed(m, L, p + "attention/linear_0/weight", d, d, &w.p_cq, tmp, d, qs, nullptr, &w.s_cq, w.ln2_g, w.ln2_b, w.b_cq, &w.c_cq))) break;
+      if (m->cq_fold) {
+        // Cross-attention query folded through the self-attention output projection (one dependent stage less per layer):
+        //   x1 = x0 + Wo a + bo,   q = rs(x1) (W'q x1 - mu(x1) c) + b'      (LayerNorm-folded form, W'q = (Wq o gamma) / 8)
+        //   W'q x1 = W'q x0 + (W'q Wo) a + W'q bo  =: q_raw  - computable from the LAYER INPUT x0 and the attention output a, i.e.
+        // in the same launch as the out-projection; mu / rs of x1 are applied by the cross-attention kernel (dec_kernels.hip).
+        // tmp holds f16(Wq o gamma) (to_packed above); W'q Wo is rounded to f16 like every other stored weight.
+        TensorSrc so; if ((rc = L.get(p + "self_attention/linear_1/weight", d, d, &so))) break;
+        hipLaunchKernelGGL(convert_kernel, dim3(blocks_for((int64_t)d * d)), dim3(256), 0, m->st, tmp, 1, fcat, 1, (int64_t)d, (int64_t)d, (int64_t)2 * d, (int64_t)d, qs);   // left half: W'q
+        hipLaunchKernelGGL(transpose_to_f16_kernel, dim3(cdiv(d, 32), cdiv(d, 32)), dim3(256), 0, m->st, so.p, so.f16, fwot, d, d);
+        GemmP gp = gemm_plain(fcat, 2 * d, fwot, d, d, d);
+        if ((rc = launch_gemm_generic(m->st, gp, nullptr, nullptr, fwqo, 0))) break;                                     // W'q . Wo  (f16 inputs, fp32 accumulate)
+        hipLaunchKernelGGL(convert_kernel, dim3(blocks_for((int64_t)d * d)), dim3(256), 0, m->st, fwqo, 1, fcat + d, 1, (int64_t)d, (int64_t)d, (int64_t)2 * d, (int64_t)0, 1.f);   // right half
+        if ((rc = dalloc(m, &w.p_cqo, (size_t)d * 2 * d))) break;
+        if ((rc = launch_pack_gemv(m->st, fcat, w.p_cqo, d, d, 2 * d, 0, 1.f, 16))) break;
+        if ((rc = dalloc(m, &w.b_cqo, (size_t)d))) break;
+        hipLaunchKernelGGL(matvec_rows_kernel, dim3(d), dim3(64), 0, m->st, fcat, 2 * d, w.b_out, w.b_cqo, d, d);
+      }
       w.w_ckv = m->w_ckv_all + (size_t)l * 2 * d * d; w.b_ckv = m->b_ckv_all + (size_t)l * 2 * d;
       if ((rc = to_f16_mat(m, L, p + "attention/linear_1/weight", 2 * d, d, &w.w_ckv))) break;
       if ((rc = to_f32(m, L, p + "attention/linear_1/bias", 2 * d, &w.b_ckv))) break;
@@ -323,7 +372,7 @@ int load_weights(wis_model* m, const Loader& L) {
     }
   } while (0);
   hipError_t e = hipStreamSynchronize(m->st);
-  hipFree(tmp);
+  hipFree(tmp); hipFree(fcat); hipFree(fwot); hipFree(fwqo);
   if (rc) return rc;
   if (e != hipSuccess) { set_error("weight conversion failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;
@@ -366,6 +415,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->dao, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dh, (size_t)MAX_ROWS * 4 * d));
   WIS_RET(dalloc(m, &m->dln, (size_t)MAX_ROWS * d));
+  WIS_RET(dalloc(m, &m->dxh, (size_t)MAX_ROWS * d));
   {  // fragment images (kernels.hpp xf_index): [K/32][3 row blocks][64][8] f16; zeroed once (rows >= M are never written)
     const size_t blk = (size_t)(MAX_ROWS / 16) * 64 * 8;
     WIS_RET(dalloc(m, &m->dxf, (size_t)(d / 32) * blk)); WIS_RET(dalloc(m, &m->daoxf, (size_t)(d / 32) * blk)); WIS_RET(dalloc(m, &m->dhxf, (size_t)(4 * d / 32) * blk));
@@ -525,7 +575,9 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   const int chunks = env_chunks ? env_chunks : 6;
   static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;      // A/B switch: the round-1 batched path (LayerNorm launches + LDS-staged rows)
   if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
-  WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d));
+  // fused out-proj + cross-Q stage (load_weights: cq_fold): f16 decoder weights, <= 8 rows (the LayerNorm-fused row counts)
+  const bool fold = m->cq_fold && M <= 8;
+  WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
     // stamp rows of this layer's 8 kernels: QKV, self-attn, out, cross-Q, cross-attn, cross-out, FFN1, FFN2
@@ -538,6 +590,17 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
+    if (fold) {
+      // ONE launch: x1 = x0 + Wo a + bo (tiles [0, d/16)) and q_raw = W'q x0 + (W'q Wo) a + W'q bo (the other d/16 tiles); the
+      // cross-attention kernel applies the LayerNorm statistics of x1 (rs, mu) and b' to q_raw
+      GemvP ga; memset(&ga, 0, sizeof(ga));
+      ga.x = m->dao; ga.Wp = w.p_out; ga.bias = w.b_out; ga.y = m->dx; ga.M = M; ga.N = d; ga.K = d; ga.flags = GV_RESID; ga.prof = pr ? pr + 32 : nullptr;
+      GemvP gb; memset(&gb, 0, sizeof(gb));
+      gb.x = m->dxh; gb.x2 = m->dao; gb.xsplit = d; gb.Wp = w.p_cqo; gb.bias = w.b_cqo; gb.y = m->dq; gb.M = M; gb.N = d; gb.K = 2 * d; gb.flags = GV_OUT_F32;
+      WIS_RET(launch_gemv_dual(st, ga, gb));
+      WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
+                                    m->dx, w.c_cq, w.b_cq));
+    } else {
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.wscale = w.s_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
@@ -548,6 +611,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
+    }
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
@@ -559,6 +623,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
     g.x = m->dh; g.Wp = w.p_f2; g.wscale = w.s_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 112 : nullptr;
+    g.y16 = fold ? m->dxh : nullptr;             // the next layer's x0 in f16
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
@@ -618,6 +683,7 @@ int wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_by
   wis_model* m = new wis_model();
   m->cfg = *cfg; m->device = device; m->ctx = ctx;
   m->w8 = cfg->decoder_weight_bits == 8;
+  m->cq_fold = !m->w8 && getenv("WIS_NO_CQFOLD") == nullptr;     // (8-bit weights keep the two-stage form: the fold would change what is quantised)
   m->use_graph = getenv("WIS_NO_GRAPH") == nullptr;
   memset(&m->timing, 0, sizeof(m->timing));
   int rc = WIS_OK;
