@@ -918,13 +918,18 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // projection, computed one stage early from the layer input and the self-attention output; the LayerNorm statistics belong
   // to the rows the out-projection has produced SINCE (xres = x1, fp32 [B*R][d]).  Every workgroup reduces its utterance's R
   // rows itself (R x d floats from L2, requested together with K and V) and finishes q = rs (q_raw - mu c) + b'.
-  constexpr int NXS = FOLD ? 10 : 1;                      // float4 per thread: R * d / 4 <= 2560 (R <= 8, d <= 1280)
-  float4 xs4[NXS]; float4 cs0, cs1, cs2, cs3, bq0, bq1, bq2, bq3;
+  // wave w reduces rows w and w + 4 of the utterance (R <= 8): 5 float4 per lane and row cover d <= 1280
+  constexpr int NXS = FOLD ? 5 : 1;
+  float4 xs4[2][NXS]; float4 cs0, cs1, cs2, cs3, bq0, bq1, bq2, bq3;
   const int d4 = d >> 2;
   if (FOLD) {
-    const float4* xr = reinterpret_cast<const float4*>(xres) + (size_t)b * R * d4;
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) { const int idx = tid + 256 * i; xs4[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (idx < R * d4) xs4[i] = xr[idx]; }
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave + 4 * j;
+      const float4* xr = reinterpret_cast<const float4*>(xres) + (size_t)(b * R + (r < R ? r : R - 1)) * d4;
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) { const int c4 = lane + 64 * i; xs4[j][i] = make_float4(0.f, 0.f, 0.f, 0.f); if (c4 < d4) xs4[j][i] = xr[c4]; }
+    }
     const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
     cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
     bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
@@ -946,39 +951,25 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 
   float4 qa0 = qa0_, qa1 = qa1_, qb0 = qb0_, qb1 = qb1_;
   if (FOLD) {
-    // row sums in a FIXED order (bit-reproducible): per-thread piece sums, then for every row a DPP wave reduction of the
-    // pieces that belong to it, one LDS slot per (wave, row), four-way sum below
+    // mean / rstd of the rows: a DPP wave reduction per row (fixed order: bit-reproducible), published through LDS behind a RAW
+    // barrier - `__syncthreads()` would first wait for every outstanding load, i.e. for the K / V fragments this prologue is
+    // supposed to run in the shadow of (measured with three `__syncthreads()` here: cross-attention 9.0 -> 12.1 us)
     __shared__ float srow[16][2];
-    float* sacc = &ssc[0][0];                             // [4 waves][16 rows][2], ssc is free until the scores are written
-    float p1[NXS], p2[NXS]; int prow[NXS];
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      const int idx = tid + 256 * i;
-      const float4 v = xs4[i];
-      p1[i] = (v.x + v.y) + (v.z + v.w); p2[i] = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-      prow[i] = idx < R * d4 ? idx / d4 : -1;
-    }
-    for (int r = 0; r < R; ++r) {
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave + 4 * j;
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < NXS; ++i) if (prow[i] == r) { a1 += p1[i]; a2 += p2[i]; }
+      for (int i = 0; i < NXS; ++i) { const float4 v = xs4[j][i]; a1 += (v.x + v.y) + (v.z + v.w); a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
       a1 = wave_sum(a1); a2 = wave_sum(a2);
-      if (lane == 0) { sacc[(wave * 16 + r) * 2] = a1; sacc[(wave * 16 + r) * 2 + 1] = a2; }
+      if (lane == 0 && r < R) { const float mu = a1 / (float)d; srow[r][0] = mu; srow[r][1] = 1.0f / sqrtf(fmaxf(a2 / (float)d - mu * mu, 0.f) + 1e-5f); }
     }
-    __syncthreads();
-    if (tid < R) {
-      const float s1 = (sacc[(0 * 16 + tid) * 2] + sacc[(1 * 16 + tid) * 2]) + (sacc[(2 * 16 + tid) * 2] + sacc[(3 * 16 + tid) * 2]);
-      const float s2 = (sacc[(0 * 16 + tid) * 2 + 1] + sacc[(1 * 16 + tid) * 2 + 1]) + (sacc[(2 * 16 + tid) * 2 + 1] + sacc[(3 * 16 + tid) * 2 + 1]);
-      const float mu = s1 / (float)d;
-      srow[tid][0] = mu; srow[tid][1] = 1.0f / sqrtf(fmaxf(s2 / (float)d - mu * mu, 0.f) + 1e-5f);
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float mu = srow[rq][0], rs = srow[rq][1];
     qa0 = make_float4(rs * (qa0.x - mu * cs0.x) + bq0.x, rs * (qa0.y - mu * cs0.y) + bq0.y, rs * (qa0.z - mu * cs0.z) + bq0.z, rs * (qa0.w - mu * cs0.w) + bq0.w);
     qa1 = make_float4(rs * (qa1.x - mu * cs1.x) + bq1.x, rs * (qa1.y - mu * cs1.y) + bq1.y, rs * (qa1.z - mu * cs1.z) + bq1.z, rs * (qa1.w - mu * cs1.w) + bq1.w);
     qb0 = make_float4(rs * (qb0.x - mu * cs2.x) + bq2.x, rs * (qb0.y - mu * cs2.y) + bq2.y, rs * (qb0.z - mu * cs2.z) + bq2.z, rs * (qb0.w - mu * cs2.w) + bq2.w);
     qb1 = make_float4(rs * (qb1.x - mu * cs3.x) + bq3.x, rs * (qb1.y - mu * cs3.y) + bq3.y, rs * (qb1.z - mu * cs3.z) + bq3.z, rs * (qb1.w - mu * cs3.w) + bq3.w);
-    __syncthreads();                                       // sacc aliases ssc: the scores are written next
   }
   f16x8 qf0, qf1;
   qf0[0] = (f16)qa0.x; qf0[1] = (f16)qa0.y; qf0[2] = (f16)qa0.z; qf0[3] = (f16)qa0.w; qf0[4] = (f16)qa1.x; qf0[5] = (f16)qa1.y; qf0[6] = (f16)qa1.z; qf0[7] = (f16)qa1.w;
@@ -1115,7 +1106,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
                           const float* xres, const float* qcs, const float* qb) {
-  if (xres && (!qcs || !qb || R * (d >> 2) > 10 * 256)) { set_error("dec_cross_attn: folded query needs column sums, bias and R*d <= 10240"); return WIS_E_ARG; }
+  if (xres && (!qcs || !qb || R > 8 || d > 1280)) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
