@@ -252,42 +252,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   const int c8 = KC >> 3, k8n = K >> 3, nx = M * c8;     // 16-byte pieces per chunk row / per full row / per chunk
   if (fastx) {
     const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
-    if (p.part) {               // deferred cross-attention combine: the row pieces are built from the chunk partials (kernels.hpp GemvP::part)
-      const int C = p.part_C, R = p.part_R, H = p.part_H;
-#pragma unroll
-      for (int i = 0; i < NXH; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < nx) {
-          const int row = idx / c8, k0 = (idx - row * c8) * 8, h = k0 >> 6, dh0 = k0 & 63, bb = row / R, r = row - bb * R;
-          const float* base = p.part + (((size_t)(bb * H + h) * C) * R + r) * CA_PART;
-          float2 ml[CA_DEFER_MAX]; float4 o0[CA_DEFER_MAX], o1[CA_DEFER_MAX];
-#pragma unroll
-          for (int cc = 0; cc < CA_DEFER_MAX; ++cc) {
-            if (cc < C) {
-              const float* pp = base + (size_t)cc * R * CA_PART;
-              ml[cc] = *reinterpret_cast<const float2*>(pp + 64);
-              o0[cc] = *reinterpret_cast<const float4*>(pp + dh0); o1[cc] = *reinterpret_cast<const float4*>(pp + dh0 + 4);
-            }
-          }
-          float Mx = -INFINITY;
-#pragma unroll
-          for (int cc = 0; cc < CA_DEFER_MAX; ++cc) if (cc < C) Mx = fmaxf(Mx, ml[cc].x);
-          float L = 0.f; float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-#pragma unroll
-          for (int cc = 0; cc < CA_DEFER_MAX; ++cc) {
-            if (cc < C) {
-              const float w = __expf(ml[cc].x - Mx);
-              L = fmaf(ml[cc].y, w, L);
-              a0.x = fmaf(o0[cc].x, w, a0.x); a0.y = fmaf(o0[cc].y, w, a0.y); a0.z = fmaf(o0[cc].z, w, a0.z); a0.w = fmaf(o0[cc].w, w, a0.w);
-              a1.x = fmaf(o1[cc].x, w, a1.x); a1.y = fmaf(o1[cc].y, w, a1.y); a1.z = fmaf(o1[cc].z, w, a1.z); a1.w = fmaf(o1[cc].w, w, a1.w);
-            }
-          }
-          const float inv = 1.0f / L;
-          const f16x8 hv = {(f16)(a0.x * inv), (f16)(a0.y * inv), (f16)(a0.z * inv), (f16)(a0.w * inv), (f16)(a1.x * inv), (f16)(a1.y * inv), (f16)(a1.z * inv), (f16)(a1.w * inv)};
-          xh[i] = *reinterpret_cast<const u32x4*>(&hv);
-        }
-      }
-    } else if (p.x2) {          // columns >= xsplit come from a second row-major matrix (the fused out-proj + cross-Q stage)
+    if (p.x2) {                 // columns >= xsplit come from a second row-major matrix (the fused out-proj + cross-Q stage)
       const u32x4* y8 = reinterpret_cast<const u32x4*>(p.x2);
       const int s8 = p.xsplit >> 3, r8 = c8 - s8;
 #pragma unroll
@@ -567,9 +532,6 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
       else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
     }
   } else if (!(p.flags & GV_LN) && p.M * (KC / 8) <= 30 * 256) mode = 2;       // register-staged f16 chunks (single or multi chunk)
-  if (p.part && !(MB == 1 && mode == 2 && KC == p.K && p.part_C >= 2 && p.part_C <= CA_DEFER_MAX && p.K == 64 * p.part_H)) {
-    set_error("gemv: the deferred cross-attention combine needs <= 16 rows staged from registers, K = 64 H and 2..%d chunks", CA_DEFER_MAX); return WIS_E_UNSUPPORTED;
-  }
   const int sck = KC / 128;
   const int sc = ((KC == p.K || mode == 2) && (sck == 3 || sck == 4 || sck == 6 || sck == 8 || sck == 10)) ? sck : 0;
 #define WIS_GV1(MBv, MODEv, SCv, RMv, W8v) do { \
@@ -933,7 +895,7 @@ template <int TPW, int CM, bool FOLD>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
                                                              int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb,
-                                                             const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb, int defer) {
+                                                             const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb) {
   __shared__ float ssc[16][257];
   __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
   __shared__ float smax[16][16];
@@ -1082,18 +1044,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     return;
   }
   // ---- split-T: publish the partial with write-through stores; the last-arriving workgroup combines
-  float* pbase = part + ((size_t)(b * H + h) * C) * R * CA_PART;
-  if (defer) {       // the consuming projection combines the chunks on load: plain stores, the kernel boundary publishes them
-    if (l15 < R) {
-      float* pp = pbase + ((size_t)c * R + l15) * CA_PART;
-      *reinterpret_cast<float4*>(pp + dh0) = make_float4(oacc[0], oacc[1], oacc[2], oacc[3]);
-      if (wave == 0 && kq == 0) *reinterpret_cast<float2*>(pp + 64) = make_float2(smx[l15], ssum[l15]);
-    }
-    if (tid == 0) tl_end(prof);
-    return;
-  }
+  float* pbase = part + ((size_t)(b * H + h) * C) * R * 66;
   if (l15 < R) {
-    float* pp = pbase + ((size_t)c * R + l15) * CA_PART;
+    float* pp = pbase + ((size_t)c * R + l15) * 66;
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) st_sc1(pp + dh0 + r4, oacc[r4]);
     if (wave == 0 && kq == 0) { st_sc1(pp + 64, smx[l15]); st_sc1(pp + 65, ssum[l15]); }
@@ -1125,7 +1078,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 #pragma unroll
     for (int cc = 0; cc < CM; ++cc) {
       if (cc < C) {
-        const float* pp = pbase + ((size_t)cc * R + r) * CA_PART;
+        const float* pp = pbase + ((size_t)cc * R + r) * 66;
         ml[cc] = *reinterpret_cast<const float2*>(pp + 64);
         ov[cc] = *reinterpret_cast<const float2*>(pp + 2 * dp);
       }
@@ -1152,16 +1105,14 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
-                          const float* xres, const float* qcs, const float* qb, bool defer_combine) {
+                          const float* xres, const float* qcs, const float* qb) {
   if (xres && (!qcs || !qb || R > 8 || d > 1280)) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
 #define WIS_CA(TPWv, CMv, FOLDv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, \
-                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb, dfr)
-  if (defer_combine && (used > CA_DEFER_MAX || used < 2)) { set_error("dec_cross_attn: the deferred combine handles 2..%d chunks (%d)", CA_DEFER_MAX, used); return WIS_E_UNSUPPORTED; }
-  const int dfr = defer_combine ? 1 : 0;
+                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb)
   if (xres) { if (CL <= 128) WIS_CA(2, 16, true); else if (used <= 6) WIS_CA(4, 6, true); else WIS_CA(4, 16, true); }
   else { if (CL <= 128) WIS_CA(2, 16, false); else if (used <= 6) WIS_CA(4, 6, false); else WIS_CA(4, 16, false); }
 #undef WIS_CA

@@ -53,10 +53,6 @@ struct GemvP {
   float* q; f16* kc; f16* vc; const int* slot; const int* pos; int d; int ctx;   // cache [slots][ctx][d]
   unsigned long long* prof;      // optional phase stamps (workgroup 0)
   int rows;                      // weight rows per workgroup tile (16 / 8 / 4; 0 => 16): must match the packing
-  // f16 activations computed on load from the cross-attention chunk partials (deferred combine): a[m][64 h + j] =
-  // sum_c w_c o_c[j] / sum_c w_c l_c, w_c = exp(max_c - max) - the cross-attention kernel then ends at its partial stores (no
-  // ticket, no acquire fence, no reload); part_C chunks (<= CA_DEFER_MAX), part_R rows per utterance, part_H heads
-  const float* part; int part_C, part_R, part_H;
   const void* x2; int xsplit;    // f16 activations only: columns >= xsplit are read from x2 (row-major [M][K - xsplit]); x then is [M][xsplit]
   f16* y16;                      // GV_RESID: optional f16 row-major copy of the produced rows
   // ---- batched rows (launch_gemv_frag, M > 8): activations live in HBM in MFMA B-fragment order ("xf", xf_index below)
@@ -98,15 +94,7 @@ int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f1
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0,
-                          const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr,   // folded query: see the kernel
-                          bool defer_combine = false);   // true: leave the chunk partials in `part` for the consuming projection (out is not written)
-
-// cross-attention chunk partials: [(b * H + h)][chunk][row][CA_PART] fp32 = o[64] (un-normalised), chunk max, chunk sum, padding
-// (68 floats = 272 B: every row is 16-byte aligned for the float4 loads of the consumer-side combine)
-constexpr int CA_PART = 68;
-// chunks that actually hold keys for a request of `chunks` chunks over T keys (chunk length: a multiple of 32 keys)
-static inline int cross_chunks_used(int T, int chunks) { const int CL = cdiv(cdiv(T, chunks), 32) * 32; return cdiv(T, CL); }
-constexpr int CA_DEFER_MAX = 6;   // chunks the consumer-side combine (gemv MODE 2 with GemvP::part) handles
+                          const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr);   // folded query: see the kernel
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

@@ -424,7 +424,7 @@ int alloc_buffers(wis_model* m) {
     WIS_HIP_CHECK(hipMemsetAsync(m->dhxf, 0, (size_t)(4 * d / 32) * blk * 2, m->st));
   }
   WIS_RET(dalloc(m, &m->logits, (size_t)MAX_ROWS * m->n_vocab_pad));
-  WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * CA_PART));
+  WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * 66));
   WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
   WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bm * H * 4, m->st));
   WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
@@ -577,12 +577,6 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
   // fused out-proj + cross-Q stage (load_weights: cq_fold): f16 decoder weights, <= 8 rows (the LayerNorm-fused row counts)
   const bool fold = m->cq_fold && M <= 8;
-  // deferred cross-attention combine (<= 8 rows): the attention kernel ends at its chunk partials, the output projection that
-  // follows builds its f16 activation rows from them while it waits for its weights - the in-launch ticket, the agent-scope
-  // acquire and the partial reload (about half of the attention kernel's time at one utterance) leave the step
-  static const bool no_defer = getenv("WIS_NO_DEFER") != nullptr;
-  const int used_chunks = cross_chunks_used(T, chunks);
-  const bool defer = !no_defer && M <= 8 && used_chunks >= 2 && used_chunks <= CA_DEFER_MAX;
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
@@ -605,7 +599,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
       gb.x = m->dxh; gb.x2 = m->dao; gb.xsplit = d; gb.Wp = w.p_cqo; gb.bias = w.b_cqo; gb.y = m->dq; gb.M = M; gb.N = d; gb.K = 2 * d; gb.flags = GV_OUT_F32;
       WIS_RET(launch_gemv_dual(st, ga, gb));
       WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
-                                    m->dx, w.c_cq, w.b_cq, defer));
+                                    m->dx, w.c_cq, w.b_cq));
     } else {
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.wscale = w.s_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
@@ -616,12 +610,10 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.x = m->dx; g.csum = w.c_cq; g.Wp = w.p_cq; g.wscale = w.s_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
-    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
-                                  nullptr, nullptr, nullptr, defer));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
     }
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
-    if (defer) { g.part = m->part; g.part_C = used_chunks; g.part_R = R; g.part_H = H; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
@@ -1193,7 +1185,7 @@ int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void
   hipStream_t st = ctx_stream(c);
   float* part = nullptr; unsigned* counters = nullptr;
   int rc = WIS_OK;
-  if (hipMalloc(reinterpret_cast<void**>(&part), (size_t)B * H * 16 * 16 * CA_PART * 4) != hipSuccess ||
+  if (hipMalloc(reinterpret_cast<void**>(&part), (size_t)B * H * 16 * 16 * 66 * 4) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&counters), (size_t)B * H * 4) != hipSuccess) { set_error("wis_op_dec_cross_attn: out of device memory"); rc = WIS_E_NOMEM; }
   if (!rc) {
     hipMemsetAsync(counters, 0, (size_t)B * H * 4, st);
