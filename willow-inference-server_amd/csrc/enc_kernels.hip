@@ -483,178 +483,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
   }
 }
 
-// Split-key variant for small batches: 8 waves per workgroup - waves 0-3 (group 0) take the even 64-key tiles, waves 4-7 (group 1)
-// the odd ones, both over the SAME 128 queries, each with its own online-softmax state, merged once at the end.  With one
-// workgroup per CU (240 workgroups at one utterance) the 4-wave kernel leaves every SIMD with a single wave and nothing to
-// overlap its LDS / MFMA / transcendental latencies with; here every SIMD holds two waves working on different tiles.
-// Dynamic LDS: two (K, V) tile pairs, double buffered = 8 x 9216 B = 72 KiB.
-__global__ __launch_bounds__(512) void enc_attn8_kernel(const f16* __restrict__ qk, const f16* __restrict__ vt,
-                                                        f16* __restrict__ out, int T, int Tpad, int H, int d) {
-  extern __shared__ __attribute__((aligned(16))) char smem8[];
-  f16* sK = reinterpret_cast<f16*>(smem8);                    // [2 buffers][2 tiles][AKT * ASTR]
-  f16* sV = sK + 4 * AKT * ASTR;                              // [2 buffers][2 tiles][64 * ASTR]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wq = wave & 3, l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q_row = blockIdx.x * 128 + wq * 32 + l31;
-  const int q_c = q_row < T ? q_row : T - 1;
-  const int ld = 2 * d;
-  f16x8 qf[4];
-  {
-    const f16* qp = qk + (size_t)(b * T + q_c) * ld + h * 64;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const f16x8*>(qp + kk * 16 + hi * 8);
-  }
-  // tile loaders: per pair of tiles 2 x (64 rows x 8 chunks of 16 B) for K and for V^T; thread -> (row, chunk), both tiles
-  const f16* kbase = qk + (size_t)b * T * ld + d + h * 64;
-  const f16* vbase = vt + (size_t)(b * H + h) * 64 * Tpad;
-  const int lrow = tid >> 3, lch = (tid & 7) * 8, so = lrow * ASTR + lch;
-  const f16* vp = vbase + (size_t)lrow * Tpad + lch;
-  const int ntiles = cdiv(T, AKT), npairs = (ntiles + 1) >> 1;
-  uint4 rk[2], rv[2];
-#define WIS_GLOAD8(pr)                                                                      \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
-    int kt = 2 * (pr) + j; if (kt > ntiles - 1) kt = ntiles - 1;                            \
-    int key = kt * AKT + lrow; if (key > T - 1) key = T - 1;                                \
-    rk[j] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + lch);               \
-    rv[j] = *reinterpret_cast<const uint4*>(vp + kt * AKT);                                \
-  }
-#define WIS_SSTORE8(buf)                                                                    \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
-    *reinterpret_cast<uint4*>(&sK[((buf) * 2 + j) * AKT * ASTR + so]) = rk[j];              \
-    *reinterpret_cast<uint4*>(&sV[((buf) * 2 + j) * 64 * ASTR + so]) = rv[j];               \
-  }
-  f32x16 o[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  constexpr float LOG2E = 1.4426950408889634f;
-
-  WIS_GLOAD8(0) WIS_SSTORE8(0)
-  __syncthreads();
-  for (int pr = 0; pr < npairs; ++pr) {
-    const int cur = pr & 1, kt = 2 * pr + grp;
-    if (pr + 1 < npairs) { WIS_GLOAD8(pr + 1) }
-    if (kt < ntiles) {
-      const f16* tK = sK + (cur * 2 + grp) * AKT * ASTR;
-      const f16* tV = sV + (cur * 2 + grp) * 64 * ASTR;
-      f32x16 st[2];
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const f16x8 kf = *reinterpret_cast<const f16x8*>(&tK[(t2 * 32 + l31) * ASTR + kk * 16 + hi * 8]);
-          st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[t2], 0, 0, 0);
-        }
-      }
-      float mx = -INFINITY;
-      if (kt == ntiles - 1) {
-        const int key_base = kt * AKT + 4 * hi;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key_base + t2 * 32 + (r & 3) + 8 * (r >> 2);
-            if (key >= T) st[t2][r] = -INFINITY;
-          }
-      }
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32)) * LOG2E;
-      const float m_new = fmaxf(m_run, mx);
-      const bool grew = m_new > m_run;
-      float rs = 0.f;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float pv = __builtin_amdgcn_exp2f(fmaf(st[t2][r], LOG2E, -m_new)); st[t2][r] = pv; rs += pv; }
-      if (__any(grew)) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
-      }
-      l_run += rs; m_run = m_new;
-      f16x8 pf[4];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[s2][j] = (f16)st[s2 >> 1][8 * (s2 & 1) + j];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          const f16x8 vf = *reinterpret_cast<const f16x8*>(&tV[(dt * 32 + l31) * ASTR + 16 * s2 + 8 * hi]);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], o[dt], 0, 0, 0);
-        }
-    }
-    if (pr + 1 < npairs) { WIS_SSTORE8(cur ^ 1) }
-    __syncthreads();
-  }
-#undef WIS_GLOAD8
-#undef WIS_SSTORE8
-  // merge the two groups (same queries, disjoint keys): group 1 parks (m, l, o) in LDS (the tile buffers are free now)
-  float* mrg = reinterpret_cast<float*>(smem8);               // [4 waves][34][64 lanes]
-  const int mo = (wq * 34) * 64 + lane;
-  if (grp == 1) {
-    mrg[mo] = m_run; mrg[mo + 64] = l_run;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mrg[mo + (2 + a * 16 + r) * 64] = o[a][r];
-  }
-  __syncthreads();
-  if (grp == 1) return;
-  {
-    const float m1 = mrg[mo], l1 = mrg[mo + 64];
-    const float m = fmaxf(m_run, m1);
-    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
-    l_run = l_run * a0 + l1 * a1;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[a][r] = o[a][r] * a0 + mrg[mo + (2 + a * 16 + r) * 64] * a1;
-  }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  if (q_row < T) {
-    f16* op = out + (size_t)(b * T + q_row) * d + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int dh = dt * 32 + 8 * r4 + 4 * hi;
-        f32x4 v = {o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv, o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv};
-        st4h(op + dh, v);
-      }
-  }
-}
-
 int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H) {
   if (Tpad < cdiv(T, AKT) * AKT || Tpad % 8) { set_error("enc_attention: Tpad=%d too small for T=%d", Tpad, T); return WIS_E_ARG; }
-  // split-key 8-wave workgroups while the grid leaves at most ~2 workgroups per CU (one or two utterances); beyond that the
-  // 4-wave kernel already has several workgroups per CU to overlap (WIS_ENC_ATTN=4|8 overrides)
-  static const int env = getenv("WIS_ENC_ATTN") ? atoi(getenv("WIS_ENC_ATTN")) : 0;
-  const int wgs = cdiv(T, 128) * H * B;
-  const bool use8 = env ? env == 8 : wgs <= 600;
-  if (use8) {
-    constexpr int lds8 = 8 * AKT * ASTR * 2;       // 73728 B
-    static bool ok[64] = {};
-    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (!ok[dev & 63]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds8) != hipSuccess) { set_error("enc_attention: cannot raise the dynamic LDS limit"); return WIS_E_HIP; }
-      ok[dev & 63] = true;
-    }
-    hipLaunchKernelGGL(enc_attn8_kernel, dim3(cdiv(T, 128), H, B), dim3(512), lds8, st, qk, vt, out, T, Tpad, H, H * 64);
-    return WIS_OK;
-  }
   hipLaunchKernelGGL(enc_attn_kernel, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64);
   return WIS_OK;
 }
