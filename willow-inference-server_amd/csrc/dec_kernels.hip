@@ -1120,7 +1120,10 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
 }
 
 // =======================================================================================
-// logits processors + log-softmax statistics + per-chunk top-n_cand.  grid (STAT_CHUNKS, M), block 256
+// logits processors + log-softmax statistics + per-sub-chunk top-n_cand.  grid (STAT_SUB / 4, M), block 256: every WAVE owns one
+// of the STAT_SUB = 64 sub-chunks of a logits row (811 values for the multilingual vocabulary, 13 per lane) and works alone - the
+// maximum, the sum of exponentials and the n_cand selection rounds are DPP wave reductions, no workgroup barrier anywhere
+// (round 1 ran ten block-wide arg-best rounds with a barrier each: 21 us per step).
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
 
 __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restrict__ logits, const float* __restrict__ bias_all,
@@ -1128,13 +1131,12 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
                                                           float* __restrict__ st_max, float* __restrict__ st_sum,
                                                           float* __restrict__ st_val, int* __restrict__ st_idx, SampleCfg cfg,
                                                           int lr_b, int lr_j, int lr_off) {
-  constexpr int PT = 16;   // values per thread: supports n_vocab <= 16*256*16
-  __shared__ float sv[4];
+  constexpr int PT = 16;   // values per lane: supports n_vocab <= 64 * 64 * 16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.x, m = blockIdx.y, b = m / cfg.beam;
+  const int sc = blockIdx.x * 4 + wave, m = blockIdx.y, b = m / cfg.beam;
   const int step = step_u[b];
-  const int CHL = cdiv(cfg.n_vocab, STAT_CHUNKS);
-  const int lo = c * CHL, hi = (lo + CHL < cfg.n_vocab) ? lo + CHL : cfg.n_vocab;
+  const int SL = cdiv(cfg.n_vocab, STAT_SUB);
+  const int lo = sc * SL, hi = (lo + SL < cfg.n_vocab) ? lo + SL : cfg.n_vocab;
   // logits row of (utterance b, beam j): decode steps b*beam + j; the merged prefill+first step samples every beam from the
   // utterance's last prompt row (beams > 0 carry cum = -inf there)
   const float* row = logits + (size_t)(b * lr_b + (m - b * cfg.beam) * lr_j + lr_off) * cfg.n_vocab_pad;
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
   float mx = -INFINITY;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
-    const int nidx = lo + tid + 256 * i;
+    const int nidx = lo + lane + 64 * i;
     float v = -INFINITY;
     if (nidx < hi) {
       // all three streams are requested before the step counter has arrived (one round trip instead of two); the begin-of-
@@ -1161,29 +1163,21 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
     vals[i] = v; mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
-  if (lane == 0) sv[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
   float sum = 0.f;
   if (mx > -INFINITY) {
 #pragma unroll
     for (int i = 0; i < PT; ++i) sum += __expf(vals[i] - mx);   // exp(-inf) = 0 for masked / out of range
   }
   sum = wave_sum(sum);
-  __syncthreads();
-  if (lane == 0) sv[wave] = sum;
-  __syncthreads();
-  if (tid == 0) { st_max[m * STAT_CHUNKS + c] = mx; st_sum[m * STAT_CHUNKS + c] = (sv[0] + sv[1]) + (sv[2] + sv[3]); }
-
-  // top-n_cand of the chunk in (value desc, index asc) order: n_cand rounds of block arg-best (DPP wave reduction,
-  // one barrier per round with a double-buffered 4-entry LDS exchange)
-  __shared__ float xv[2][4]; __shared__ int xi[2][4];
+  if (lane == 0) { st_max[m * STAT_SUB + sc] = mx; st_sum[m * STAT_SUB + sc] = sum; }
+  // top-n_cand of the sub-chunk in (value desc, index asc) order: n_cand rounds of a wave arg-best over the lanes' best
+  // not-yet-picked value
   float pv = INFINITY; int pi = -1;   // previous pick
   for (int rnd = 0; rnd < cfg.n_cand; ++rnd) {
     float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-      const int nidx = lo + tid + 256 * i;
+      const int nidx = lo + lane + 64 * i;
       if (nidx < hi) {
         const float v = vals[i];
         // strictly after the previous pick in the order, and better than the current best
@@ -1191,122 +1185,118 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
       }
     }
     wave_argbest(bv, bi);
-    const int pb = rnd & 1;
-    if (lane == 0) { xv[pb][wave] = bv; xi[pb][wave] = bi; }
-    __syncthreads();
-    float fv = xv[pb][0]; int fi = xi[pb][0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) if (better(xv[pb][w], xi[pb][w], fv, fi)) { fv = xv[pb][w]; fi = xi[pb][w]; }
-    if (tid == 0) {
-      st_val[((size_t)m * STAT_CHUNKS + c) * cfg.n_cand + rnd] = fv;
-      st_idx[((size_t)m * STAT_CHUNKS + c) * cfg.n_cand + rnd] = fi;
+    if (lane == 0) {
+      st_val[((size_t)m * STAT_SUB + sc) * cfg.n_cand + rnd] = bv;
+      st_idx[((size_t)m * STAT_SUB + sc) * cfg.n_cand + rnd] = bi;
     }
-    pv = fv; pi = fi;
+    pv = bv; pi = bi;
   }
 }
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
                        float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg, int lr_b, int lr_j, int lr_off) {
-  if (cdiv(cfg.n_vocab, STAT_CHUNKS) > 16 * 256) { set_error("logit_stats: vocab too large"); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(logit_stats_kernel, dim3(STAT_CHUNKS, B * cfg.beam), dim3(256), 0, st, logits, bias_all, bias_begin, step_u,
+  if (cdiv(cfg.n_vocab, STAT_SUB) > 16 * 64) { set_error("logit_stats: vocab too large"); return WIS_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(logit_stats_kernel, dim3(STAT_SUB / 4, B * cfg.beam), dim3(256), 0, st, logits, bias_all, bias_begin, step_u,
                      st_max, st_sum, st_val, st_idx, cfg, lr_b, lr_j, lr_off);
   return WIS_OK;
 }
 
 // =======================================================================================
-// beam search bookkeeping (CTranslate2 4.1.0 BeamSearch::search semantics).
-// grid B, block 64 (one wave per utterance).
-__global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__ st_max, const float* __restrict__ st_sum,
-                                                       const float* __restrict__ st_val, const int* __restrict__ st_idx,
-                                                       BeamState bs, RowMeta rm, int P, int ctx, SampleCfg cfg, unsigned long long* prof) {
-  constexpr int PSL = (STAT_CHUNKS * MAX_CAND + 63) / 64;    // pool slots per lane and row (4)
-  __shared__ float lse[MAX_R];
+// beam search bookkeeping (CTranslate2 4.1.0 BeamSearch::search semantics).  grid B, block 256 (four waves per
+// utterance).  Everything the step needs from memory - the candidate pool (k rows x 64 sub-chunks x n_cand), the row statistics,
+// the cumulative scores, the step / done / hypothesis counters and the token histories - is requested up front in one round
+// trip; the pool lives in registers (<= 32 entries per thread), the n_cand selection rounds are wave arg-bests joined through a
+// double-buffered 4-entry LDS exchange (one barrier per round).
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ st_max, const float* __restrict__ st_sum,
+                                                        const float* __restrict__ st_val, const int* __restrict__ st_idx,
+                                                        BeamState bs, RowMeta rm, int P, int ctx, SampleCfg cfg, unsigned long long* prof) {
+  constexpr int PSL = (MAX_R * STAT_SUB * MAX_CAND + 255) / 256;    // pool entries per thread at the largest beam (32)
+  constexpr int HPT = (MAX_R * 256 + 255) / 256;                    // history tokens per thread (8)
+  __shared__ float lse[MAX_R], s_cum[MAX_R];
   __shared__ float cand_v[MAX_CAND]; __shared__ int cand_word[MAX_CAND]; __shared__ int cand_org[MAX_CAND];
   __shared__ int nb_src[MAX_R]; __shared__ int nb_tok[MAX_R]; __shared__ float nb_cum[MAX_R];
   __shared__ int hyp_src[MAX_R]; __shared__ int hyp_slot[MAX_R]; __shared__ int hyp_n[MAX_R]; __shared__ int n_newhyp;
   __shared__ int s_finished;
   __shared__ int sh_alive[MAX_R * 256];
-  const int b = blockIdx.x, lane = threadIdx.x;
-  unsigned long long* pf = (b == 0 && lane == 0) ? prof : nullptr;
+  __shared__ float xv[2][4]; __shared__ int xi[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* pf = (b == 0 && tid == 0) ? prof : nullptr;
   stamp(pf, 0);
   const int k = cfg.beam, NC = cfg.n_cand, V = cfg.n_vocab;
-  const int r0 = b * k, per_row = STAT_CHUNKS * NC;
-  // The candidate pool (k rows x STAT_CHUNKS x n_cand entries) lives in REGISTERS, slot [j][u] = entry lane + 64u of row j: all
-  // of it, the row statistics and the cumulative scores are requested in one round trip before anything is waited for (the
-  // LDS-resident pool cost 9 us to build - 13 serialised round trips - and 17 us to scan ten times).
-  float pv_[MAX_R][PSL]; int pi_[MAX_R][PSL]; float cum_[MAX_R];
+  const int r0 = b * k, per_row = STAT_SUB * NC, total = k * per_row;
+  // ---- one round trip: pool, statistics, scores, counters, histories
+  float pv_[PSL]; int pi_[PSL];
 #pragma unroll
-  for (int j = 0; j < MAX_R; ++j) {
-    cum_[j] = 0.f;
-#pragma unroll
-    for (int u = 0; u < PSL; ++u) { pv_[j][u] = -INFINITY; pi_[j][u] = 0x7fffffff; }
-    if (j < k) {
-      cum_[j] = bs.cum[r0 + j];
-#pragma unroll
-      for (int u = 0; u < PSL; ++u) {
-        const int e = lane + 64 * u;
-        if (e < per_row) { pv_[j][u] = st_val[(size_t)(r0 + j) * per_row + e]; pi_[j][u] = st_idx[(size_t)(r0 + j) * per_row + e]; }
-      }
-    }
+  for (int u = 0; u < PSL; ++u) {
+    pv_[u] = -INFINITY; pi_[u] = 0x7fffffff;
+    const int e = tid + 256 * u;
+    if (e < total) { pv_[u] = st_val[(size_t)r0 * per_row + e]; pi_[u] = st_idx[(size_t)r0 * per_row + e]; }     // rows r0 .. r0+k-1 are contiguous
   }
-  float smx[STAT_CHUNKS], ssm[STAT_CHUNKS];
-  {
-    const int m = r0 + (lane < k ? lane : 0);
+  float smx[2], ssm[2];                      // wave w reduces rows w and w + 4; lane = sub-chunk
 #pragma unroll
-    for (int c = 0; c < STAT_CHUNKS; ++c) { smx[c] = st_max[m * STAT_CHUNKS + c]; ssm[c] = st_sum[m * STAT_CHUNKS + c]; }
+  for (int j2 = 0; j2 < 2; ++j2) {
+    const int j = wave + 4 * j2, mrow = r0 + (j < k ? j : 0);
+    smx[j2] = st_max[mrow * STAT_SUB + lane]; ssm[j2] = st_sum[mrow * STAT_SUB + lane];
+  }
+  const float my_cum = tid < k ? bs.cum[r0 + tid] : 0.f;
+  int hist_tok[HPT];
+#pragma unroll
+  for (int u = 0; u < HPT; ++u) {            // token histories of the k beams, whole rows (nothing here waits for the step counter)
+    const int i = tid + 256 * u, j = i >> 8, t = i & 255;
+    hist_tok[u] = (j < k && t < cfg.max_new) ? bs.alive[(size_t)(r0 + j) * cfg.max_new + t] : 0;
   }
   const int done_b = bs.done[b];
   const int step = bs.step_u[b];
+  const int nh0 = bs.n_hyp[b];
   if (done_b) return;
 
   stamp(pf, 1);
+#pragma unroll
+  for (int u = 0; u < HPT; ++u) { const int i = tid + 256 * u; if (i < MAX_R * 256) sh_alive[i] = hist_tok[u]; }
+  if (tid < k) s_cum[tid] = my_cum;
   // log-softmax normaliser per live row
-  if (lane < k) {
-    float M_ = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < STAT_CHUNKS; ++c) M_ = fmaxf(M_, smx[c]);
-    float S = 0.f;
-#pragma unroll
-    for (int c = 0; c < STAT_CHUNKS; ++c) if (smx[c] > -INFINITY) S += ssm[c] * __expf(smx[c] - M_);
-    lse[lane] = M_ + logf(S);
+  for (int j2 = 0; j2 < 2; ++j2) {
+    const int j = wave + 4 * j2;
+    const float M_ = wave_max(smx[j2]);
+    const float S = wave_sum(smx[j2] > -INFINITY ? ssm[j2] * __expf(smx[j2] - M_) : 0.f);
+    if (lane == 0 && j < k) lse[j] = M_ + logf(S);
   }
   __syncthreads();
   stamp(pf, 2);
-  // score = logit - lse + cum ; flat id = beam * V + token; lane-local best in (score desc, flat id asc) order
+  // score = logit - lse + cum ; flat id = beam * V + token; thread-local best in (score desc, flat id asc) order
   float lbv = -INFINITY; int lbi = 0x7fffffff;
 #pragma unroll
-  for (int j = 0; j < MAX_R; ++j) {
-    if (j < k) {
-#pragma unroll
-      for (int u = 0; u < PSL; ++u) {
-        if (lane + 64 * u < per_row) {
-          const float v = pv_[j][u];
-          pv_[j][u] = (v > -INFINITY) ? (v - lse[j]) + cum_[j] : -INFINITY;
-          int tk = pi_[j][u]; if (tk > V - 1) tk = V - 1;   // exhausted chunks report INT_MAX with -inf
-          pi_[j][u] = (j << 20) | tk;                       // orders like the flat id j * V + tk (V < 2^20), no division to unpack
-          if (better(pv_[j][u], pi_[j][u], lbv, lbi)) { lbv = pv_[j][u]; lbi = pi_[j][u]; }
-        }
-      }
+  for (int u = 0; u < PSL; ++u) {
+    const int e = tid + 256 * u;
+    if (e < total) {
+      const int j = e / per_row;
+      const float v = pv_[u];
+      pv_[u] = (v > -INFINITY) ? (v - lse[j]) + s_cum[j] : -INFINITY;
+      int tk = pi_[u]; if (tk > V - 1) tk = V - 1;      // exhausted sub-chunks report INT_MAX with -inf
+      pi_[u] = (j << 20) | tk;                          // orders like the flat id j * V + tk (V < 2^20), no division to unpack
+      if (better(pv_[u], pi_[u], lbv, lbi)) { lbv = pv_[u]; lbi = pi_[u]; }
     }
   }
   stamp(pf, 3);
-  // top-NC of the pool: NC rounds of a wave arg-best over the lane-local bests; every lane then retires its copies of the
-  // winner (identical (score, id) pairs - the clamped -inf entries of exhausted chunks - are picked once, as before) and
-  // refreshes its local best
+  // top-NC of the pool: NC rounds of (wave arg-best over the thread-local bests, 4-entry exchange); every thread then retires
+  // its copies of the winner (identical (score, id) pairs - the clamped -inf entries of exhausted sub-chunks - are picked once)
+  // and refreshes its local best
   for (int rnd = 0; rnd < NC; ++rnd) {
     float bv = lbv; int bi = lbi;
     wave_argbest(bv, bi);
-    if (lane == 0) { cand_v[rnd] = bv; cand_word[rnd] = bi & 0xFFFFF; cand_org[rnd] = (bi >> 20) & 0x7FF; }
+    const int pb = rnd & 1;
+    if (lane == 0) { xv[pb][wave] = bv; xi[pb][wave] = bi; }
+    __syncthreads();
+    bv = xv[pb][0]; bi = xi[pb][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) if (better(xv[pb][w], xi[pb][w], bv, bi)) { bv = xv[pb][w]; bi = xi[pb][w]; }
+    if (tid == 0) { cand_v[rnd] = bv; cand_word[rnd] = bi & 0xFFFFF; cand_org[rnd] = (bi >> 20) & 0x7FF; }
     lbv = -INFINITY; lbi = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < MAX_R; ++j) {
-      if (j < k) {
-#pragma unroll
-        for (int u = 0; u < PSL; ++u) {
-          if (64 * u < per_row) {
-            if (pi_[j][u] == bi && pv_[j][u] == bv) { pv_[j][u] = -INFINITY; pi_[j][u] = 0x7fffffff; }
-            if (better(pv_[j][u], pi_[j][u], lbv, lbi)) { lbv = pv_[j][u]; lbi = pi_[j][u]; }
-          }
-        }
+    for (int u = 0; u < PSL; ++u) {
+      if (256 * u < total) {
+        if (pi_[u] == bi && pv_[u] == bv) { pv_[u] = -INFINITY; pi_[u] = 0x7fffffff; }
+        if (better(pv_[u], pi_[u], lbv, lbi)) { lbv = pv_[u]; lbi = pi_[u]; }
       }
     }
   }
@@ -1314,9 +1304,9 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
 
   stamp(pf, 4);
   // serial bookkeeping
-  if (lane == 0) {
+  if (tid == 0) {
     const bool is_last = (step + 1 >= cfg.max_new);
-    int nh = bs.n_hyp[b], second = k, newh = 0; bool top_finished = false;
+    int nh = nh0, second = k, newh = 0; bool top_finished = false;
     for (int kk = 0; kk < k; ++kk) {
       int next = kk;
       const bool eos = cand_word[kk] == cfg.eot;
@@ -1342,22 +1332,18 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   __syncthreads();
 
   stamp(pf, 5);
-  // stage this utterance's token histories, then write the permuted rows back (the KV rows follow in kv_reorder_kernel)
-  const int hist = step;                 // tokens already in alive[]
+  const int hist = step;                 // tokens already in alive[] (sh_alive holds the whole rows)
   const int npos = P - 1 + step + 1;     // cache positions valid after this step
-  for (int i = lane; i < k * hist; i += 64) { const int j = i / hist, t = i - j * hist; sh_alive[j * 256 + t] = bs.alive[(size_t)(r0 + j) * cfg.max_new + t]; }
-  __syncthreads();
-  stamp(pf, 6);
   // finished hypotheses of this step
   for (int hh = 0; hh < n_newhyp; ++hh) {
     const int kk = hyp_src[hh], org = cand_org[kk], n = hyp_n[hh];
     int* dst = bs.hyp_tok + ((size_t)b * cfg.max_hyp + hyp_slot[hh]) * cfg.max_new;
-    for (int t = lane; t < n; t += 64) dst[t] = (t < hist) ? sh_alive[org * 256 + t] : cand_word[kk];
+    for (int t = tid; t < n; t += 256) dst[t] = (t < hist) ? sh_alive[org * 256 + t] : cand_word[kk];
   }
   if (s_finished) {
     __syncthreads();
     __threadfence_block();
-    if (lane == 0) {
+    if (tid == 0) {
       // finalize_result: score / len^length_penalty, best first
       const int nh = bs.n_hyp[b];
       int best = 0; float bsc = -INFINITY;
@@ -1376,7 +1362,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
     __syncthreads();
     const int best = cand_org[0], n = bs.hyp_len[b * cfg.max_hyp + best];
     const int* src = bs.hyp_tok + ((size_t)b * cfg.max_hyp + best) * cfg.max_new;
-    for (int t = lane; t < n; t += 64) bs.out_ids[(size_t)b * cfg.max_new + t] = src[t];
+    for (int t = tid; t < n; t += 256) bs.out_ids[(size_t)b * cfg.max_new + t] = src[t];
     return;
   }
   stamp(pf, 7);
@@ -1384,8 +1370,8 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
   for (int j = 0; j < k; ++j) {
     const int org = cand_org[nb_src[j]];
     int* al = bs.alive + (size_t)(r0 + j) * cfg.max_new;
-    for (int t = lane; t < hist; t += 64) al[t] = sh_alive[org * 256 + t];
-    if (lane == 0) {
+    for (int t = tid; t < hist; t += 256) al[t] = sh_alive[org * 256 + t];
+    if (tid == 0) {
       al[hist] = nb_tok[j];
       // KV slot this beam continues from: the merged prefill + first step left the prompt's K/V in the utterance's first slot
       bs.parent[r0 + j] = (step == 0) ? r0 : r0 + org;
@@ -1395,13 +1381,13 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__
       rm.slot[r0 + j] = r0 + j;                    // decode rows own their KV slot (the merged first step ran on prompt rows)
     }
   }
-  if (lane == 0) bs.step_u[b] = step + 1;
+  if (tid == 0) bs.step_u[b] = step + 1;
   stamp(pf, 8);
 }
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof) {
   if (cfg.beam > MAX_R || cfg.n_cand > MAX_CAND || cfg.max_new > 256 || ctx > 512 || cfg.n_vocab > (1 << 20)) { set_error("beam_step: config out of range"); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
   return WIS_OK;
 }
 

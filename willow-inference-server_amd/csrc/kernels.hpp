@@ -101,7 +101,7 @@ struct SampleCfg {
   int n_vocab, n_vocab_pad, eot, beam, n_cand, max_new, fixed_new, suppress_blank, greedy;
   float length_penalty; int max_hyp; int allow_early_exit; int max_candidates;
 };
-constexpr int STAT_CHUNKS = 16;
+constexpr int STAT_SUB = 64;      // sub-chunks per logits row (one wave each): statistics and top-n_cand candidates per sub-chunk
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
                        float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg,
                        int lr_b, int lr_j, int lr_off);   // logits row of (b, j) = b*lr_b + j*lr_j + lr_off

@@ -438,8 +438,8 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.hyp_tok, (size_t)Bm * max_hyp * max_new));
   WIS_RET(dalloc(m, &m->bs.all_done, 4));
   WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
-  WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_CHUNKS)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_CHUNKS));
-  WIS_RET(dalloc(m, &m->st_val, (size_t)MAX_ROWS * STAT_CHUNKS * MAX_CAND)); WIS_RET(dalloc(m, &m->st_idx, (size_t)MAX_ROWS * STAT_CHUNKS * MAX_CAND));
+  WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_SUB)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_SUB));
+  WIS_RET(dalloc(m, &m->st_val, (size_t)MAX_ROWS * STAT_SUB * MAX_CAND)); WIS_RET(dalloc(m, &m->st_idx, (size_t)MAX_ROWS * STAT_SUB * MAX_CAND));
   WIS_RET(dalloc(m, &m->d_in, (size_t)Bm * WIS_N_SAMPLES));
   WIS_RET(dalloc(m, &m->d_nsamp, Bm));
   WIS_RET(dalloc(m, &m->lm_logspec, (size_t)Bm * WIS_N_MELS * WIS_N_FRAMES));
