@@ -74,6 +74,31 @@ __device__ __forceinline__ int wave_min_i(int v) {
   const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
   return min(min(a, b), min(c, d));
 }
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16), c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+// Selection keys: a (value, index) pair ordered "value descending, then index ascending" becomes ONE unsigned 64-bit number
+// ordered ascending = better - the order-preserving image of the float in the high word, the complemented index in the low
+// word.  A selection step is then a 64-bit compare and two selects, with no mask logic on the scalar unit (the (v > w) ||
+// (v == w && i < j) form costs three compares, two SALU mask ops and the VALU <-> SALU hazards between them per element).
+// Key 0 = "no entry" (below every real key, whose high word is at least 0x007fffff = the image of -inf).
+typedef unsigned long long u64;
+__device__ __forceinline__ unsigned ord_f(float x) { const unsigned u = __float_as_uint(x); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ u64 sel_key(float v, int idx) { return ((u64)ord_f(v) << 32) | (unsigned)(~idx); }
+__device__ __forceinline__ float key_value(u64 k) { return ord_inv((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_index(u64 k) { return (int)~(unsigned)k; }
+__device__ __forceinline__ u64 key_max(u64 a, u64 b) { return a > b ? a : b; }
+__device__ __forceinline__ u64 wave_max_key(u64 k) {
+  const unsigned hi = wave_max_u((unsigned)(k >> 32));
+  const unsigned lo = wave_max_u((unsigned)(k >> 32) == hi ? (unsigned)k : 0u);
+  return ((u64)hi << 32) | lo;
+}
 // wave-wide best of (value descending, index ascending): returns the winning pair on every lane
 __device__ __forceinline__ void wave_argbest(float& v, int& idx) {
   const float mx = wave_max(v);

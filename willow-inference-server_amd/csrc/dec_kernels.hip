@@ -1125,15 +1125,21 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
 // maximum, the sum of exponentials and the n_cand selection rounds are DPP wave reductions, no workgroup barrier anywhere
 // (round 1 ran ten block-wide arg-best rounds with a barrier each: 21 us per step).
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+// the same order without short-circuit control flow (hipcc turns `||` / `&&` on lane-varying operands into exec-mask branches;
+// inside unrolled selection loops that is one branch per element)
+__device__ __forceinline__ bool better_b(float av, int ai, float bv, int bi) { return (av > bv) | ((av == bv) & (ai < bi)); }
+__device__ __forceinline__ void take_better(float& v, int& i, float ov, int oi) { const bool t = better_b(ov, oi, v, i); v = t ? ov : v; i = t ? oi : i; }
 
 __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restrict__ logits, const float* __restrict__ bias_all,
                                                           const float* __restrict__ bias_begin, const int* __restrict__ step_u,
                                                           float* __restrict__ st_max, float* __restrict__ st_sum,
                                                           float* __restrict__ st_val, int* __restrict__ st_idx, SampleCfg cfg,
-                                                          int lr_b, int lr_j, int lr_off) {
+                                                          int lr_b, int lr_j, int lr_off, unsigned long long* prof) {
   constexpr int PT = 16;   // values per lane: supports n_vocab <= 64 * 64 * 16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sc = blockIdx.x * 4 + wave, m = blockIdx.y, b = m / cfg.beam;
+  unsigned long long* pf = (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) ? prof : nullptr;
+  stamp(pf, 0);
   const int step = step_u[b];
   const int SL = cdiv(cfg.n_vocab, STAT_SUB);
   const int lo = sc * SL, hi = (lo + SL < cfg.n_vocab) ? lo + SL : cfg.n_vocab;
@@ -1144,24 +1150,27 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
   const bool mask_eot = cfg.fixed_new > 0 && step < cfg.fixed_new;
   const bool force_eot = cfg.fixed_new > 0 && step >= cfg.fixed_new;
 
-  float vals[PT];
+  // straight-line loads: every stream of every value is requested before anything is waited for (clamped addresses, masks applied
+  // by select - a guarded `if (nidx < hi) { load }` per value compiled into sixteen branches with a wait each: 15k cycles)
+  float vals[PT]; u64 keys[PT];
+  float lv[PT], la[PT], lb[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int nidx = lo + lane + 64 * i;
+    const int cidx = nidx < hi ? nidx : hi - 1;
+    lv[i] = row[cidx]; lb[i] = bias_begin[cidx]; la[i] = bias_all ? bias_all[cidx] : 0.f;
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int nidx = lo + lane + 64 * i;
-    float v = -INFINITY;
-    if (nidx < hi) {
-      // all three streams are requested before the step counter has arrived (one round trip instead of two); the begin-of-
-      // sequence bias is applied by select
-      const float bb = bias_begin[nidx];
-      v = row[nidx];
-      if (bias_all) v += bias_all[nidx];
-      if (first) v += bb;
-      if (mask_eot && nidx == cfg.eot) v = -INFINITY;
-      if (force_eot && nidx != cfg.eot) v = -INFINITY;
-    }
-    vals[i] = v; mx = fmaxf(mx, v);
+    float v = lv[i] + la[i];
+    v = first ? v + lb[i] : v;
+    const bool dead = (nidx >= hi) | (mask_eot & (nidx == cfg.eot)) | (force_eot & (nidx != cfg.eot));
+    v = dead ? -INFINITY : v;
+    vals[i] = v; keys[i] = nidx < hi ? sel_key(v, nidx) : 0ull; mx = fmaxf(mx, v);
   }
+  stamp(pf, 1);
   mx = wave_max(mx);
   float sum = 0.f;
   if (mx > -INFINITY) {
@@ -1170,33 +1179,36 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
   }
   sum = wave_sum(sum);
   if (lane == 0) { st_max[m * STAT_SUB + sc] = mx; st_sum[m * STAT_SUB + sc] = sum; }
+  stamp(pf, 2);
   // top-n_cand of the sub-chunk in (value desc, index asc) order: n_cand rounds of a wave arg-best over the lanes' best
   // not-yet-picked value
-  float pv = INFINITY; int pi = -1;   // previous pick
+  // n_cand rounds: lane-local best key strictly below the previous pick (independent tests, a 4-level max tree - a scan that
+  // threads one running best through all 16 values is a 16-deep dependent chain, and a lone wave per SIMD has nothing to hide a
+  // dependent VALU latency behind), then a wave maximum of the keys
+  u64 prev = ~0ull;
   for (int rnd = 0; rnd < cfg.n_cand; ++rnd) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
+    u64 t[PT];
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-      const int nidx = lo + lane + 64 * i;
-      if (nidx < hi) {
-        const float v = vals[i];
-        // strictly after the previous pick in the order, and better than the current best
-        if (better(pv, pi, v, nidx) && better(v, nidx, bv, bi)) { bv = v; bi = nidx; }
-      }
+    for (int i = 0; i < PT; ++i) t[i] = keys[i] < prev ? keys[i] : 0ull;
+#pragma unroll
+    for (int w = PT / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) t[i] = key_max(t[i], t[i + w]);
+    const u64 best = wave_max_key(t[0]);
+    if (lane == 0) {     // an exhausted sub-chunk (every value picked or out of range) reports (-inf, INT_MAX)
+      st_val[((size_t)m * STAT_SUB + sc) * cfg.n_cand + rnd] = best ? key_value(best) : -INFINITY;
+      st_idx[((size_t)m * STAT_SUB + sc) * cfg.n_cand + rnd] = best ? key_index(best) : 0x7fffffff;
     }
-    wave_argbest(bv, bi);
-    if (lane == 0) {
-      st_val[((size_t)m * STAT_SUB + sc) * cfg.n_cand + rnd] = bv;
-      st_idx[((size_t)m * STAT_SUB + sc) * cfg.n_cand + rnd] = bi;
-    }
-    pv = bv; pi = bi;
+    prev = best;
   }
+  stamp(pf, 3);
 }
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
-                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg, int lr_b, int lr_j, int lr_off) {
+                       float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg, int lr_b, int lr_j, int lr_off,
+                       unsigned long long* prof) {
   if (cdiv(cfg.n_vocab, STAT_SUB) > 16 * 64) { set_error("logit_stats: vocab too large"); return WIS_E_UNSUPPORTED; }
   hipLaunchKernelGGL(logit_stats_kernel, dim3(STAT_SUB / 4, B * cfg.beam), dim3(256), 0, st, logits, bias_all, bias_begin, step_u,
-                     st_max, st_sum, st_val, st_idx, cfg, lr_b, lr_j, lr_off);
+                     st_max, st_sum, st_val, st_idx, cfg, lr_b, lr_j, lr_off, prof);
   return WIS_OK;
 }
 
@@ -1206,10 +1218,11 @@ int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_al
 // the cumulative scores, the step / done / hypothesis counters and the token histories - is requested up front in one round
 // trip; the pool lives in registers (<= 32 entries per thread), the n_cand selection rounds are wave arg-bests joined through a
 // double-buffered 4-entry LDS exchange (one barrier per round).
+// PSL = pool entries per thread: 16 covers beam <= 5 (5 x 64 x 10 = 3200 entries), 32 the largest beam (8 x 64 x 16)
+template <int PSL>
 __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ st_max, const float* __restrict__ st_sum,
                                                         const float* __restrict__ st_val, const int* __restrict__ st_idx,
                                                         BeamState bs, RowMeta rm, int P, int ctx, SampleCfg cfg, unsigned long long* prof) {
-  constexpr int PSL = (MAX_R * STAT_SUB * MAX_CAND + 255) / 256;    // pool entries per thread at the largest beam (32)
   constexpr int HPT = (MAX_R * 256 + 255) / 256;                    // history tokens per thread (8)
   __shared__ float lse[MAX_R], s_cum[MAX_R];
   __shared__ float cand_v[MAX_CAND]; __shared__ int cand_word[MAX_CAND]; __shared__ int cand_org[MAX_CAND];
@@ -1217,7 +1230,6 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
   __shared__ int hyp_src[MAX_R]; __shared__ int hyp_slot[MAX_R]; __shared__ int hyp_n[MAX_R]; __shared__ int n_newhyp;
   __shared__ int s_finished;
   __shared__ int sh_alive[MAX_R * 256];
-  __shared__ float xv[2][4]; __shared__ int xi[2][4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long* pf = (b == 0 && tid == 0) ? prof : nullptr;
   stamp(pf, 0);
@@ -1227,9 +1239,9 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
   float pv_[PSL]; int pi_[PSL];
 #pragma unroll
   for (int u = 0; u < PSL; ++u) {
-    pv_[u] = -INFINITY; pi_[u] = 0x7fffffff;
-    const int e = tid + 256 * u;
-    if (e < total) { pv_[u] = st_val[(size_t)r0 * per_row + e]; pi_[u] = st_idx[(size_t)r0 * per_row + e]; }     // rows r0 .. r0+k-1 are contiguous
+    const int e = tid + 256 * u, ce = e < total ? e : total - 1;       // clamped address, masked by select: straight-line loads
+    const float v = st_val[(size_t)r0 * per_row + ce]; const int ix = st_idx[(size_t)r0 * per_row + ce];     // rows r0 .. r0+k-1 are contiguous
+    pv_[u] = e < total ? v : -INFINITY; pi_[u] = e < total ? ix : 0x7fffffff;
   }
   float smx[2], ssm[2];                      // wave w reduces rows w and w + 4; lane = sub-chunk
 #pragma unroll
@@ -1242,7 +1254,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {            // token histories of the k beams, whole rows (nothing here waits for the step counter)
     const int i = tid + 256 * u, j = i >> 8, t = i & 255;
-    hist_tok[u] = (j < k && t < cfg.max_new) ? bs.alive[(size_t)(r0 + j) * cfg.max_new + t] : 0;
+    const int cj = j < k ? j : k - 1, ct = t < cfg.max_new ? t : cfg.max_new - 1;
+    hist_tok[u] = bs.alive[(size_t)(r0 + cj) * cfg.max_new + ct];
   }
   const int done_b = bs.done[b];
   const int step = bs.step_u[b];
@@ -1263,41 +1276,52 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
   }
   __syncthreads();
   stamp(pf, 2);
-  // score = logit - lse + cum ; flat id = beam * V + token; thread-local best in (score desc, flat id asc) order
-  float lbv = -INFINITY; int lbi = 0x7fffffff;
+  // score = logit - lse + cum ; id = (beam << 20) | token (orders like the flat id beam * V + token, V < 2^20); every pool entry
+  // becomes one selection key (common.hpp sel_key: score descending, then id ascending)
+  u64 pk[PSL];
+  u64 lbest = 0ull;
+  const float inv_per_row = 1.0f / (float)per_row;
 #pragma unroll
   for (int u = 0; u < PSL; ++u) {
     const int e = tid + 256 * u;
-    if (e < total) {
-      const int j = e / per_row;
-      const float v = pv_[u];
-      pv_[u] = (v > -INFINITY) ? (v - lse[j]) + s_cum[j] : -INFINITY;
-      int tk = pi_[u]; if (tk > V - 1) tk = V - 1;      // exhausted sub-chunks report INT_MAX with -inf
-      pi_[u] = (j << 20) | tk;                          // orders like the flat id j * V + tk (V < 2^20), no division to unpack
-      if (better(pv_[u], pi_[u], lbv, lbi)) { lbv = pv_[u]; lbi = pi_[u]; }
-    }
+    int j = (int)(((float)e + 0.5f) * inv_per_row);          // e / per_row (e < 8192: exact in fp32), no integer division
+    j = j < k ? j : k - 1;                                   // entries beyond the pool: clamped row, masked below
+    const float v = pv_[u];
+    const float sc_ = (v - lse[j]) + s_cum[j];               // (-inf stays -inf: lse and cum of a live row are finite or -inf, never +inf)
+    int tk = pi_[u]; tk = tk > V - 1 ? V - 1 : tk;           // exhausted sub-chunks report INT_MAX with -inf
+    pk[u] = e < total ? sel_key(v > -INFINITY ? sc_ : -INFINITY, (j << 20) | tk) : 0ull;
+    lbest = key_max(lbest, pk[u]);
   }
   stamp(pf, 3);
-  // top-NC of the pool: NC rounds of (wave arg-best over the thread-local bests, 4-entry exchange); every thread then retires
-  // its copies of the winner (identical (score, id) pairs - the clamped -inf entries of exhausted sub-chunks - are picked once)
-  // and refreshes its local best
+  // top-NC of the pool, hierarchically (a block-wide selection round costs a wave reduction, an LDS exchange and a barrier - 2400
+  // cycles measured; ten of them were half the kernel): every wave selects the top NC of ITS quarter of the pool on its own (wave
+  // maximum of the lane-local bests, retire, 4-level max tree; no barrier), then the 4 NC wave candidates are ranked in one pass -
+  // a candidate's rank is the number of candidates with a larger key (keys are distinct: the id is part of the key).
+  __shared__ u64 wcand[4 * MAX_CAND];
   for (int rnd = 0; rnd < NC; ++rnd) {
-    float bv = lbv; int bi = lbi;
-    wave_argbest(bv, bi);
-    const int pb = rnd & 1;
-    if (lane == 0) { xv[pb][wave] = bv; xi[pb][wave] = bi; }
-    __syncthreads();
-    bv = xv[pb][0]; bi = xi[pb][0];
+    const u64 wb = wave_max_key(lbest);
+    if (lane == 0) wcand[wave * NC + rnd] = wb;
 #pragma unroll
-    for (int w = 1; w < 4; ++w) if (better(xv[pb][w], xi[pb][w], bv, bi)) { bv = xv[pb][w]; bi = xi[pb][w]; }
-    if (tid == 0) { cand_v[rnd] = bv; cand_word[rnd] = bi & 0xFFFFF; cand_org[rnd] = (bi >> 20) & 0x7FF; }
-    lbv = -INFINITY; lbi = 0x7fffffff;
+    for (int u = 0; u < PSL; ++u) pk[u] = pk[u] == wb ? 0ull : pk[u];
+    u64 t[PSL];
 #pragma unroll
-    for (int u = 0; u < PSL; ++u) {
-      if (256 * u < total) {
-        if (pi_[u] == bi && pv_[u] == bv) { pv_[u] = -INFINITY; pi_[u] = 0x7fffffff; }
-        if (better(pv_[u], pi_[u], lbv, lbi)) { lbv = pv_[u]; lbi = pi_[u]; }
-      }
+    for (int u = 0; u < PSL; ++u) t[u] = pk[u];
+#pragma unroll
+    for (int w = PSL / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int u = 0; u < w; ++u) t[u] = key_max(t[u], t[u + w]);
+    lbest = t[0];
+  }
+  if (tid < MAX_CAND) { cand_v[tid] = -INFINITY; cand_word[tid] = V - 1; cand_org[tid] = 0; }     // fewer real entries than candidates: -inf on a valid row / token
+  __syncthreads();
+  if (tid < 4 * NC) {
+    const u64 mine = wcand[tid];
+    int rank = 0;
+#pragma unroll
+    for (int m2 = 0; m2 < 4 * MAX_CAND; ++m2) rank += (m2 < 4 * NC && wcand[m2] > mine) ? 1 : 0;      // broadcast LDS reads, independent compares
+    if (mine != 0ull && rank < NC) {
+      const int bi = key_index(mine);
+      cand_v[rank] = key_value(mine); cand_word[rank] = bi & 0xFFFFF; cand_org[rank] = (bi >> 20) & 0x7FF;
     }
   }
   __syncthreads();
@@ -1387,7 +1411,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof) {
   if (cfg.beam > MAX_R || cfg.n_cand > MAX_CAND || cfg.max_new > 256 || ctx > 512 || cfg.n_vocab > (1 << 20)) { set_error("beam_step: config out of range"); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
+  if (cfg.beam * STAT_SUB * cfg.n_cand <= 16 * 256) hipLaunchKernelGGL(beam_step_kernel<16>, dim3(B), dim3(256), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
+  else hipLaunchKernelGGL(beam_step_kernel<32>, dim3(B), dim3(256), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
   return WIS_OK;
 }
 

@@ -104,7 +104,7 @@ struct SampleCfg {
 constexpr int STAT_SUB = 64;      // sub-chunks per logits row (one wave each): statistics and top-n_cand candidates per sub-chunk
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
                        float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg,
-                       int lr_b, int lr_j, int lr_off);   // logits row of (b, j) = b*lr_b + j*lr_j + lr_off
+                       int lr_b, int lr_j, int lr_off, unsigned long long* prof = nullptr);   // logits row of (b, j) = b*lr_b + j*lr_j + lr_off
 struct BeamState {
   int* step_u;      // [B] generated-token count so far
   int* done;        // [B]

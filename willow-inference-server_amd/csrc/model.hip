@@ -788,7 +788,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) { tok[b * P + i] = prompt[b * P + i]; pos[b * P + i] = i; slot[b * P + i] = b * beam; ls[b * P + i] = b * beam; }
     WIS_RET(upload_rows(m, tok, pos, slot, ls));
     WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
-    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1));
+    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 + 16 : nullptr));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
   }
@@ -796,7 +796,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
 
   auto one_step = [&]() -> int {
     WIS_RET(dec_forward(m, Mrows, beam, B, true, beam, 1));
-    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, beam, 1, 0));
+    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, beam, 1, 0, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 + 16 : nullptr));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
     return WIS_OK;
