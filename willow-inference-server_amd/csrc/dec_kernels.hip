@@ -799,7 +799,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int p0 = 0; p0 < len; p0 += 64) {
+  // (do-while: a `for (p0 = 0; p0 < len; ...)` head makes hipcc wait for the row length - a scalar load, one full round trip -
+  // BEFORE it issues the q / K / V loads above; the first block is unconditional, len >= 1)
+  int p0 = 0;
+  do {
     if (p0 > 0) {   // histories beyond 64 positions: next block (not prefetched)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -842,7 +845,8 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
     }
     l_run = l_run * alpha + wave_sum(lsum) * 0.125f;   // every position is replicated on its 8 chunk lanes
     m_run = m_new;
-  }
+    p0 += 64;
+  } while (p0 < len);
   stamp(pf, 2);
   // reduce acc over the 8 position slots: xor 8 inside the 16-lane row by DPP, the four rows through LDS
 #pragma unroll
@@ -1426,13 +1430,19 @@ int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, c
 __global__ __launch_bounds__(256) void kv_reorder_kernel(f16* __restrict__ kc, f16* __restrict__ vc, size_t lstride, const int* __restrict__ parent,
                                                          const int* __restrict__ step_u, const int* __restrict__ done, int k, int P, int ctx, int d) {
   const int b = blockIdx.z, lk = blockIdx.y, tid = threadIdx.x;
-  if (k < 2 || done[b]) return;
+  if (k < 2) return;
   const int r0 = b * k;
-  int par[MAX_R]; bool ident = true;
+  // the three control words are requested together (a `done` test in front of the `parent` loads in front of the `step` load is
+  // three dependent round trips before the first cache row moves)
+  const int dn = done[b], st = step_u[b];
+  int par[MAX_R];
 #pragma unroll
-  for (int j = 0; j < MAX_R; ++j) { par[j] = r0 + j; if (j < k) { par[j] = parent[r0 + j]; ident = ident && par[j] == r0 + j; } }
-  if (ident) return;
-  const int npos = P - 1 + step_u[b];           // beam_step already counted this step: positions 0 .. npos-1 hold history
+  for (int j = 0; j < MAX_R; ++j) par[j] = parent[r0 + (j < k ? j : 0)];
+  bool ident = true;
+#pragma unroll
+  for (int j = 0; j < MAX_R; ++j) { if (j < k) ident = ident & (par[j] == r0 + j); else par[j] = r0 + j; }
+  if (dn | (int)ident) return;
+  const int npos = P - 1 + st;                  // beam_step already counted this step: positions 0 .. npos-1 hold history
   f16* cache = ((lk & 1) ? vc : kc) + (size_t)(lk >> 1) * lstride;
   const int c8 = d >> 3;
   for (int p = blockIdx.x; p < npos; p += gridDim.x) {
