@@ -372,21 +372,28 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
   const f16* vp0 = vbase + (size_t)lrow0 * Tpad + lch;
   const f16* vp1 = vbase + (size_t)lrow1 * Tpad + lch;
   const int so0 = lrow0 * ASTR + lch, so1 = lrow1 * ASTR + lch;
-  uint4 rk0, rk1, rv0, rv1;
+  // The next tile's K / V pieces are fetched by inline-asm loads that hipcc does not count: with compiler-visible loads its
+  // waitcnt pass put `s_waitcnt vmcnt(3..0)` between the Q.K^T MFMAs at the TOP of the iteration (the ds_read destinations there
+  // alias the address temporaries of the in-flight loads), so every tile waited out the L2 latency of its own prefetch before
+  // computing.  The wait is stated by hand where the data is consumed - in front of the LDS stores at the bottom, behind all 16
+  // MFMAs and the softmax (cdna_hip_programming.md 5.7, form (iii): "=v" loads, "+v" operands on the wait).
+  u32x4 rk0, rk1, rv0, rv1;
 #define WIS_GLOAD(kt)                                                                      \
   {                                                                                        \
     int key0 = (kt) * AKT + lrow0; if (key0 > T - 1) key0 = T - 1;                          \
     int key1 = (kt) * AKT + lrow1; if (key1 > T - 1) key1 = T - 1;                          \
-    rk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)key0 * ld + lch);                \
-    rk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)key1 * ld + lch);                \
-    rv0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * AKT);                               \
-    rv1 = *reinterpret_cast<const uint4*>(vp1 + (kt) * AKT);                               \
+    const f16* a0_ = kbase + (size_t)key0 * ld + lch; const f16* a1_ = kbase + (size_t)key1 * ld + lch;   \
+    const f16* a2_ = vp0 + (kt) * AKT; const f16* a3_ = vp1 + (kt) * AKT;                   \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"  \
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"      \
+                 : "=&v"(rk0), "=&v"(rk1), "=&v"(rv0), "=&v"(rv1) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
   }
 #define WIS_SSTORE(buf)                                                                    \
-  *reinterpret_cast<uint4*>(&sK[buf][so0]) = rk0;                                          \
-  *reinterpret_cast<uint4*>(&sK[buf][so1]) = rk1;                                          \
-  *reinterpret_cast<uint4*>(&sV[buf][so0]) = rv0;                                          \
-  *reinterpret_cast<uint4*>(&sV[buf][so1]) = rv1;
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(rk0), "+v"(rk1), "+v"(rv0), "+v"(rv1) :: "memory"); \
+  *reinterpret_cast<u32x4*>(&sK[buf][so0]) = rk0;                                          \
+  *reinterpret_cast<u32x4*>(&sK[buf][so1]) = rk1;                                          \
+  *reinterpret_cast<u32x4*>(&sV[buf][so0]) = rv0;                                          \
+  *reinterpret_cast<u32x4*>(&sV[buf][so1]) = rv1;
 
   f32x16 o[2];
 #pragma unroll
@@ -397,6 +404,10 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
 
   const int ntiles = cdiv(T, AKT);
   WIS_GLOAD(0) WIS_SSTORE(0)
+  // the Q fragments are complete here, and hipcc must KNOW it: its waitcnt pass otherwise carries "q loads may be outstanding"
+  // into the loop and, the vmcnt counter being in-order, expresses that as vmcnt(3..0) in front of the Q.K^T MFMAs - which in the
+  // loop means "wait for the four prefetch loads just issued".  A builtin wait is visible to the pass.
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) expcnt(7) lgkmcnt(15)
   __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
