@@ -19,6 +19,8 @@
 //  * suppress masks, log-softmax statistics and the top-2*beam candidates are computed in one
 //    pass over the logits (16 chunks per row), the beam bookkeeping runs on device (one wave per
 //    utterance) so the host never sees logits and a whole step replays as one HIP graph.
+#include <atomic>
+#include <mutex>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -250,6 +252,10 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   constexpr int NXH = fastx ? (MB == 1 ? 13 : 30) : 1;
   u32x4 xh[NXH];
   const int c8 = KC >> 3, k8n = K >> 3, nx = M * c8;     // 16-byte pieces per chunk row / per full row / per chunk
+  // piece index -> row without an integer division (hipcc expands `idx / c8` by a run-time divisor into ~30 instructions, thirteen
+  // times per thread, in front of the weight prefetch): (idx + 0.5) * (1 / c8) truncates to the exact quotient for idx < 2^20
+  const float inv_c8 = 1.0f / (float)c8;
+#define WIS_ROW_OF(idx) ((int)(((float)(idx) + 0.5f) * inv_c8))
   if (fastx) {
     const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
     if (p.x2) {                 // columns >= xsplit come from a second row-major matrix (the fused out-proj + cross-Q stage)
@@ -258,14 +264,14 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
 #pragma unroll
       for (int i = 0; i < NXH; ++i) {
         const int idx = tid + 256 * i;
-        if (idx < nx) { const int row = idx / c8, col = idx - row * c8; xh[i] = col < s8 ? x8[(size_t)row * s8 + col] : y8[(size_t)row * r8 + (col - s8)]; }
+        if (idx < nx) { const int row = WIS_ROW_OF(idx), col = idx - row * c8; xh[i] = col < s8 ? x8[(size_t)row * s8 + col] : y8[(size_t)row * r8 + (col - s8)]; }
       }
     } else if (MB == 1 || KC == K) {   // MB == 1: the launcher only selects this mode for a single chunk
 #pragma unroll
       for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) xh[i] = x8[idx]; }
     } else {
 #pragma unroll
-      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = idx / c8; xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
+      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = WIS_ROW_OF(idx); xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
     }
   }
   // weight prefetch for chunk 0 (independent of x)
@@ -315,7 +321,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
 #pragma unroll
     for (int i = 0; i < NXH; ++i) {
       const int idx = tid + 256 * i;
-      if (idx < nx) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
+      if (idx < nx) { const int row = WIS_ROW_OF(idx), k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
     }
   }
 
@@ -337,7 +343,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
     if (fastx && more) {   // next chunk's activations: in flight during this chunk's MFMAs
       const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x) + ((kc0 + KC) >> 3);
 #pragma unroll
-      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = idx / c8; xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
+      for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = WIS_ROW_OF(idx); xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
     }
     if (!fast && !fastx) {
       // stage x[:, kc0:kc0+KC] (f16 activations)
@@ -383,7 +389,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
 #pragma unroll
       for (int i = 0; i < NXH; ++i) {
         const int idx = tid + 256 * i;
-        if (idx < nx) { const int row = idx / c8, k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
+        if (idx < nx) { const int row = WIS_ROW_OF(idx), k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
       }
     }
   }
@@ -457,6 +463,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   }
   stamp(pf, 6);
   if (tid == 0) tl_end(p.prof);
+#undef WIS_ROW_OF
 }
 template <int MB, int MODE, int SC, int RM, bool W8>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
@@ -471,6 +478,20 @@ __global__ __launch_bounds__(256) void gemv_dual_kernel(GemvP pa, GemvP pb, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < nA) gemv_body<1, 2, SCA, 1, false>(pa, pa.K, blockIdx.x, smem);
   else gemv_body<1, 2, SCB, 1, false>(pb, pb.K, (int)blockIdx.x - nA, smem);
+}
+// per-device launch state of the skinny GEMM (several replica worker threads may launch on different GPUs at once): the dynamic-LDS
+// ceiling of each device, queried once, and the lock under which the per-instantiation attribute is raised
+static std::mutex g_gemv_dev_mu;
+static std::atomic<size_t> g_gemv_lds_max[64];
+static size_t gemv_lds_limit(int dev) {
+  size_t v = g_gemv_lds_max[dev & 63].load(std::memory_order_acquire);
+  if (!v) {
+    int a = 0;
+    if (hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || a < 65536) a = 65536;
+    v = (size_t)a;
+    g_gemv_lds_max[dev & 63].store(v, std::memory_order_release);
+  }
+  return v;
 }
 int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
   if (pa.M != pb.M || pa.M < 1 || pa.M > 16 || pa.wscale || pb.wscale || (pa.flags & (GV_LN | GV_QKV)) || (pb.flags & (GV_LN | GV_QKV))) { set_error("gemv_dual: unsupported pair"); return WIS_E_UNSUPPORTED; }
@@ -497,14 +518,9 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int MB = cdiv(p.M, 16);
   // largest K-chunk (multiple of 128 dividing K) whose f16 image of M rows fits the LDS: 64 KiB for <= 16 rows (several
   // workgroups per CU), the whole 160 KiB CU array (minus slack) for the batched-decode row counts
-  static size_t lds_dev_max = 0;      // same for every device of the node (one GPU model per node)
   int cur_dev = 0;
   if (hipGetDevice(&cur_dev) != hipSuccess) cur_dev = 0;
-  if (!lds_dev_max) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, cur_dev) != hipSuccess || v < 65536) v = 65536;
-    lds_dev_max = (size_t)v;
-  }
+  const size_t lds_dev_max = gemv_lds_limit(cur_dev);
   // (two half-size chunks so that two workgroups fit a CU were measured slower for N = 4d: 24.3 vs 19.0 us at 40 rows)
   const size_t lds_cap = MB == 1 ? 65536 : (lds_dev_max > 155648 ? 155648 : lds_dev_max);
   int KC = p.K;
@@ -535,9 +551,13 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   const int sck = KC / 128;
   const int sc = ((KC == p.K || mode == 2) && (sck == 3 || sck == 4 || sck == 6 || sck == 8 || sck == 10)) ? sck : 0;
 #define WIS_GV1(MBv, MODEv, SCv, RMv, W8v) do { \
-    if (lds > 65536) { static bool big_ok[64] = {};          /* the attribute is per device: one process may drive several GPUs */ \
-      if (!big_ok[cur_dev & 63]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
-                       set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } big_ok[cur_dev & 63] = true; } } \
+    if (lds > 65536) {      /* the attribute is per device and per instantiation: set once each, under the per-device state's lock */ \
+      static std::atomic<unsigned long long> big_ok{0};      /* bit = device */ \
+      if (!((big_ok.load(std::memory_order_acquire) >> (cur_dev & 63)) & 1ull)) { \
+        std::lock_guard<std::mutex> lk(g_gemv_dev_mu); \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
+          set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } \
+        big_ok.fetch_or(1ull << (cur_dev & 63), std::memory_order_release); } } \
     hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), grid, block, lds, st, pp, KC); } while (0)
 #define WIS_GV(MBv, MODEv, SCv, RMv) do { if (p.wscale) WIS_GV1(MBv, MODEv, SCv, RMv, true); else WIS_GV1(MBv, MODEv, SCv, RMv, false); } while (0)
 #define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \
