@@ -28,51 +28,62 @@ namespace wis {
 
 // =======================================================================================
 // LayerNorm: fp32 [M][d] -> f16 [M][d]; one 64-lane wave per row, two-pass in registers.
+#define WIS_PIN4(r) asm volatile("" :: "v"((r).x), "v"((r).y), "v"((r).z), "v"((r).w))
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, f16* __restrict__ y, int M, int d) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int n4 = d >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * d);
-  float4 v[8];
+  // loads are unconditional (clamped index, masked value): a guarded `if (idx < n4) v = x4[idx]` per float4 compiles into a branch
+  // and a wait each, which serialises the row's eight memory round trips
+  // (the same goes for gamma / beta: requested with the row, not one round trip per output quad behind the statistics)
+  float4 v[8], g[AFFINE ? 8 : 1], be[AFFINE ? 8 : 1];
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);      // !AFFINE: plain normalisation (the affine part is folded into
+  const float4* b4 = reinterpret_cast<const float4*>(beta);       // the weights of the projection that follows)
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int idx = lane + 64 * i;
-    if (idx < n4) { v[i] = x4[idx]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    const int idx = lane + 64 * i, ic = idx < n4 ? idx : n4 - 1;
+    float4 a = x4[ic];
+    if (AFFINE) { g[i] = g4[ic]; be[i] = b4[ic]; }
+    if (idx >= n4) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = a;
+    s += (a.x + a.y) + (a.z + a.w);
+  }
+  if (AFFINE) {      // pin the gamma / beta requests here: hipcc otherwise sinks them below the statistics (a second round trip)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { WIS_PIN4(g[i]); WIS_PIN4(be[i]); }
   }
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < n4) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
-      q += (a * a + b * b) + (c * c + e * e);
-    }
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    const float t = (a * a + b * b) + (c * c + e * e);
+    q += idx < n4 ? t : 0.f;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-  const float4* g4 = reinterpret_cast<const float4*>(gamma);      // gamma == nullptr: plain normalisation (the affine part is folded
-  const float4* b4 = reinterpret_cast<const float4*>(beta);       // into the weights of the projection that follows)
   f16x4* y4 = reinterpret_cast<f16x4*>(y + (size_t)row * d);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = lane + 64 * i;
-    if (idx < n4) {
-      const float4 g = gamma ? g4[idx] : make_float4(1.f, 1.f, 1.f, 1.f), b = gamma ? b4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-      f16x4 o;
-      o[0] = (f16)((v[i].x - mean) * rstd * g.x + b.x);
-      o[1] = (f16)((v[i].y - mean) * rstd * g.y + b.y);
-      o[2] = (f16)((v[i].z - mean) * rstd * g.z + b.z);
-      o[3] = (f16)((v[i].w - mean) * rstd * g.w + b.w);
-      y4[idx] = o;
-    }
+    const float4 gg = AFFINE ? g[i] : make_float4(1.f, 1.f, 1.f, 1.f), bb = AFFINE ? be[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    f16x4 o;
+    o[0] = (f16)((v[i].x - mean) * rstd * gg.x + bb.x);
+    o[1] = (f16)((v[i].y - mean) * rstd * gg.y + bb.y);
+    o[2] = (f16)((v[i].z - mean) * rstd * gg.z + bb.z);
+    o[3] = (f16)((v[i].w - mean) * rstd * gg.w + bb.w);
+    if (idx < n4) y4[idx] = o;
   }
 }
 
 int launch_layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, f16* y, int M, int d) {
   if (d % 4 || d > 2048) { set_error("layernorm: d=%d unsupported", d); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, y, M, d);
+  if (gamma) hipLaunchKernelGGL((layernorm_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, y, M, d);
+  else hipLaunchKernelGGL((layernorm_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, y, M, d);
   return WIS_OK;
 }
 
@@ -153,11 +164,23 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi e
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
+  // Staging order.  EARLY (64x128 and 256x256 tiles): k-tile k+1 is stored to LDS at the TOP of iteration k - its loads were
+  // requested a whole iteration earlier - and k-tile k+2 is requested right behind the stores, so the request has the whole
+  // iteration to land.  The 128x128 tile (two workgroups per CU) keeps "request at the top, store at the bottom": the two
+  // co-resident workgroups already cover each other's waits and the early order measured slower there.
+  // tools/gemm_lab.hip on MI355X, us per GEMM, late | early order:
+  //   M = 1500   64x128: out-proj 15.5 | 13.6   FFN2 (K = 4d) 51.2 | 42.9     128x128: QKV 28.4 | 30.5   FFN1 31.0 | 33.3
+  //   M = 12000 256x256: QKV 182 | 169   out-proj 56.3 | 51.2   FFN1 242 | 223   FFN2 190 | 171
+  constexpr bool EARLY = BM_ != 128;
   WIS_GLOAD(0) WIS_SSTORE(0)
+  if (EARLY && nk > 1) { WIS_GLOAD(1) }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) { WIS_GLOAD(kt + 1) }
+    if (EARLY) {
+      if (kt + 1 < nk) { WIS_SSTORE(cur ^ 1) }
+      if (kt + 2 < nk) { WIS_GLOAD(kt + 2) }
+    } else if (kt + 1 < nk) { WIS_GLOAD(kt + 1) }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       f16x8 wf[NI], af[MI];
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi e
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
-    if (kt + 1 < nk) { WIS_SSTORE(cur ^ 1) }
+    if (!EARLY && kt + 1 < nk) { WIS_SSTORE(cur ^ 1) }
     __syncthreads();
   }
 #undef WIS_GLOAD
@@ -310,13 +333,81 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
     reinterpret_cast<float4*>(X)[i] = make_float4(a.x + b.x + r.x, a.y + b.y + r.y, a.z + b.z + r.z, a.w + b.w + r.w);
   }
 }
-int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float* scratch, const float* bias, const float* resid, float* X) {
+// The same reduction with the LayerNorm that consumes the new residual rows fused in: one wave per row, the row stays in registers
+// between "x = sum of partials + bias + residual" (written back in fp32) and "y = LN(x) gamma + beta" (f16, the A operand of the
+// next projection) - one launch and one 7.7 MB read of x less per use.  Same summation order as splitk_reduce_kernel and the same
+// two-pass statistics as layernorm_kernel.  Loads are unconditional (clamped column index, masked result): a guarded load per
+// float4 compiles into a branch and a wait each.
+template <int SPLITS>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ part, int64_t zstride, const float* __restrict__ bias,
+                                                               const float* resid, float* X, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, f16* __restrict__ Y, int M, int d) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int n4 = d >> 2;
+  const int64_t z4 = zstride >> 2;
+  const float4* p4 = reinterpret_cast<const float4*>(part) + (size_t)row * n4;
+  const float4* r4 = reinterpret_cast<const float4*>(resid) + (size_t)row * n4;
+  const float4* b4 = reinterpret_cast<const float4*>(bias);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* e4 = reinterpret_cast<const float4*>(beta);
+  float4 v[8], g[8], be[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i, ic = idx < n4 ? idx : n4 - 1;
+    float4 a = p4[ic];
+#pragma unroll
+    for (int z = 1; z < SPLITS; ++z) { const float4 t = p4[z * z4 + ic]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+    const float4 b = b4[ic], r = r4[ic];
+    g[i] = g4[ic]; be[i] = e4[ic];
+    a = make_float4(a.x + b.x + r.x, a.y + b.y + r.y, a.z + b.z + r.z, a.w + b.w + r.w);
+    if (idx >= n4) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = a;
+    s += (a.x + a.y) + (a.z + a.w);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { WIS_PIN4(g[i]); WIS_PIN4(be[i]); }      // as in layernorm_kernel
+  float4* x4 = reinterpret_cast<float4*>(X) + (size_t)row * n4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int idx = lane + 64 * i; if (idx < n4) x4[idx] = v[i]; }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    const float t = (a * a + b * b) + (c * c + e * e);
+    q += idx < n4 ? t : 0.f;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+  f16x4* y4 = reinterpret_cast<f16x4*>(Y + (size_t)row * d);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    f16x4 o;
+    o[0] = (f16)((v[i].x - mean) * rstd * g[i].x + be[i].x);
+    o[1] = (f16)((v[i].y - mean) * rstd * g[i].y + be[i].y);
+    o[2] = (f16)((v[i].z - mean) * rstd * g[i].z + be[i].z);
+    o[3] = (f16)((v[i].w - mean) * rstd * g[i].w + be[i].w);
+    if (idx < n4) y4[idx] = o;
+  }
+}
+// ln_gamma / ln_beta / Y given: the fused reduction + LayerNorm (N <= 2048); otherwise the plain reduction.
+int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float* scratch, const float* bias, const float* resid, float* X,
+                             const float* ln_gamma, const float* ln_beta, f16* Y) {
   GemmP p = p0;
   if (splits < 2 || p.K % (splits * BK) || p.N % 128) { set_error("splitk: K=%d splits=%d unsupported", p.K, splits); return WIS_E_UNSUPPORTED; }
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
   hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
+  if (Y) {
+    if (!ln_gamma || !ln_beta || p.N > 2048 || (splits != 2 && splits != 4)) { set_error("splitk: fused LayerNorm needs gamma, beta, N <= 2048 and 2 or 4 splits"); return WIS_E_ARG; }
+    if (splits == 2) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2>), dim3(cdiv(p.M, 4)), dim3(256), 0, st, scratch, zs, bias, resid, X, ln_gamma, ln_beta, Y, p.M, p.N);
+    else hipLaunchKernelGGL((splitk_reduce_ln_kernel<4>), dim3(cdiv(p.M, 4)), dim3(256), 0, st, scratch, zs, bias, resid, X, ln_gamma, ln_beta, Y, p.M, p.N);
+    return WIS_OK;
+  }
   const int64_t n4 = zs / 4;
   int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, scratch, splits, zs, bias, resid, X, n4, p.N);

@@ -19,7 +19,8 @@ int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const
 // split-K GEMM for deep-K / narrow-N shapes: `splits` K-slices write fp32 partial tiles to `scratch` ([splits][M][N]), then
 // one elementwise pass adds the slices + bias + residual into X (fp32, may alias resid).  Keeps dense 128x128 tiles and still
 // launches >= 1 workgroup per CU.
-int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p, int splits, float* scratch, const float* bias, const float* resid, float* X);
+int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p, int splits, float* scratch, const float* bias, const float* resid, float* X,
+                             const float* ln_gamma = nullptr, const float* ln_beta = nullptr, f16* Y = nullptr);
 int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C, int T);
 int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
 int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);

@@ -166,6 +166,14 @@ namespace {
 // fragments instead of each owning a 4 KB page - every decode kernel touches 3-5 of them on its critical path, and a
 // translation miss there costs more than the kernel's whole weight stream.
 constexpr size_t SLAB_BYTES = (size_t)1 << 30;
+// K-splits of the encoder's FFN2 at M rows (0 = one workgroup per output tile over the whole K): split while the 128x128 tiles
+// are too few for 256 CUs; four ways while that still leaves <= 512 workgroups, else two (the split length stays a multiple of
+// the 64-deep k-tile for every Whisper width)
+static int enc_splitk(int d, int M) {
+  const int tiles = (d / 128) * cdiv(M, 128);
+  if (tiles >= 200) return 0;
+  return (tiles <= 128 && (4 * d) % (4 * 64) == 0) ? 4 : 2;
+}
 template <class T>
 int dalloc(wis_model* m, T** p, size_t n_elems) {
   size_t b = n_elems * sizeof(T); if (b == 0) b = 16;
@@ -392,7 +400,12 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->ao, (size_t)Bm * T * d));
   WIS_RET(dalloc(m, &m->hbuf, (size_t)Bm * T * 4 * d));
   WIS_RET(dalloc(m, &m->mem, (size_t)Bm * T * d));
-  WIS_RET(dalloc(m, &m->skbuf, (size_t)2 * Bm * T * d));
+  {  // fp32 partial tiles of the K-split FFN2 (small row counts only)
+    size_t sk = 0;
+    for (int b = 1; b <= Bm; ++b) { const int sp = enc_splitk(d, b * T); if (sp) sk = (size_t)sp * b * T * d; }
+    m->skbuf = nullptr;
+    if (sk) WIS_RET(dalloc(m, &m->skbuf, sk));
+  }
   WIS_HIP_CHECK(hipMemsetAsync(m->img, 0, ((size_t)Bm * 3002 * 96 + 64) * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->c1, 0, (size_t)Bm * 3002 * d * 2, m->st));
   WIS_HIP_CHECK(hipMemsetAsync(m->vt, 0, (size_t)Bm * H * 64 * m->Tpad * 2, m->st));
@@ -487,20 +500,33 @@ int run_encoder(wis_model* m, int B) {
     GemmP p; p.klen = 0; p.A = m->c1; p.a_bs = (int64_t)3002 * d; p.a_rs = 2 * d; p.a_rpb = T; p.W = m->w_conv2; p.M = M; p.N = d; p.K = 3 * d;
     WIS_RET(launch_gemm_conv2(st, p, m->b_conv2, m->enc_pos, m->x, T));
   }
+  // Few row tiles (one utterance of the larger models): FFN2 (N = d, K = 4d) has too few 128x128 tiles for 256 CUs, so K is split
+  // over workgroups (240-480 of them) and the reduction launch carries the LayerNorm of whatever consumes the rows next - the next
+  // layer's ln1, or ln_post after the last layer.  Measured for large-v2 at M = 1500 with the weights streamed from HBM
+  // (tools/gemm_lab.hip): 64x128 tiles over the whole K 52 us; 2 splits 42.6 + 6.0 (reduce) + 6.2 (LayerNorm) us; 4 splits + fused
+  // reduce-LayerNorm: see profiles/.
+  const int splits = enc_splitk(d, M);
+  const bool split = splits > 0;
+  bool xn_ready = false;
   for (int l = 0; l < c.n_enc_layers; ++l) {
     const EncLayerW& w = m->enc[l];
-    WIS_RET(launch_layernorm(st, m->x, w.ln1_g, w.ln1_b, m->xn, M, d));
+    if (!xn_ready) WIS_RET(launch_layernorm(st, m->x, w.ln1_g, w.ln1_b, m->xn, M, d));
     WIS_RET(launch_gemm_qkv(st, gemm_plain(m->xn, d, w.w_qkv, M, 3 * d, d), w.b_qkv, m->qk, m->vt, d, T, m->Tpad, H));
     WIS_RET(launch_enc_attention(st, m->qk, m->vt, m->ao, B, T, m->Tpad, H));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->ao, d, w.w_out, M, d, d), w.b_out, m->x, m->x, 2 | 4));
     WIS_RET(launch_layernorm(st, m->x, w.ln2_g, w.ln2_b, m->xn, M, d));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->xn, d, w.w_f1, M, 4 * d, d), w.b_f1, nullptr, m->hbuf, 1));
-    if ((d / 128) * cdiv(M, 128) < 200)   // too few 128x128 tiles for 256 CUs: split K in two, keep the dense tile
-      WIS_RET(launch_gemm_splitk_resid(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), 2, m->skbuf, w.b_f2, m->x, m->x));
-    else
+    if (split) {
+      const bool last = l + 1 == c.n_enc_layers;
+      const float* g = last ? m->enc_ln_g : m->enc[l + 1].ln1_g;
+      const float* b = last ? m->enc_ln_b : m->enc[l + 1].ln1_b;
+      WIS_RET(launch_gemm_splitk_resid(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), splits, m->skbuf, w.b_f2, m->x, m->x, g, b, last ? m->mem : m->xn));
+      xn_ready = true;
+    } else {
       WIS_RET(launch_gemm_generic(st, gemm_plain(m->hbuf, 4 * d, w.w_f2, M, d, 4 * d), w.b_f2, m->x, m->x, 2 | 4));
+    }
   }
-  WIS_RET(launch_layernorm(st, m->x, m->enc_ln_g, m->enc_ln_b, m->mem, M, d));
+  if (!split) WIS_RET(launch_layernorm(st, m->x, m->enc_ln_g, m->enc_ln_b, m->mem, M, d));
   return WIS_OK;
 }
 int run_cross_kv(wis_model* m, int B) {
