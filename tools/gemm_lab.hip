@@ -463,7 +463,7 @@ static void run_stamps(LaunchFn fn, P p, hipStream_t st, const char* tag) {
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 1500;
-  const int d = 1280;
+  const int d = argc > 4 ? atoi(argv[4]) : 1280;
   const Shape shapes[4] = {{"qkv ", 3 * d, d}, {"out ", d, d}, {"ffn1", 4 * d, d}, {"ffn2", d, 4 * d}};
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<f16> hA((size_t)M * 4 * d), hW((size_t)4 * d * 4 * d);

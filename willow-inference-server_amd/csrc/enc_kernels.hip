@@ -6,9 +6,9 @@
 // final LN, then per decoder layer the cross-attention K/V projection of the encoder memory.
 //
 // MI355X mapping:
-//  * one MFMA GEMM template (v_mfma_f32_32x32x16_f16, fp32 accumulate, 128x128x32 tiles,
-//    64-wide waves in a 2x2 grid, LDS double-buffered with register prefetch, 80-byte row
-//    pitch = conflict-free ds_read_b128 fragment reads) serves conv1/conv2 (implicit im2col:
+//  * one MFMA GEMM template (v_mfma_f32_32x32x16_f16, fp32 accumulate, 64-deep k-tiles, 64-wide
+//    waves with a 64x64 or 128x64 wave tile, LDS double-buffered with register staging, 144-byte
+//    row pitch = conflict-free ds_read_b128 fragment reads; tile shapes chosen by row count) serves conv1/conv2 (implicit im2col:
 //    the time-major, zero-padded activation makes a k=3 window ONE contiguous 3C-long row, so
 //    a conv is a GEMM whose A rows overlap: row pitch C for stride 1, 2C for stride 2), QKV,
 //    out-proj, FFN and the cross-K/V projection.  The weight tile is the MFMA A operand and the
@@ -97,18 +97,27 @@ constexpr int BK = 64, LSTR = 72;  // 64-deep k-tiles; LDS row pitch 72 f16 = 14
 // order — a speed assumption only) form one contiguous range, then mapped m-fastest, so an XCD works on a few W column
 // panels (<= ~2 MB, L2-resident) against all of A.
 
-// Tile shapes (BM_ x BN_, WM_ x WN_ waves, wave tile (BM_/WM_) x (BN_/WN_)):
-//   128x128, 2x2 waves   the B = 1 encoder shapes with >= 240 tiles (two workgroups co-reside per CU)
-//    64x128, 2x2 waves   N = d GEMMs at B = 1 (out-proj, conv2): 240 instead of 120 workgroups
-//   256x256, 2x4 waves   batched encoders (M = B * 1500): 128 FLOP per operand byte fetched instead of 64
-// Measured on MI355X (tools/gemm_tiles.sh; per-GEMM us at M = 1500 | M = 12000):
-//   QKV (N = 3d)   128x128 30.3 | 189     64x128 43.1     128x192 34.6     128x256 39.8     256x128 32.6 | 200     256x256 48.9 | 162
-//   FFN1 (N = 4d)  128x128 37.9 | 281     64x128 50.1                      128x256 50.3     256x128 39.0 | 298     256x256 61.0 | 258
-// and, for the 128x128 tile at M = 1500, three different operand pipelines - register staging one k-tile ahead (this kernel),
-// a 2-stage LDS-DMA double buffer, and a 4-stage LDS-DMA ring with counted vmcnt waits, a raw s_barrier and inline-asm
-// fragment reads (three stages in flight) - all land on the same 6.4 ms encoder: the loop is not latency-bound; with two
-// workgroups per CU the CUs ingest operands at ~30 GB/s each (~7.6 TB/s aggregate L2 -> CU), which is what 64 FLOP per
-// fetched byte turns into ~490 TFLOP/s.  torch.matmul (hipBLASLt) on the same shapes: 21.7 / 23.9 us (tools/mm_bench.py).
+// Tile shapes (BM_ x BN_, WM_ x WN_ waves, wave tile (BM_/WM_) x (BN_/WN_)); gemm_pick_tile chooses by row count:
+//   128x128, 2x2 waves   default (two workgroups co-reside per CU and cover each other's waits)
+//    64x128, 2x2 waves   N = d GEMMs of one utterance (out-proj, conv2): 240 instead of 120 workgroups
+//   256x256, 2x4 waves   from 150 tiles on (two or more utterances): 128 FLOP per operand byte fetched instead of 64
+//   256x128 ping-pong    gemm_pp_kernel below: 128-256 tiles (one utterance, N = 3d / 4d, the K-slices of FFN2)
+// What bounds the loop (tools/gemm_lab.hip: the variants side by side on the four per-layer shapes, weights rotated through
+// 640 MB so that W streams from HBM as it does in the encoder; shader-clock stamps of one wave):
+//  * one k-tile of the 128x128 workgroup = 415 cycles issuing its 8 loads per thread (the CU's texture path takes a 1 KiB wave
+//    request per ~13-16 cycles) + 810 for 16 MFMAs and their fragment reads (512 of MFMA pipe) + 70 waiting for the loads + 400
+//    for the 8 ds_write_b128 (13 cycles per wave instruction on the CU's one LDS store path) + 135 barrier = 1970: the phases of
+//    a workgroup run one after the other, all four waves being in the same phase;
+//  * per CU that is 16-20 bytes of operand per cycle for EVERY tile shape and staging mechanism tried - register staging in
+//    either order, LDS-DMA (global_load_lds) with 2 or 3 buffers, the ping-pong groups: within 10 % of each other;
+//  * with all staging traffic removed (ablation) the ping-pong loop still takes 1820 cycles per 256x128 k-tile (56 % of the MFMA
+//    pipe; 256x256: 66 %): fragment-read latency after each barrier and the barriers themselves.  The 256x256 tile runs at 3900
+//    cycles per k-tile = 53 %, the figure the guide's plain-HIP 8-phase template reaches on random data; hipBLASLt's 21.7 us on
+//    the QKV shape (tools/mm_bench.py) corresponds to ~80 % per CU on 90 such tiles - assembly-level scheduling.
+// us per GEMM at M = 1500 | 3000 | 12000 (large-v2 widths, early staging order where this kernel uses it):
+//   QKV   128x128 29.8 | 54.5 | 209    256x128 ping-pong 27.6 | 53.2 | 193    256x256 41.3 | 46.3 | 169
+//   FFN1  128x128 32.4 | 67.0 | 267    256x128 ping-pong 30.3 | 61.3 | 261    256x256 43.2 | 54.8 | 222
+//   out   128x128 20.8 | 22.6 | 65.9    64x128 13.9 | 21.8 | 81.4             256x256 36.9 | 38.1 | 50.3
 template <class Epi, int BM_, int BN_, int WM_, int WN_>
 __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi epi) {
   constexpr int T = 64 * WM_ * WN_;            // threads
@@ -218,13 +227,124 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi e
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Ping-pong workgroup for row counts that give 128-256 tiles of 256 x 128 (one utterance of the larger models: QKV 180, FFN1 240,
+// the four K-slices of FFN2 240): 512 threads = two groups of four waves; group g owns rows [128 g, 128 g + 128) of the tile and
+// the groups alternate roles every phase (a phase ends in a workgroup barrier): while one group runs its 16 MFMAs on k-tile k,
+// the other stores its share of k-tile k+1 to LDS and requests k-tile k+2.  Wave w and wave w + 4 share a SIMD, so every SIMD has
+// one wave on the matrix pipe and one on the memory pipes, with ONE workgroup per CU (the 128 x 128 tile gets that overlap only
+// on the CUs that happen to hold two workgroups):
+//   phase 2k   : G0 MFMA(k) reads buf k&1          | G1 stores tile k+1 -> buf (k+1)&1, requests tile k+2
+//   phase 2k+1 : G0 stores tile k+1, requests k+2  | G1 MFMA(k) reads buf k&1
+// Same MFMA order per output element as gemm_f16_kernel: bit-identical results.  tools/gemm_lab.hip, weights streamed from HBM,
+// M = 1500: QKV 29.8 -> 27.6 us, FFN1 32.4 -> 30.3 us against the 128 x 128 tile.
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p, Epi epi) {
+  constexpr int BM_ = 256, BN_ = 128;
+  __shared__ __attribute__((aligned(16))) f16 sA[2][BM_ * LSTR];
+  __shared__ __attribute__((aligned(16))) f16 sW[2][BN_ * LSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, gtid = tid & 255;
+  const int wm = (wave & 3) >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
+  int wg;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN_;
+  // loader: group g loads rows 128 g + lrow + 32 i (i < 4) of A and rows 64 g + lrow + 32 i (i < 2) of W
+  const int lrow = gtid >> 3, lkc = (gtid & 7) * 8;
+  const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
+  auto arow = [&](int i) -> const f16* {
+    int lm = m0 + 128 * grp + lrow + 32 * i; if (lm > p.M - 1) lm = p.M - 1;
+    return p.A + (int64_t)(lm / p.a_rpb) * p.a_bs + (int64_t)(lm % p.a_rpb) * p.a_rs + lkc + kbeg;
+  };
+  const f16* ga0 = arow(0); const f16* ga1 = arow(1); const f16* ga2 = arow(2); const f16* ga3 = arow(3);
+  const f16* gw0 = p.W + (int64_t)(n0 + 64 * grp + lrow) * p.K + lkc + kbeg;
+  const int64_t wrp = (int64_t)32 * p.K;
+  const int soffA = (128 * grp + lrow) * LSTR + lkc, soffW = (64 * grp + lrow) * LSTR + lkc;
+  uint4 ra0, ra1, ra2, ra3, rw0, rw1;
+#define WIS_PLOAD(kt) ra0 = *reinterpret_cast<const uint4*>(ga0 + (kt) * BK); ra1 = *reinterpret_cast<const uint4*>(ga1 + (kt) * BK); \
+  ra2 = *reinterpret_cast<const uint4*>(ga2 + (kt) * BK); ra3 = *reinterpret_cast<const uint4*>(ga3 + (kt) * BK); \
+  rw0 = *reinterpret_cast<const uint4*>(gw0 + (kt) * BK); rw1 = *reinterpret_cast<const uint4*>(gw0 + wrp + (kt) * BK);
+#define WIS_PSTORE(buf) *reinterpret_cast<uint4*>(&sA[buf][soffA]) = ra0; *reinterpret_cast<uint4*>(&sA[buf][soffA + 32 * LSTR]) = ra1; \
+  *reinterpret_cast<uint4*>(&sA[buf][soffA + 64 * LSTR]) = ra2; *reinterpret_cast<uint4*>(&sA[buf][soffA + 96 * LSTR]) = ra3; \
+  *reinterpret_cast<uint4*>(&sW[buf][soffW]) = rw0; *reinterpret_cast<uint4*>(&sW[buf][soffW + 32 * LSTR]) = rw1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int arow0 = 128 * grp + wm * 64;
+#define WIS_PMMA(cur) do { \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) { \
+      f16x8 wf[2], af[2]; \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const f16x8*>(&sW[cur][(wn * 64 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(&sA[cur][(arow0 + i * 32 + l31) * LSTR + kk * 16 + hi * 8]); \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0); \
+    } } while (0)
+  const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
+  WIS_PLOAD(0) WIS_PSTORE(0)
+  if (nk > 1) { WIS_PLOAD(1) }
+  __syncthreads();
+  // both groups execute exactly two barriers per k-tile
+  if (grp == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      WIS_PMMA(cur);
+      __syncthreads();
+      if (kt + 1 < nk) { WIS_PSTORE(cur ^ 1) }
+      if (kt + 2 < nk) { WIS_PLOAD(kt + 2) }
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) { WIS_PSTORE(cur ^ 1) }
+      if (kt + 2 < nk) { WIS_PLOAD(kt + 2) }
+      __syncthreads();
+      WIS_PMMA(cur);
+      __syncthreads();
+    }
+  }
+#undef WIS_PLOAD
+#undef WIS_PSTORE
+#undef WIS_PMMA
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + arow0 + mi * 32 + l31;
+      if (m < p.M) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * r4 + 4 * hi;
+          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
+          epi(m, n, v);
+        }
+      }
+    }
+}
+// 128-256 ping-pong tiles: every tile has a CU of its own and at least half of the CUs have one (medium, M = 1500: QKV at 144
+// tiles 21.8 us against 24.0 for 288 tiles of 128 x 128)
+static bool gemm_pp_fits(const GemmP& p, int splits) {
+  const int t = cdiv(p.M, 256) * (p.N / 128) * splits;
+  return p.N % 128 == 0 && t >= 128 && t <= 256 && p.M >= 256;
+}
+
 // Tile choice (WIS_GEMM_TILE=BMxBN overrides with one of the instantiated shapes, tuning only).
 static void gemm_pick_tile(const GemmP& p, int* bm, int* bn) {
   static int ebm = -1, ebn = -1;
   if (ebm < 0) { ebm = 0; ebn = 0; if (const char* e = getenv("WIS_GEMM_TILE")) sscanf(e, "%dx%d", &ebm, &ebn); }
-  const bool known = (ebm == 64 && ebn == 128) || (ebm == 128 && ebn == 128) || (ebm == 256 && ebn == 256);
+  const bool known = (ebm == 64 && ebn == 128) || (ebm == 128 && ebn == 128) || (ebm == 256 && ebn == 256) || (ebm == 256 && ebn == 128);
   if (known && p.N % ebn == 0 && (ebm != 64 || p.M > 64)) { *bm = ebm; *bn = ebn; return; }
-  if (p.N % 256 == 0 && (p.N / 256) * cdiv(p.M, 256) >= 200) { *bm = 256; *bn = 256; return; }     // batched encoder
+  // batched encoder; from 150 tiles on the dense tile beats more, smaller ones (two utterances, QKV: 180 tiles 46.3 us, 720 tiles
+  // of 128 x 128 54.5 us)
+  if (p.N % 256 == 0 && (p.N / 256) * cdiv(p.M, 256) >= 150) { *bm = 256; *bn = 256; return; }
+  if (gemm_pp_fits(p, 1)) { *bm = 256; *bn = 128; return; }                                           // one utterance, wide N
   const bool small = (p.N / 128) * cdiv(p.M, 128) < 200 && p.M > 64;
   *bm = small ? 64 : 128; *bn = 128;
 }
@@ -235,6 +355,7 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   int bm, bn; gemm_pick_tile(p, &bm, &bn);
   const dim3 grid((p.N / bn) * cdiv(p.M, bm), 1, p.klen > 0 ? p.K / p.klen : 1);
   if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
+  else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   return WIS_OK;
@@ -401,7 +522,8 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
-  hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
+  if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, p, e);
+  else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
   if (Y) {
     if (!ln_gamma || !ln_beta || p.N > 2048 || (splits != 2 && splits != 4)) { set_error("splitk: fused LayerNorm needs gamma, beta, N <= 2048 and 2 or 4 splits"); return WIS_E_ARG; }
     if (splits == 2) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2>), dim3(cdiv(p.M, 4)), dim3(256), 0, st, scratch, zs, bias, resid, X, ln_gamma, ln_beta, Y, p.M, p.N);
