@@ -560,15 +560,27 @@ int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* 
 
 // =======================================================================================
 // Encoder self-attention (non-causal, dh = 64).  grid (ceil(T/128), H, B), block 256.
+// The loop is bound by the softmax arithmetic, not by the matrix pipe: per 64-key tile a wave issues 16 MFMAs (512 cycles) and, on
+// the vector ALU, 32 maxima, 32 fma + v_exp_f32 (a quarter-rate instruction: 16 cycles per wave) and 32 sums and conversions -
+// about 1100 cycles - in one dependent chain Q.K^T -> softmax -> P.V.  A second wave on the SIMD fills one pipe while the first
+// uses the other (eight utterances: 19.5 us per utterance and layer against 33 us for one), so:
+// SPLIT (one or two utterances, <= 2 workgroups per CU otherwise): the keys of a (query tile, head) are divided between TWO
+// workgroups (grid.x doubles: 480 workgroups for one utterance = two per CU, free-running against each other); each ends with its
+// own online-softmax state (m, l, O) and publishes it with write-through stores; the one that draws the second ticket merges the
+// other's state into its registers and writes the rows (dec_cross_attn_kernel's hand-off: relaxed ticket, one acquire, plain
+// loads).  The merge is symmetric in the two states, so the result does not depend on which workgroup arrives last.
 constexpr int AKT = 64, ASTR = 72;  // 64-key tiles, LDS row pitch 72 f16 = 144 B
+constexpr int ENC_PART_FLOATS = 34 * 256;     // per workgroup: m, l, O[32] per thread
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ qk, const f16* __restrict__ vt,
-                                                       f16* __restrict__ out, int T, int Tpad, int H, int d) {
+                                                       f16* __restrict__ out, int T, int Tpad, int H, int d, float* part, unsigned* counters) {
   __shared__ __attribute__((aligned(16))) f16 sK[2][AKT * ASTR];
   __shared__ __attribute__((aligned(16))) f16 sV[2][64 * ASTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  const int qt = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, half = SPLIT ? (int)blockIdx.x & 1 : 0;
+  const int q_row = qt * 128 + wave * 32 + l31;
   const int q_c = q_row < T ? q_row : T - 1;
   const int ld = 2 * d;
 
@@ -615,15 +627,17 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
     for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = cdiv(T, AKT);
-  WIS_GLOAD(0) WIS_SSTORE(0)
+  const int nt_all = cdiv(T, AKT), nt_half = (nt_all + 1) >> 1;
+  const int t_beg = SPLIT ? half * nt_half : 0;
+  const int ntiles = SPLIT ? (t_beg + nt_half < nt_all ? t_beg + nt_half : nt_all) : nt_all;      // one past this workgroup's last tile
+  WIS_GLOAD(t_beg) WIS_SSTORE(0)
   // the Q fragments are complete here, and hipcc must KNOW it: its waitcnt pass otherwise carries "q loads may be outstanding"
   // into the loop and, the vmcnt counter being in-order, expresses that as vmcnt(3..0) in front of the Q.K^T MFMAs - which in the
   // loop means "wait for the four prefetch loads just issued".  A builtin wait is visible to the pass.
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) expcnt(7) lgkmcnt(15)
   __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = t_beg; kt < ntiles; ++kt) {
+    const int cur = (kt - t_beg) & 1;
     if (kt + 1 < ntiles) WIS_GLOAD(kt + 1)
     // S^T[key][q] = K . Q^T  (A = K rows, B = Q rows)
     f32x16 st[2];
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
     // the accumulator rescale is skipped while no lane of the wave saw a new maximum (the common case after a few tiles)
     constexpr float LOG2E = 1.4426950408889634f;
     float mx = -INFINITY;
-    if (kt == ntiles - 1) {
+    if (kt == nt_all - 1) {
       const int key_base = kt * AKT + 4 * hi;
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
@@ -692,6 +706,48 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
   }
 #undef WIS_GLOAD
 #undef WIS_SSTORE
+  if (SPLIT) {
+    // publish (write-through, relaxed agent scope), drain, ticket; the second arriver merges the first one's state into its own
+    __shared__ int s_last;
+    const int nqt = (int)gridDim.x >> 1;
+    const size_t pair = (size_t)(b * H + h) * nqt + qt;
+    float* mine = part + (pair * 2 + half) * ENC_PART_FLOATS + tid;
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine), __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 256), __float_as_uint(l_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(mine + (2 + a * 16 + r) * 256), __float_as_uint(o[a][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(counters + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == 1u;
+      if (last) {
+        __hip_atomic_store(counters + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* other = part + (pair * 2 + (half ^ 1)) * ENC_PART_FLOATS + tid;
+    const float m1 = other[0], l1 = other[256];
+    float o1[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o1[a][r] = other[(2 + a * 16 + r) * 256];
+    const float mm = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+    // (a0 x + a1 y is evaluated as the sum of two products, never as an fma chain: the same bits whichever side is `mine`)
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[a][r] = o[a][r] * a0 + o1[a][r] * a1;
+  }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   if (q_row < T) {
@@ -707,9 +763,16 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
   }
 }
 
-int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H) {
+// part / counters: ENC_PART_FLOATS floats per workgroup and one zeroed counter per (utterance, head, query tile); given and with
+// at most 600 unsplit workgroups (one or two utterances) the key range is split over two workgroups
+size_t enc_attention_part_floats(int B, int T, int H) { return (size_t)B * H * cdiv(T, 128) * 2 * ENC_PART_FLOATS; }
+int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H, float* part, unsigned* counters) {
   if (Tpad < cdiv(T, AKT) * AKT || Tpad % 8) { set_error("enc_attention: Tpad=%d too small for T=%d", Tpad, T); return WIS_E_ARG; }
-  hipLaunchKernelGGL(enc_attn_kernel, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64);
+  static const int env = getenv("WIS_ENC_ATTN_SPLIT") ? atoi(getenv("WIS_ENC_ATTN_SPLIT")) : -1;      // tuning: 0 never, 1 whenever possible
+  const int wgs = cdiv(T, 128) * H * B;
+  const bool split = part && counters && cdiv(T, AKT) >= 4 && (env >= 0 ? env == 1 : wgs <= 600);
+  if (split) hipLaunchKernelGGL((enc_attn_kernel<true>), dim3(2 * cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
+  else hipLaunchKernelGGL((enc_attn_kernel<false>), dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
   return WIS_OK;
 }
 

@@ -25,7 +25,8 @@ int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C,
 int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
 int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);
 int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H, int64_t kx_lstride, int64_t vt_lstride);
-int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H);
+int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H, float* part = nullptr, unsigned* counters = nullptr);
+size_t enc_attention_part_floats(int B, int T, int H);
 
 // ---- decoder ---------------------------------------------------------------------------
 constexpr int MAX_ROWS = 48;      // decoder rows per pass: B*beam (decode) or B*P (merged prefill + first step); wis_hip/ctranslate2.py MAX_DECODER_ROWS

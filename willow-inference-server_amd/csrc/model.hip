@@ -132,7 +132,7 @@ struct wis_model {
   // activations
   int Tpad;
   f16 *img, *c1, *xn, *qk, *vt, *ao, *hbuf, *mem;
-  float* x; float* skbuf;
+  float* x; float* skbuf; float* enc_part = nullptr; unsigned* enc_cnt = nullptr;
   std::vector<f16*> kx, vx;             // per decoder layer cross K / V
   std::vector<f16*> kc, vc;             // per decoder layer self KV cache [slots][ctx][d] (views into kc_all / vc_all)
   f16 *kc_all = nullptr, *vc_all = nullptr; size_t kv_layer_stride = 0;
@@ -400,6 +400,14 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->ao, (size_t)Bm * T * d));
   WIS_RET(dalloc(m, &m->hbuf, (size_t)Bm * T * 4 * d));
   WIS_RET(dalloc(m, &m->mem, (size_t)Bm * T * d));
+  {  // split-key encoder attention (small batches): per-workgroup softmax states and the pair tickets
+    int bs = 600 / (H * cdiv(T, 128)); if (bs > Bm) bs = Bm;
+    if (bs >= 1) {
+      WIS_RET(dalloc(m, &m->enc_part, enc_attention_part_floats(bs, T, H)));
+      WIS_RET(dalloc(m, &m->enc_cnt, (size_t)bs * H * cdiv(T, 128)));
+      WIS_HIP_CHECK(hipMemsetAsync(m->enc_cnt, 0, (size_t)bs * H * cdiv(T, 128) * 4, m->st));
+    }
+  }
   {  // fp32 partial tiles of the K-split FFN2 (small row counts only)
     size_t sk = 0;
     for (int b = 1; b <= Bm; ++b) { const int sp = enc_splitk(d, b * T); if (sp) sk = (size_t)sp * b * T * d; }
@@ -512,7 +520,7 @@ int run_encoder(wis_model* m, int B) {
     const EncLayerW& w = m->enc[l];
     if (!xn_ready) WIS_RET(launch_layernorm(st, m->x, w.ln1_g, w.ln1_b, m->xn, M, d));
     WIS_RET(launch_gemm_qkv(st, gemm_plain(m->xn, d, w.w_qkv, M, 3 * d, d), w.b_qkv, m->qk, m->vt, d, T, m->Tpad, H));
-    WIS_RET(launch_enc_attention(st, m->qk, m->vt, m->ao, B, T, m->Tpad, H));
+    WIS_RET(launch_enc_attention(st, m->qk, m->vt, m->ao, B, T, m->Tpad, H, m->enc_part, m->enc_cnt));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->ao, d, w.w_out, M, d, d), w.b_out, m->x, m->x, 2 | 4));
     WIS_RET(launch_layernorm(st, m->x, w.ln2_g, w.ln2_b, m->xn, M, d));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->xn, d, w.w_f1, M, 4 * d, d), w.b_f1, nullptr, m->hbuf, 1));
@@ -1136,9 +1144,21 @@ int wis_op_layernorm(int device, const float* x, const float* gamma, const float
 int wis_op_enc_attention(int device, const void* qk, const void* vt, void* out, int B, int T, int Tpad, int H) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
   std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
-  WIS_RET(launch_enc_attention(ctx_stream(c), reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H));
-  WIS_HIP_CHECK(hipGetLastError());
-  WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
+  // same rule as the encoder: the split-key form (two workgroups per query tile and head, in-launch merge) at small grids
+  hipStream_t st = ctx_stream(c);
+  float* part = nullptr; unsigned* counters = nullptr;
+  const size_t ncnt = (size_t)B * H * cdiv(T, 128);
+  int rc = WIS_OK;
+  if (hipMalloc(reinterpret_cast<void**>(&part), enc_attention_part_floats(B, T, H) * 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&counters), ncnt * 4) != hipSuccess) { set_error("wis_op_enc_attention: out of device memory"); rc = WIS_E_NOMEM; }
+  if (!rc) {
+    hipMemsetAsync(counters, 0, ncnt * 4, st);
+    rc = launch_enc_attention(st, reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H, part, counters);
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(part); hipFree(counters);
+  if (rc) return rc;
+  if (e != hipSuccess) { set_error("wis_op_enc_attention: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;
 }
 int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y, int M, int N, int K, int flags) {
