@@ -21,8 +21,12 @@ HIP_SOURCES = ["logmel.hip", "enc_kernels.hip", "dec_kernels.hip", "model.hip"]
 C_SOURCES = ["audio_io.c"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join(ROOT, "include", "wis_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx90a+ unified register file) instead of AGPRs.  hipcc's default put
+# the encoder attention's score tiles in AGPRs and moved them with 64 v_accvgpr_write / v_accvgpr_read per key tile and wave
+# (zero-initialisation and hand-over to the softmax arithmetic, ~20 % of the loop's vector-ALU time); in VGPR form the first MFMA
+# of a tile takes the inline constant 0 as its C operand and the softmax reads the result registers directly.  No kernel spills.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
+             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
 C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
 
 
