@@ -410,7 +410,7 @@ int alloc_buffers(wis_model* m) {
   }
   {  // fp32 partial tiles of the K-split FFN2 (small row counts only)
     size_t sk = 0;
-    for (int b = 1; b <= Bm; ++b) { const int sp = enc_splitk(d, b * T); if (sp) sk = (size_t)sp * b * T * d; }
+    for (int b = 1; b <= Bm; ++b) { const size_t need = (size_t)enc_splitk(d, b * T) * b * T * d; if (need > sk) sk = need; }      // not monotonic in b: 4 splits, then 2, then none
     m->skbuf = nullptr;
     if (sk) WIS_RET(dalloc(m, &m->skbuf, sk));
   }
