@@ -67,6 +67,23 @@ def test_encoder_parity(which, request, mels, lib):
     assert e <= 2e-3
 
 
+def test_encoder_parity_eight_utterances(tiny, mels, lib):
+    """The batched encoder takes other code paths than one or two utterances (256x256 GEMM tiles with the early staging order, the
+    unsplit FFN2, attention workgroup form by grid size): eight different feature windows against the oracle."""
+    import ctypes as C
+    from wis_hip import _lib, ctranslate2 as ct2
+    _, ref, w, a = tiny
+    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=8, max_beam=5)      # the module fixture holds 4 utterances
+    B = 8
+    m8 = np.ascontiguousarray(np.stack([np.roll(mels[i % 2], 53 * i, axis=-1) for i in range(B)]))
+    out = np.zeros((B, 1500, a["d_model"]), np.float32)
+    _lib.check(lib.wis_debug_encode(_handle(model), _lib.ptr(m8), _lib.WIS_IN_MEL_HOST, B, out.ctypes.data_as(C.POINTER(C.c_float))))
+    exp = ref.encode(m8).numpy()
+    e = max(_relerr(out[i], exp[i]) for i in range(B))
+    print(f"encoder tiny, 8 utterances: worst rel-L2 {e:.3e}, max abs {np.abs(out - exp).max():.3e}")
+    assert e <= 2e-3
+
+
 @pytest.mark.parametrize("which", ["tiny", "base"])
 def test_teacher_forced_logits(which, request, mels, lib):
     import ctypes as C
