@@ -233,6 +233,28 @@ def test_batch_invariance_and_determinism(tiny, mels):
     assert r1[0].sequences_ids == r1[2].sequences_ids == single[0].sequences_ids    # batch composition does not change an utterance
 
 
+def test_batch_of_eight_matches_single_utterances(tiny, mels):
+    """40 decoder rows (the fragment-image path at three 16-row blocks) and the batched encoder against one-utterance calls: the
+    length-normalised beam scores agree to rounding and the ids are those of the single calls wherever the oracle-free margin
+    allows (seeded weights: a flip needs a near tie; at most one utterance of eight may differ)."""
+    from wis_hip import ctranslate2 as ct2
+    _, ref, w, a = tiny
+    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=8, max_beam=5)
+    m8 = np.ascontiguousarray(np.stack([np.roll(mels[i % 2], 53 * i, axis=-1) for i in range(8)]))
+    r8 = model.generate(ct2.StorageView.from_array(m8), [PROMPT] * 8, beam_size=5, fixed_new_tokens=8)
+    r8b = model.generate(ct2.StorageView.from_array(m8), [PROMPT] * 8, beam_size=5, fixed_new_tokens=8)
+    assert [r.sequences_ids for r in r8] == [r.sequences_ids for r in r8b]
+    differ = 0
+    for i in range(8):
+        one = model.generate(ct2.StorageView.from_array(m8[i:i + 1]), [PROMPT], beam_size=5, fixed_new_tokens=8)[0]
+        same = one.sequences_ids == r8[i].sequences_ids
+        differ += not same
+        if same:
+            assert abs(one.scores[0] - r8[i].scores[0]) <= 2e-3, (i, one.scores, r8[i].scores)
+    print(f"batch of eight vs single calls: {differ} of 8 utterances differ")
+    assert differ <= 1
+
+
 def test_detect_language(tiny, mels):
     from wis_hip import ctranslate2 as ct2, weights as W
     model, ref, w, a = tiny
