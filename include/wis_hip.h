@@ -144,8 +144,11 @@ typedef struct {
 } wis_gen_opts_t;
 
 /* out_ids: [B][max_new] (max_new = resolved max_new_tokens), out_len: [B], out_score: [B]
- * (length-normalised log-prob of the returned hypothesis) or NULL.  Blocking; one call at a
- * time per handle (the shim serialises per replica). */
+ * (length-normalised log-prob of the returned hypothesis) or NULL.  Blocking.  Thread safety
+ * (SURVEY 8b): any number of threads may call into DIFFERENT handles; a handle itself runs one
+ * compute call at a time (single-instance activations / KV caches) - a second thread entering a
+ * busy handle gets WIS_E_STATE at once, nothing is corrupted.  The shim's micro-batcher feeds each
+ * replica from one worker thread and coalesces concurrent requests into device batches. */
 int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
                  const wis_gen_opts_t* opts, int32_t* out_ids, int32_t* out_len, float* out_score);
 
@@ -159,6 +162,11 @@ int wis_debug_encode(wis_model_t* m, const float* input, int input_kind, int B, 
 /* logits [B][T][n_vocab] f32 for decoder inputs dec_in [B][T] (no suppression applied) */
 int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B,
                      const int32_t* dec_in, int T, float* logits);
+/* the same logits computed R (1..16) positions of every utterance per decoder pass: a pass then has B*R rows, i.e. with
+ * B*R > 8 it runs the batched-row route of the decode step (the one 8 utterances x beam 5 take, main.py:685-693 with
+ * concurrent requests) instead of the <= 8-row route; B*R <= 48 */
+int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, int B,
+                          const int32_t* dec_in, int T, int R, float* logits);
 
 /* ---- timing taps: wall/device ms of the stages of the LAST wis_generate on this handle */
 typedef struct {

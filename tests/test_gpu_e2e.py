@@ -413,3 +413,35 @@ def test_replica_pool_from_one_host_upload(mels):
     flips = sum(out[i] != single[i % 2] for i in range(12))
     assert flips <= 2
     pool.close(); lone.close()
+
+
+def test_generate_refuses_concurrent_entry_on_one_handle(base, mels):
+    """the boundary must be safe under threads.  Concurrency comes from replicas and the micro-batcher; a handle
+    itself runs one call at a time - a second thread that enters `wis_generate` on a BUSY handle (bypassing the shim's lock) is
+    refused with WIS_E_STATE at once instead of corrupting the first call's KV caches, and the first call's result is unharmed."""
+    import threading
+    import time
+    from wis_hip import _lib
+    model = base[0]
+    r = model._replicas[0]
+    x = np.ascontiguousarray(mels[:1])
+    want = model._generate_chunk(r, x, [PROMPT], 4, 5, 224, 1.0, 1.0, True, True, 120, 0)[0].sequences_ids
+    refused = 0
+    for attempt in range(6):
+        oks, errs = [], []
+
+        def call():
+            try:
+                oks.append(model._generate_chunk(r, x, [PROMPT], 4, 5, 224, 1.0, 1.0, True, True, 120, 0)[0].sequences_ids)
+            except _lib.WisError as e:
+                errs.append((e.code, str(e)))
+
+        a, b = threading.Thread(target=call), threading.Thread(target=call)
+        a.start(); time.sleep(0.003); b.start()
+        a.join(); b.join()
+        assert len(oks) >= 1 and all(o == want for o in oks), "the call that held the handle was disturbed"
+        assert all(code == -6 and "another call is running" in msg for code, msg in errs), errs
+        refused += len(errs)
+    print(f"concurrent entry refused {refused} times in 6 attempts")
+    assert refused >= 1
+    assert model._generate_chunk(r, x, [PROMPT], 4, 5, 224, 1.0, 1.0, True, True, 120, 0)[0].sequences_ids == want

@@ -94,10 +94,11 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
     import torch
     from oracle.whisper_ref import WhisperRef
     from wis_hip import _lib, ctranslate2 as ct2, weights as W
+    from wis_hip.languages import LANGUAGE_CODES
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 8)))
     w = W.synthetic_weights(size, seed=1234, std=0.02, emb_std=0.06, ln_jitter=0.1)
     a = W.arch(size)
-    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5)
+    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=8 if size == "large" else 4, max_beam=5)
     ref = WhisperRef(w, a["d_model"], a["n_layers"], a["n_heads"])
     h = model._replicas[0].handle
     mels = np.ascontiguousarray(np.concatenate([_mel(golden_dir, "3sec"), _mel(golden_dir, "10sec")]))
@@ -120,6 +121,32 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
         rel = float(np.linalg.norm(out.astype(np.float64) - exp) / np.linalg.norm(exp.astype(np.float64)))
         print(f"{size}: teacher-forced logits B={B} T={T}: max abs {mx:.3e}, rel-L2 {rel:.3e}, logit std {exp.std():.2f}")
         assert mx <= 5e-2 and rel <= 5e-3
+    # ---- the batched-row route of the decode step (more than 8 rows per pass: activation fragment images, LayerNorm statistics
+    # from residual-epilogue partials - what 8 concurrent utterances x beam 5 run, BASELINE configs[3]) against the oracle at this
+    # size: R teacher-forced positions of every utterance per pass (wis_debug_logits_rows), 16 rows (one row block) and 40 rows
+    # (three row blocks, the config's own row count)
+    mels4, mem4 = np.ascontiguousarray(mels[[0, 1, 1, 0]]), mem[[0, 1, 1, 0]]
+    for B, T, R in ((2, 16, 8), (4, 20, 10)):
+        dec_in = np.ascontiguousarray(np.concatenate([np.tile(np.array(PROMPT, np.int32), (B, 1)), rng.integers(0, 50000, size=(B, T - 4)).astype(np.int32)], axis=1))
+        out = np.zeros((B, T, a["n_vocab"]), np.float32)
+        _lib.check(lib.wis_debug_logits_rows(h, _lib.ptr(mels4[:B]), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T, R,
+                                             out.ctypes.data_as(C.POINTER(C.c_float))))
+        exp = ref.decode_logits(dec_in, mem4[:B]).numpy()
+        mx = np.abs(out - exp).max()
+        rel = float(np.linalg.norm(out.astype(np.float64) - exp) / np.linalg.norm(exp.astype(np.float64)))
+        print(f"{size}: batched-row logits B={B} T={T} rows/pass {B * R}: max abs {mx:.3e}, rel-L2 {rel:.3e}")
+        assert mx <= 5e-2 and rel <= 5e-3
+    # ---- detect_language (a14) on a batch of two windows: softmax over the language tokens of the [sot] step
+    det = model.detect_language(ct2.StorageView.from_array(mels))
+    lg = ref.decode_logits(np.array([[W.SOT], [W.SOT]]), mem)[:, -1]
+    for b in range(2):
+        exp_p = torch.softmax(lg[b][list(W.LANG_IDS)], dim=-1).numpy()
+        got_p = np.zeros(len(W.LANG_IDS))
+        codes = [f"<|{c}|>" for c in LANGUAGE_CODES]
+        for tok, pr in det[b]:
+            got_p[codes.index(tok)] = pr
+        print(f"{size}: detect_language window {b}: max abs prob err {np.abs(got_p - exp_p).max():.3e}, top {det[b][0]}")
+        assert np.abs(got_p - exp_p).max() <= 2e-3 and abs(sum(p for _, p in det[b]) - 1) < 1e-4
     # ---- search (a11-a13) on the configuration's own clip / beam / length
     ci = 0 if clip == "3sec" else 1
     feats = ct2.StorageView.from_array(np.ascontiguousarray(mels[ci:ci + 1]))
@@ -138,6 +165,52 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
             assert got == ids
         else:
             assert abs(gscore - score) <= 1e-2
+    if size == "large":
+        # ---- BASELINE configs[3] shape against the ORACLE (reference call main.py:685-693 under client/jmeter-asr.jmx load): eight
+        # utterances x beam 5 in ONE device batch (40 decoder rows: the fragment-image route end to end - prefill, KV reorder, beam
+        # bookkeeping per utterance) - every utterance must come back with the oracle's answer for ITS clip
+        S8 = 12
+        order = [0, 1, 0, 1, 1, 0, 0, 1]
+        batch = ct2.StorageView.from_array(np.ascontiguousarray(mels[order]))
+        r8 = model.generate(batch, [PROMPT] * 8, beam_size=5, fixed_new_tokens=S8)
+        want = {}
+        for c in (0, 1):
+            ids, score, trace = ref.generate(None, PROMPT, beam_size=5, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN,
+                                             fixed_new=S8, memory=mem[c].numpy(), return_trace=True)
+            want[c] = (ids, score, min(trace))
+        exact = 0
+        for i, r in enumerate(r8):
+            ids, score, margin = want[order[i]]
+            got, gscore = r.sequences_ids[0], r.scores[0]
+            rescored = _oracle_rescore(ref, mem[order[i]].numpy(), got, S8)
+            print(f"large 8 x beam 5, utterance {i} (clip {order[i]}): oracle score {score:.5f} margin {margin:.5f} | hip {gscore:.5f}, "
+                  f"oracle rescoring of the hip ids {rescored:.5f}, identical {got == ids}")
+            assert len(got) == S8 and EOT not in got
+            assert abs(gscore - rescored) <= 3e-3          # the engine's score is the oracle's score of the ids it returned
+            assert rescored >= score - 1e-2                # and no worse than the oracle's best hypothesis
+            if margin > 0.02:
+                assert got == ids
+            exact += got == ids
+        assert exact >= 1
+    if size == "medium":
+        # ---- int8_float16 (reference GPU default, main.py:242) at this size: the oracle on the de-quantised decoder weights, both
+        # row routes of the decode step (<= 8 rows and the batched fragment images)
+        model8 = ct2.Whisper("unused", weights=w, arch=a, max_batch=4, max_beam=5, compute_type="int8_float16")
+        ref8 = WhisperRef(W.quantize_decoder_weights(w), a["d_model"], a["n_layers"], a["n_heads"])
+        h8 = model8._replicas[0].handle
+        B, T = 2, 16
+        dec_in = np.ascontiguousarray(np.concatenate([np.tile(np.array(PROMPT, np.int32), (B, 1)), rng.integers(0, 50000, size=(B, T - 4)).astype(np.int32)], axis=1))
+        exp = ref8.decode_logits(dec_in, mem).numpy()            # (the encoder is not quantised: same memory)
+        for R in (1, 8):
+            out = np.zeros((B, T, a["n_vocab"]), np.float32)
+            _lib.check(lib.wis_debug_logits_rows(h8, _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T, R,
+                                                 out.ctypes.data_as(C.POINTER(C.c_float))))
+            mx = np.abs(out - exp).max()
+            rel = float(np.linalg.norm(out.astype(np.float64) - exp) / np.linalg.norm(exp.astype(np.float64)))
+            print(f"medium int8_float16: logits rows/pass {B * R}: max abs {mx:.3e}, rel-L2 {rel:.3e}")
+            assert mx <= 5e-2 and rel <= 5e-3
+        model8.close()
+    model.close()
 
 
 @pytest.mark.parametrize("size,beam,clip,S", [("medium", 1, "3sec", 16), ("large", 5, "10sec", 40)])

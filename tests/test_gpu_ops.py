@@ -210,3 +210,30 @@ def test_gemv(lib, M, N, K, flags):
         print(f"gemv M{M} N{N} K{K} flags{flags} rep{rep}: rel err {e:.3e} max abs {worst:.3e}")
         assert e < (1e-3 if out_f32 else 2e-3)
         assert worst < 0.05 * (1 + float(np.abs(ref).max()))          # no single corrupted row hiding inside the L2 norm
+
+
+@pytest.mark.parametrize("M", [5, 40])
+def test_gemv_layernorm_rows_with_a_large_common_offset(lib, M):
+    """A projection behind a LayerNorm on rows whose mean is large against their spread (|mean| = 200, std 2.4): the row
+    statistics must not lose the variance to E[x^2] - mean^2 cancellation - at <= 8 rows the kernel shifts by x[r][0], above
+    8 rows (batched decode) the per-16-column partials are (sum, M2 about the tile mean) pairs merged Welford-style.  The rows
+    are exact in f16 (multiples of 1/4 in [128, 256)), so the raw-row cast of the folded form adds no error of its own."""
+    from wis_hip._lib import DevBuf, check
+    rng = np.random.default_rng(11 + M)
+    N, K = 1280, 1280
+    x = (200.0 + rng.integers(-16, 17, size=(M, K)) / 4.0).astype(np.float32)
+    x[:, ::7] += 8.0          # tile means differ from the row mean
+    Wt = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32); b = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    mu = x.astype(np.float64).mean(1, keepdims=True); var = x.astype(np.float64).var(1, keepdims=True)
+    # the folded form: W' = f16(W * gamma) on the raw rows, statistics in the epilogue (dec_kernels.hip fold_ln_kernel)
+    Wg = (Wt.astype(np.float32) * g).astype(np.float16).astype(np.float64)
+    ref = ((x.astype(np.float64) - mu) / np.sqrt(var + 1e-5)) @ Wg.T + Wt.astype(np.float64) @ b.astype(np.float64) + bias
+    dx, dW, dbias, dg, db = DevBuf.from_numpy(x), DevBuf.from_numpy(Wt), DevBuf.from_numpy(bias), DevBuf.from_numpy(g), DevBuf.from_numpy(b)
+    dy = DevBuf(M * N * 4)
+    check(lib.wis_op_gemv(0, dx.ptr, dg.ptr, db.ptr, dW.ptr, dbias.ptr, dy.ptr, M, N, K, 8 | 4))
+    out = dy.to_numpy(np.float32, (M, N))
+    e = _relerr(out, ref)
+    print(f"gemv + LayerNorm, rows at 200 +- 2.4, M{M}: rel err {e:.3e}")
+    assert e < 2e-3

@@ -180,3 +180,26 @@ def test_no_oracle_import_in_product_code():
                 src = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
                 assert "/root/reference" not in src, fn
+
+
+def test_all_special_ids_come_from_the_checkpoint_tokenizer(tmp_path):
+    """reference wis/audio.py:141-146 strips `tokenizer.all_special_ids` (HF: the added tokens flagged special) before the LCS
+    merge - for Whisper that list holds <|endoftext|> .. <|notimestamps|> but NOT the <|0.00|>.. timestamp tokens.  With a
+    tokenizer.json present the list must come from it; without one (synthetic weights) everything >= <|endoftext|> is special."""
+    from tokenizers import AddedToken, Tokenizer, models as tk_models
+    from wis_hip import audio, weights as W
+    from wis_hip.whisper import _Tokenizer
+    tok = Tokenizer(tk_models.WordLevel({f"w{i}": i for i in range(W.EOT)}, unk_token="w0"))
+    specials = ["<|endoftext|>", "<|startoftranscript|>"] + [f"<|l{i}|>" for i in range(99)] + ["<|translate|>", "<|transcribe|>", "<|startoflm|>",
+                "<|startofprev|>", "<|nospeech|>", "<|notimestamps|>"]
+    tok.add_special_tokens([AddedToken(t, special=True) for t in specials])                       # ids 50257 .. 50363
+    tok.add_tokens([AddedToken(f"<|{i * 0.02:.2f}|>", special=False) for i in range(1501)])       # timestamps: added, not special
+    tok.save(str(tmp_path / "tokenizer.json"))
+    t = _Tokenizer(str(tmp_path))
+    assert t.all_special_ids == list(range(W.EOT, W.NO_TIMESTAMPS + 1))
+    assert _Tokenizer(None).all_special_ids == list(range(W.EOT, W.N_VOCAB))
+    # a timestamp id survives the stitch with the checkpoint's list, and is dropped by the id-only fallback
+    ts = W.NO_TIMESTAMPS + 5
+    seqs = [([10, 11, ts, 12, 13], (0, 0, 0)), ([12, 13, 14, W.EOT], (0, 0, 0))]
+    assert list(audio.find_longest_common_sequence(seqs, t)) == [10, 11, ts, 12, 13, 14]
+    assert list(audio.find_longest_common_sequence(seqs, _Tokenizer(None))) == [10, 11, 12, 13, 14]

@@ -74,6 +74,35 @@ def test_microbatcher_two_workers_and_error_propagation():
         mb.submit("k", [1])
 
 
+def test_affinity_routes_device_resident_rows_to_their_replica():
+    """Rows whose features already live on one GPU (streaming sessions: WIS_IN_MEL_DEV) may only be run by THAT replica's
+    worker, and still coalesce with each other; rows without affinity go to whichever worker is free."""
+    from wis_hip.batching import MicroBatcher
+    g0, g1 = object(), object()
+    gate = threading.Event()
+    seen = []
+
+    def run(ctx, key, payloads):
+        gate.wait(2)
+        seen.append((0 if ctx is g0 else 1, key, list(payloads)))
+        return list(payloads)
+
+    mb = MicroBatcher([g0, g1], run, lambda k: 4)
+    res = {}
+    th = [threading.Thread(target=lambda i=i: res.__setitem__(i, mb.submit("dev", [i], affinity=g1))) for i in range(6)]
+    th += [threading.Thread(target=lambda i=i: res.__setitem__(i, mb.submit("host", [i]))) for i in range(6, 9)]
+    for t in th:
+        t.start()
+    time.sleep(0.1)
+    gate.set()
+    for t in th:
+        t.join()
+    assert sorted(res) == list(range(9)) and all(res[i] == [i] for i in range(9))
+    assert all(w == 1 for w, k, _ in seen if k == "dev")                     # never on the other GPU
+    assert max(len(p) for _, k, p in seen if k == "dev") > 1                 # and they did form a batch
+    mb.close()
+
+
 def test_lone_request_is_not_delayed():
     from wis_hip.batching import MicroBatcher
     mb = MicroBatcher(["g"], lambda c, k, p: list(p), lambda k: 8)
@@ -161,6 +190,12 @@ def test_endpoints_reference_error_behaviour():
             assert r.status_code == 400 and r.json() == {"error": "Invalid audio"}
             r = await c.post("/api/willow?model=tiny&voice_auth=true", content=b"", headers={"x-audio-codec": "pcm"})
             assert r.status_code == 400
+            # a beam the engine cannot serve (legal in the reference, main.py:1180) is a 400 with a message, never a 500
+            for q in ("beam_size=10", "beam_size=0", "beam_size=five"):
+                r = await c.post(f"/api/asr?model=tiny&{q}", content=body, headers=hdr)
+                assert r.status_code == 400 and "beam_size" in r.json()["error"], (q, r.status_code, r.text)
+                r = await c.post(f"/api/willow?model=tiny&{q}", content=b"\0" * 64, headers={"x-audio-codec": "pcm"})
+                assert r.status_code == 400 and "beam_size" in r.json()["error"]
 
     asyncio.run(go())
 
@@ -218,7 +253,7 @@ def test_streaming_session_schedule_without_gpu():
             self.detect_language = self.force_language = None
             self.fixed_new_tokens = 0
             self._whisper = None
-            self._pcm = np.zeros(0, np.float32)
+            self._chunks, self._n = [], 0
             import threading
             from concurrent.futures import ThreadPoolExecutor
             self._lock, self._pool = threading.Lock(), ThreadPoolExecutor(max_workers=2)

@@ -4,7 +4,8 @@
 // (reference main.py:579-581): FLAC or RIFF/WAVE bytes -> mono float32 PCM in [-1,1)
 // (int sample / 2^(bps-1), channels averaged), plus the sample rate.  Resampling is NOT
 // done here: the reference's fixtures and the Willow device stream are 16 kHz already;
-// any other rate is reported to the caller (wis_hip.audio refuses it loudly).
+// any other rate is reported to the caller, which resamples to 16 kHz on the host
+// (wis_hip.audio.resample: polyphase Kaiser-windowed sinc).
 //
 // Host-only plain C; no dependency.  The FLAC side implements the full subframe set
 // (CONSTANT / VERBATIM / FIXED 0-4 / LPC 1-32, Rice methods 0 and 1 with escape

@@ -628,14 +628,26 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   const bool ln = p.flags & GV_LN;
   float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
   int ep_slot = 0, ep_pos = 0;
+  // LayerNorm statistics from the row's per-16-column partials (sum, M2 about the tile's own mean - see the residual epilogue
+  // below): pairs merge like Welford / Chan states, so a row whose mean is large against its spread loses nothing to the
+  // E[x^2] - mu^2 cancellation (the <= 8-row kernel shifts by x[r][0] for the same reason).  K = 1280 keeps the lane's 20 pairs
+  // in registers between the two passes; other widths re-read them (L1 hits).
+  constexpr int NQR = PF == 10 ? 20 : 1;
+  float2 spr[NQR];
   float s1 = 0.f, s2 = 0.f;
+  const int nq = K >> 6;                                      // (K/16) partial pairs per row, a quarter per lane
+  const float2* sp = nullptr;
   if (ep_act) {
     const int mm = ep_m < M ? ep_m : M - 1;
     if (ln) {       // this lane sums a quarter of the row's partials (rows >= M: a clamped duplicate, discarded)
-      const int nq = K >> 6;                                  // (K/16) partial pairs per row, a quarter per lane
-      const float2* sp = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4) + (size_t)kq * nq;
+      sp = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4) + (size_t)kq * nq;
+      if (PF == 10) {
+#pragma unroll
+        for (int i = 0; i < NQR; ++i) { spr[i] = sp[i]; s1 += spr[i].x; }
+      } else {
 #pragma unroll 4
-      for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; s1 += v.x; s2 += v.y; }
+        for (int i = 0; i < nq; ++i) s1 += sp[i].x;
+      }
     }
     if (ep_ok) {
       if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
@@ -658,11 +670,21 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   }
   if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
   if (ln) {     // the four lanes of a row (kq = 0..3) hold a quarter of its sums each: ((q0 + q1) + (q2 + q3)) on every lane
-    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    s1 += __shfl_xor(s1, 16);
+    s1 += __shfl_xor(s1, 32);
     const float invK = 1.0f / (float)K;
     const float mu = s1 * invK;
-    const float rs = 1.0f / sqrtf(fmaxf(s2 * invK - mu * mu, 0.f) + 1e-5f);
+    // second pass over the partials: M2 = sum_tiles ( M2_tile + 16 (mean_tile - mu)^2 )
+    if (PF == 10) {
+#pragma unroll
+      for (int i = 0; i < NQR; ++i) { const float dm = spr[i].x * 0.0625f - mu; s2 += spr[i].y + 16.0f * dm * dm; }
+    } else {
+#pragma unroll 4
+      for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; const float dm = v.x * 0.0625f - mu; s2 += v.y + 16.0f * dm * dm; }
+    }
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    const float rs = 1.0f / sqrtf(s2 * invK + 1e-5f);
     s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
   }
   s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
@@ -688,11 +710,14 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
     if (ep_ok) {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = r;
       if (p.y_xf) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y_xf + xf_index(m, n, p.ymb)) = h; }
-      t1 = (r.x + r.y) + (r.z + r.w); t2 = (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+      t1 = (r.x + r.y) + (r.z + r.w);
     }
-    if (p.stat_out) {      // partial sums of this workgroup's 16 columns of row m (all four kq lanes take part in the shuffles)
-      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+    if (p.stat_out) {      // partials of this workgroup's 16 columns of row m: (sum, M2 about the tile mean); all four kq lanes take part in the shuffles
+      t1 += __shfl_xor(t1, 16);
+      t1 += __shfl_xor(t1, 32);
+      if (ep_ok) { const float ml = t1 * 0.0625f, a = r.x - ml, b = r.y - ml, c = r.z - ml, e = r.w - ml; t2 = (a * a + b * b) + (c * c + e * e); }
+      t2 += __shfl_xor(t2, 16);
+      t2 += __shfl_xor(t2, 32);
       if (kq == 0 && ep_m < M && 16 * nt < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt) * 2) = make_float2(t1, t2);
     }
     return;
@@ -726,10 +751,14 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
 // columns; the partials of a 16-column tile are the sums over 4 adjacent threads, in the same (a+b)+(c+d) order everywhere.
 __device__ __forceinline__ void xf_emit4(float4 v, int m, int col, f16* xf, float* stat, int K, int MB) {
   if (xf) { const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w}; *reinterpret_cast<f16x4*>(xf + xf_index(m, col, MB)) = h; }
-  if (stat) {
-    float t1 = (v.x + v.y) + (v.z + v.w), t2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-    t1 += dpp_f<0xB1>(t1); t2 += dpp_f<0xB1>(t2);       // quad: lanes 4j .. 4j+3 = the four column quads of one 16-column tile
-    t1 += dpp_f<0x4E>(t1); t2 += dpp_f<0x4E>(t2);
+  if (stat) {      // (sum, M2 about the tile mean) of the 16-column tile: the pair format gemv_frag_kernel merges
+    float t1 = (v.x + v.y) + (v.z + v.w);
+    t1 += dpp_f<0xB1>(t1);       // quad: lanes 4j .. 4j+3 = the four column quads of one 16-column tile
+    t1 += dpp_f<0x4E>(t1);
+    const float ml = t1 * 0.0625f, a = v.x - ml, b = v.y - ml, c = v.z - ml, e = v.w - ml;
+    float t2 = (a * a + b * b) + (c * c + e * e);
+    t2 += dpp_f<0xB1>(t2);
+    t2 += dpp_f<0x4E>(t2);
     if ((threadIdx.x & 3) == 0) *reinterpret_cast<float2*>(stat + ((size_t)m * (K >> 4) + (col >> 4)) * 2) = make_float2(t1, t2);
   }
 }
@@ -984,9 +1013,17 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       const int r = wave + 4 * j;
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < NXS; ++i) { const float4 v = xs4[j][i]; a1 += (v.x + v.y) + (v.z + v.w); a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
-      a1 = wave_sum(a1); a2 = wave_sum(a2);
-      if (lane == 0 && r < R) { const float mu = a1 / (float)d; srow[r][0] = mu; srow[r][1] = 1.0f / sqrtf(fmaxf(a2 / (float)d - mu * mu, 0.f) + 1e-5f); }
+      for (int i = 0; i < NXS; ++i) { const float4 v = xs4[j][i]; a1 += (v.x + v.y) + (v.z + v.w); }
+      a1 = wave_sum(a1);
+      const float mu = a1 / (float)d;       // two passes over the registers: no E[x^2] - mu^2 cancellation for rows with a large mean
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const float4 v = xs4[j][i];
+        const float a = v.x - mu, b = v.y - mu, c = v.z - mu, e = v.w - mu;
+        a2 += (lane + 64 * i < d4) ? (a * a + b * b) + (c * c + e * e) : 0.f;
+      }
+      a2 = wave_sum(a2);
+      if (lane == 0 && r < R) { srow[r][0] = mu; srow[r][1] = 1.0f / sqrtf(a2 / (float)d + 1e-5f); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float mu = srow[rq][0], rs = srow[rq][1];

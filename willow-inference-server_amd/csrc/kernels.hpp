@@ -25,7 +25,10 @@ int launch_gemm_conv1(hipStream_t st, const GemmP& p, const float* bias, f16* C,
 int launch_gemm_conv2(hipStream_t st, const GemmP& p, const float* bias, const float* pos, float* X, int T);
 int launch_gemm_qkv(hipStream_t st, const GemmP& p, const float* bias, f16* qk, f16* vt, int d, int T, int Tpad, int H);
 int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* kx, f16* vt, int d, int T, int Tpad, int H, int64_t kx_lstride, int64_t vt_lstride);
-int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H, float* part = nullptr, unsigned* counters = nullptr);
+// part / counters: split-key scratch sized for `part_cap` (utterance, head, 128-query tile) triples (enc_attention_part_floats); the
+// split-key form is only taken when the launch fits that capacity
+int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H, float* part = nullptr, unsigned* counters = nullptr,
+                         size_t part_cap = 0);
 size_t enc_attention_part_floats(int B, int T, int H);
 
 // ---- decoder ---------------------------------------------------------------------------
@@ -59,7 +62,7 @@ struct GemvP {
   f16* y16;                      // GV_RESID: optional f16 row-major copy of the produced rows
   // ---- batched rows (launch_gemv_frag, M > 8): activations live in HBM in MFMA B-fragment order ("xf", xf_index below)
   int xmb;                       // 16-row blocks of the x fragment image (= ceil(M / 16))
-  const float* stat_in;          // GV_LN: per-row partial sums of the raw fp32 rows, [M][K/16][2] = (sum x, sum x^2) per 16 columns
+  const float* stat_in;          // GV_LN: per-row partials of the raw fp32 rows, [M][K/16][2] = (sum x, sum (x - tile mean)^2) per 16 columns (merged Welford-style)
   float* stat_out;               // GV_RESID: the same partials of the rows this launch produces, [M][N/16][2]
   f16* y_xf;                     // GV_RESID: f16 fragment image of the produced rows (next projection's input); f16 output: the output itself
   int ymb;                       // 16-row blocks of y_xf (0: f16 output stays row-major [M][N])

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <string>
@@ -157,6 +158,8 @@ struct wis_model {
   f16* dxh = nullptr;           // f16 row-major copy of the layer input rows (written by the embedding / FFN2 epilogues)
   unsigned long long* d_prof;   // [L*8][16] stamp rows, one per layer kernel (wis_debug_phase_cycles / wis_debug_timeline)
   bool prof_on; bool prof_all;
+  size_t enc_part_cap = 0;      // (utterance, head, query tile) triples the split-key encoder attention buffers were sized for
+  std::atomic_flag busy = ATOMIC_FLAG_INIT;   // one compute call at a time per handle (BusyGuard)
 };
 
 namespace {
@@ -406,6 +409,7 @@ int alloc_buffers(wis_model* m) {
       WIS_RET(dalloc(m, &m->enc_part, enc_attention_part_floats(bs, T, H)));
       WIS_RET(dalloc(m, &m->enc_cnt, (size_t)bs * H * cdiv(T, 128)));
       WIS_HIP_CHECK(hipMemsetAsync(m->enc_cnt, 0, (size_t)bs * H * cdiv(T, 128) * 4, m->st));
+      m->enc_part_cap = (size_t)bs * H * cdiv(T, 128);
     }
   }
   {  // fp32 partial tiles of the K-split FFN2 (small row counts only)
@@ -520,7 +524,7 @@ int run_encoder(wis_model* m, int B) {
     const EncLayerW& w = m->enc[l];
     if (!xn_ready) WIS_RET(launch_layernorm(st, m->x, w.ln1_g, w.ln1_b, m->xn, M, d));
     WIS_RET(launch_gemm_qkv(st, gemm_plain(m->xn, d, w.w_qkv, M, 3 * d, d), w.b_qkv, m->qk, m->vt, d, T, m->Tpad, H));
-    WIS_RET(launch_enc_attention(st, m->qk, m->vt, m->ao, B, T, m->Tpad, H, m->enc_part, m->enc_cnt));
+    WIS_RET(launch_enc_attention(st, m->qk, m->vt, m->ao, B, T, m->Tpad, H, m->enc_part, m->enc_cnt, m->enc_part_cap));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->ao, d, w.w_out, M, d, d), w.b_out, m->x, m->x, 2 | 4));
     WIS_RET(launch_layernorm(st, m->x, w.ln2_g, w.ln2_b, m->xn, M, d));
     WIS_RET(launch_gemm_generic(st, gemm_plain(m->xn, d, w.w_f1, M, 4 * d, d), w.b_f1, nullptr, m->hbuf, 1));
@@ -690,6 +694,19 @@ int check_batch(wis_model* m, int B, int beam) {
   return WIS_OK;
 }
 
+// A handle runs ONE compute call at a time (its activations, KV caches and stream are single-instance; the Python shim feeds every
+// replica from one worker thread).  A second thread entering the same handle is refused with WIS_E_STATE instead of silently
+// corrupting the first call's state - SURVEY 8(b) asks for thread safety at the boundary: concurrency comes from replicas and the
+// micro-batcher, never from two calls inside one replica.
+struct BusyGuard {
+  wis_model* m; bool ok;
+  explicit BusyGuard(wis_model* mm) : m(mm), ok(!mm->busy.test_and_set(std::memory_order_acquire)) {}
+  ~BusyGuard() { if (ok) m->busy.clear(std::memory_order_release); }
+};
+#define WIS_ENTER(m, what)                                                                                      \
+  BusyGuard _busy(m);                                                                                           \
+  if (!_busy.ok) { set_error(what ": another call is running on this handle (one call at a time per replica)"); return WIS_E_STATE; }
+
 }  // namespace
 
 // =======================================================================================
@@ -769,6 +786,7 @@ size_t wis_model_device_bytes(const wis_model_t* m) { return m ? m->bytes : 0; }
 int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
                  const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score) {
   if (!m || !input || !prompt || !o || !out_ids || !out_len) { set_error("wis_generate: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_generate")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   const wis_config_t& c = m->cfg;
   const int beam = o->beam_size < 1 ? 1 : o->beam_size;
@@ -883,7 +901,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   std::vector<float> sc_h(B);
   WIS_HIP_CHECK(hipMemcpyAsync(sc_h.data(), m->bs.out_score, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   WIS_HIP_CHECK(hipStreamSynchronize(st));
-  // out_ids is laid out [B][256] on device (allocation constant); caller's is [B][max_new]
+  // out_ids is [B][max_new] on device too (beam_step_kernel indexes by the resolved max_new; the ALLOCATION is [max_batch][256])
   for (int b = 0; b < B; ++b) {
     if (out_len[b] > max_new) out_len[b] = max_new;
     for (int t = 0; t < max_new; ++t) out_ids[(size_t)b * max_new + t] = t < out_len[b] ? ids[(size_t)b * max_new + t] : 0;
@@ -917,6 +935,7 @@ static int single_row_setup(wis_model* m, int B, const std::vector<int>& tok, in
 int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int B, float* lang_probs) {
   if (!m || !input || !lang_probs) { set_error("wis_detect_language: bad argument"); return WIS_E_ARG; }
   if (m->cfg.n_lang <= 0) { set_error("model has no lang_ids"); return WIS_E_UNSUPPORTED; }
+  WIS_ENTER(m, "wis_detect_language")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, 1));
   WIS_RET(stage_input(m, input, input_kind, B));
@@ -933,6 +952,7 @@ int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int 
 
 int wis_debug_encode(wis_model_t* m, const float* input, int input_kind, int B, float* enc_out) {
   if (!m || !input || !enc_out) { set_error("wis_debug_encode: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_debug_encode")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, 1));
   WIS_RET(stage_input(m, input, input_kind, B));
@@ -946,6 +966,7 @@ int wis_debug_encode(wis_model_t* m, const float* input, int input_kind, int B, 
 
 int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, const int32_t* dec_in, int T, float* logits) {
   if (!m || !input || !dec_in || !logits || T < 1 || T > m->cfg.n_text_ctx) { set_error("wis_debug_logits: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_debug_logits")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, 1));
   WIS_RET(stage_input(m, input, input_kind, B));
@@ -964,9 +985,38 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, 
   return WIS_OK;
 }
 
+int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, int B, const int32_t* dec_in, int T, int R, float* logits) {
+  if (!m || !input || !dec_in || !logits || T < 1 || T > m->cfg.n_text_ctx || R < 1 || R > 16) { set_error("wis_debug_logits_rows: bad argument (1 <= R <= 16)"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_debug_logits_rows")
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, B, 1));
+  if (B * R > MAX_ROWS) { set_error("wis_debug_logits_rows: B*R = %d exceeds %d decoder rows per pass", B * R, MAX_ROWS); return WIS_E_STATE; }
+  WIS_RET(stage_input(m, input, input_kind, B));
+  WIS_RET(run_encoder(m, B));
+  WIS_RET(run_cross_kv(m, B));
+  const int V = m->cfg.n_vocab;
+  // teacher-forced in blocks of R positions: the rows (b, i) of a pass sit at positions t0 + i of utterance b's KV slot (causal by
+  // position, like the merged prompt pass of wis_generate), so a pass has B * R rows - with B * R > 8 it takes the batched-row
+  // route (dec_forward_frag: fragment images, partial-sum LayerNorm statistics) that wis_debug_logits' one row per utterance never
+  // reaches at small B
+  for (int t0 = 0; t0 < T; t0 += R) {
+    const int rows = std::min(R, T - t0), M = B * rows;
+    std::vector<int> tok(M), pos(M), slot(M), ls(M);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i) { const int r = b * rows + i; tok[r] = dec_in[b * T + t0 + i]; pos[r] = t0 + i; slot[r] = b; ls[r] = b; }
+    for (int r = 0; r < M; ++r) if (tok[r] < 0 || tok[r] >= V) { set_error("wis_debug_logits_rows: token %d out of range", tok[r]); return WIS_E_ARG; }
+    WIS_RET(upload_rows(m, tok, pos, slot, ls));
+    WIS_RET(dec_forward(m, M, rows, B, true, 1, 0));
+    for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i)
+      WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t0 + i) * V, m->logits + (size_t)(b * rows + i) * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
+    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  }
+  return WIS_OK;
+}
+
 int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* out) {
   if (!m || !out) { set_error("wis_debug_phase_cycles: bad argument"); return WIS_E_ARG; }
   if (!WIS_TAPS) { set_error("tuning taps are not compiled in (rebuild with WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1)"); return WIS_E_UNSUPPORTED; }
+  WIS_ENTER(m, "wis_debug_phase_cycles")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, beam));
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx;
@@ -1000,6 +1050,7 @@ int wis_debug_sampling_cycles(wis_model_t* m, uint64_t* out) {
 int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, uint64_t* out, int n_out) {
   if (!m || !out) { set_error("wis_debug_timeline: bad argument"); return WIS_E_ARG; }
   if (!WIS_TAPS) { set_error("tuning taps are not compiled in (rebuild with WIS_EXTRA_HIPFLAGS=-DWIS_TAPS=1)"); return WIS_E_UNSUPPORTED; }
+  WIS_ENTER(m, "wis_debug_timeline")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, beam));
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx, nk = m->cfg.n_dec_layers * 8;
@@ -1040,6 +1091,7 @@ int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, 
 
 int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, int* launches_per_pass, double* bytes_per_pass) {
   if (!m || M < 1 || M > MAX_ROWS || passes < 1 || !total_ms) { set_error("wis_bench_weight_stream: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_bench_weight_stream")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   const int d = m->cfg.d_model; hipStream_t st = m->st;
   int launches = 0; double bytes = 0;
@@ -1153,7 +1205,7 @@ int wis_op_enc_attention(int device, const void* qk, const void* vt, void* out, 
       hipMalloc(reinterpret_cast<void**>(&counters), ncnt * 4) != hipSuccess) { set_error("wis_op_enc_attention: out of device memory"); rc = WIS_E_NOMEM; }
   if (!rc) {
     hipMemsetAsync(counters, 0, ncnt * 4, st);
-    rc = launch_enc_attention(st, reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H, part, counters);
+    rc = launch_enc_attention(st, reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H, part, counters, ncnt);
   }
   hipError_t e = hipStreamSynchronize(st);
   hipFree(part); hipFree(counters);

@@ -134,13 +134,11 @@ class MelFeatures:
         return self._arr if dtype is None else self._arr.astype(dtype)
 
 
-_rr = [0]
-
-
 def log_mel_spectrogram(audio, n_mels: int = N_MELS, device=None):
     """float32 [480000] (or [n, 480000]) -> MelFeatures wrapping float32 [80, 3000] (or [n, 80, 3000]).
-    `device`: the GPU to run on (a replica's device index); None = round-robin over the visible GPUs.  Re-entrant: concurrent
-    calls never share a stream or a buffer (csrc/logmel.hip)."""
+    `device`: the GPU to run on (callers that own a model pass one of ITS replicas' devices, wis_hip.whisper.do_whisper); None =
+    device 0 - the call never touches a GPU it was not pointed at.  Re-entrant: concurrent calls never share a stream or a
+    buffer (csrc/logmel.hip)."""
     assert n_mels == 80, f"Unsupported n_mels: {n_mels}"
     x = np.ascontiguousarray(np.asarray(audio, dtype=np.float32))
     single = x.ndim == 1
@@ -148,10 +146,8 @@ def log_mel_spectrogram(audio, n_mels: int = N_MELS, device=None):
         x = x[None]
     if x.ndim != 2 or x.shape[1] != N_SAMPLES:
         raise ValueError(f"log_mel_spectrogram expects pad_or_trim'ed audio of {N_SAMPLES} samples, got {x.shape}")
-    n_dev = _lib.require_gpu()
-    if device is None:
-        _rr[0] = (_rr[0] + 1) % n_dev          # a benign race: any device is a correct answer
-        device = _rr[0]
+    _lib.require_gpu()
+    device = 0 if device is None else int(device)
     n = x.shape[0]
     out = np.empty((n, N_MELS, N_FRAMES), np.float32)
     ns = (C.c_int64 * n)(*([N_SAMPLES] * n))

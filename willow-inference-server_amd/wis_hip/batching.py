@@ -13,10 +13,10 @@ from collections import deque
 
 
 class _Item:
-    __slots__ = ("key", "payload", "done", "result", "error")
+    __slots__ = ("key", "payload", "done", "result", "error", "affinity")
 
-    def __init__(self, key, payload):
-        self.key, self.payload = key, payload
+    def __init__(self, key, payload, affinity=None):
+        self.key, self.payload, self.affinity = key, payload, affinity
         self.done = threading.Event()
         self.result = self.error = None
 
@@ -35,9 +35,10 @@ class MicroBatcher:
         for t in self._threads:
             t.start()
 
-    def submit(self, key, payloads):
-        """Blocks until every payload has a result; results come back in payload order."""
-        items = [_Item(key, p) for p in payloads]
+    def submit(self, key, payloads, affinity=None):
+        """Blocks until every payload has a result; results come back in payload order.  `affinity`: the worker context (GPU
+        replica) that must run these payloads - e.g. features that already live in that GPU's memory; None = any worker."""
+        items = [_Item(key, p, affinity) for p in payloads]
         with self._cv:
             if self._stop:
                 raise RuntimeError("batcher is closed")
@@ -50,26 +51,34 @@ class MicroBatcher:
                 raise it.error
         return [it.result for it in items]
 
-    def _take(self):
-        """Oldest item + every queued item with the same key, up to capacity (queue order preserved for the rest)."""
-        first = self._q.popleft()
-        cap = max(1, int(self._capacity(first.key)))
-        batch, rest = [first], deque()
-        while self._q and len(batch) < cap:
+    def _takeable(self, ctx):
+        return any(it.affinity is None or it.affinity is ctx for it in self._q)
+
+    def _take(self, ctx):
+        """Oldest item this worker may run + every queued item with the same key it may run, up to capacity (queue order
+        preserved for the rest)."""
+        first, batch, rest, cap = None, [], deque(), 1
+        while self._q:
             it = self._q.popleft()
-            (batch if it.key == first.key else rest).append(it)
-        rest.extend(self._q)
+            mine = it.affinity is None or it.affinity is ctx
+            if first is None and mine:
+                first, batch = it, [it]
+                cap = max(1, int(self._capacity(first.key)))
+            elif first is not None and mine and it.key == first.key and len(batch) < cap:
+                batch.append(it)
+            else:
+                rest.append(it)
         self._q = rest
         return batch
 
     def _loop(self, idx, ctx):
         while True:
             with self._cv:
-                while not self._q and not self._stop:
+                while not self._takeable(ctx) and not self._stop:
                     self._cv.wait()
-                if self._stop and not self._q:
+                if self._stop and not self._takeable(ctx):
                     return
-                batch = self._take()
+                batch = self._take(ctx)
             try:
                 out = self._run(ctx, batch[0].key, [it.payload for it in batch])
                 if len(out) != len(batch):

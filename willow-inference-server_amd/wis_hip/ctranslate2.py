@@ -64,6 +64,7 @@ class _Replica:
         self.handle, self.device = handle, device
         self.lock = threading.Lock()
         self.inflight = 0
+        self.stage = None           # device block for batches of device-resident features (lazy)
 
 
 def make_config(a, max_batch, max_beam, suppress_ids=None, suppress_begin=None, lang_ids=None, n_vocab=None, weight_bits=16):
@@ -125,20 +126,28 @@ def create_replicas(a, arena, index, devices, max_batch=8, max_beam=5, **cfgkw):
         return [create_handle(a, arena, index, devices[0], max_batch, max_beam, **cfgkw)]
     lib = _lib.load()
     bufs = [None] * len(devices)
-    bufs[0] = _lib.DevBuf.from_numpy(arena, devices[0])
-    have = 1
-    while have < len(devices):          # doubling: every device that holds the arena feeds one that does not
-        for src in range(have):
-            dst = have + src
-            if dst >= len(devices):
-                break
-            bufs[dst] = _lib.DevBuf(arena.nbytes, devices[dst])
-            _lib.check(lib.wis_dev_copy_peer(devices[dst], bufs[dst].ptr, devices[src], bufs[src].ptr, arena.nbytes))
-        have *= 2
     handles = []
     try:
-        for d, b in zip(devices, bufs):
-            handles.append(create_handle(a, None, index, d, max_batch, max_beam, arena_device_ptr=(b.ptr.value, arena.nbytes), **cfgkw))
+        bufs[0] = _lib.DevBuf.from_numpy(arena, devices[0])
+        have = 1
+        while have < len(devices):          # doubling: every device that holds the arena feeds one that does not
+            for src in range(have):
+                dst = have + src
+                if dst >= len(devices):
+                    break
+                bufs[dst] = _lib.DevBuf(arena.nbytes, devices[dst])
+                _lib.check(lib.wis_dev_copy_peer(devices[dst], bufs[dst].ptr, devices[src], bufs[src].ptr, arena.nbytes))
+            have *= 2
+        # every copy is done (hipMemcpyPeer is synchronous): each device's arena copy is released as soon as ITS replica has
+        # re-packed it, so a device never holds more than its own arena copy + its model
+        for i, d in enumerate(devices):
+            handles.append(create_handle(a, None, index, d, max_batch, max_beam, arena_device_ptr=(bufs[i].ptr.value, arena.nbytes), **cfgkw))
+            bufs[i].free()
+            bufs[i] = None
+    except BaseException:
+        for h in handles:                   # a failed fan-out leaves nothing behind on any GPU
+            lib.wis_model_destroy(h)
+        raise
     finally:
         for b in bufs:
             if b is not None:
@@ -162,6 +171,8 @@ def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_bl
 
 
 MAX_DECODER_ROWS = 48      # csrc/kernels.hpp MAX_ROWS: decoder rows per device pass
+MAX_BEAM = 8               # csrc/kernels.hpp MAX_R: rows per utterance (beam size)
+MAX_PROMPT = 16            # wis_generate: prompt tokens per utterance
 
 
 def _capacity(max_batch, key):
@@ -171,11 +182,29 @@ def _capacity(max_batch, key):
     return max(1, min(max_batch, MAX_DECODER_ROWS // max(beam, 1), MAX_DECODER_ROWS // max(P, 1)))
 
 
+_MEL_BYTES = 80 * 3000 * 4
+
+
 def _run_batch(replica, key, rows):
     P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind = key
+    prompts = [p for _, p in rows]
+    if kind == _lib.WIS_IN_MEL_DEV:
+        # features that already live in this replica's HBM (streaming sessions: audio.MelStream.finish): one utterance goes in
+        # by pointer, several are gathered device-to-device into the replica's staging block - nothing visits the host
+        with replica.lock:
+            if len(rows) == 1:
+                ptr = int(rows[0][0])
+            else:
+                if replica.stage is None or replica.stage.nbytes < len(rows) * _MEL_BYTES:
+                    replica.stage = _lib.DevBuf(max(len(rows), 8) * _MEL_BYTES, replica.device)
+                lib = _lib.load()
+                for i, (src, _) in enumerate(rows):
+                    _lib.check(lib.wis_dev_copy_peer(replica.device, C.c_void_p(replica.stage.ptr.value + i * _MEL_BYTES), replica.device, C.c_void_p(int(src)), _MEL_BYTES))
+                ptr = replica.stage.ptr.value
+            return _generate_chunk(replica, len(rows), prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=ptr)
     mel = np.ascontiguousarray(np.stack([m for m, _ in rows]))
     with replica.lock:
-        return _generate_chunk(replica, mel, [p for _, p in rows], P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind)
+        return _generate_chunk(replica, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind)
 
 
 class Whisper:
@@ -203,6 +232,8 @@ class Whisper:
         devs = list(device_index) if isinstance(device_index, (list, tuple)) else [int(device_index)]
         if not 1 <= int(max_batch) <= MAX_DECODER_ROWS:
             raise ValueError(f"max_batch={max_batch}: a device batch holds 1..{MAX_DECODER_ROWS} utterances")
+        if not 1 <= int(max_beam) <= MAX_BEAM:
+            raise ValueError(f"max_beam={max_beam}: the engine decodes with beam sizes 1..{MAX_BEAM}")
         arena, index = W.build_arena(weights)
         kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"),
                   weight_bits=8 if self.compute_type == "int8_float16" else 16)
@@ -292,11 +323,24 @@ class Whisper:
         P = len(prompts[0])
         if any(len(p) != P for p in prompts):
             raise ValueError("all prompts must have the same length")
+        # the engine's capacity limits are request errors (ValueError -> HTTP 400 in wis_hip.server), not internal ones
+        if not 1 <= int(beam_size) <= self.max_beam:
+            raise ValueError(f"beam_size {beam_size} outside 1..{self.max_beam} (setting max_beam; engine ceiling {MAX_BEAM})")
+        if not 1 <= P <= MAX_PROMPT:
+            raise ValueError(f"prompt length {P} outside 1..{MAX_PROMPT}")
         max_new = min(max_length // 2, max_length - P)
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), list(suppress_tokens) == [-1],
                int(fixed_new_tokens), int(input_kind))
         rows = [(np.ascontiguousarray(mel[b]), [int(t) for t in prompts[b]]) for b in range(B)]
         return self._batcher.submit(key, rows)
+
+    def acquire_replica(self):
+        """The least-loaded replica, counted as in use until release_replica (a streaming session pins its log-mel front-end
+        and its windows to ONE GPU for its lifetime; sessions spread over the replicas like requests do)."""
+        return self._acquire()
+
+    def release_replica(self, r):
+        self._release(r)
 
     def replica_on(self, device):
         """A replica that lives on `device` (streaming sessions keep their features on one GPU)."""
@@ -308,13 +352,17 @@ class Whisper:
     def generate_from_device(self, device, mel_device_ptr, prompt, *, beam_size=5, max_length=448, length_penalty=1, patience=1,
                              suppress_blank=True, fixed_new_tokens=0):
         """One utterance whose log-mel features ALREADY live in HBM on `device` (f32 [80][3000] at `mel_device_ptr`, e.g. an
-        audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Runs on that device's replica."""
+        audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Goes through the micro-batcher
+        with that device's replica as its affinity: concurrent windows of several streaming sessions on the same GPU coalesce
+        into one device batch like REST requests do."""
         r = self.replica_on(device)
         P = len(prompt)
         max_new = min(max_length // 2, max_length - P)
-        with r.lock:
-            return _generate_chunk(r, 1, [prompt], P, int(beam_size), max_new, float(length_penalty), float(patience), suppress_blank, True,
-                                   int(fixed_new_tokens), _lib.WIS_IN_MEL_DEV, device_ptr=int(mel_device_ptr))[0]
+        if not 1 <= int(beam_size) <= self.max_beam:
+            raise ValueError(f"beam_size {beam_size} outside 1..{self.max_beam}")
+        key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), True, int(fixed_new_tokens),
+               int(_lib.WIS_IN_MEL_DEV))
+        return self._batcher.submit(key, [(int(mel_device_ptr), [int(t) for t in prompt])], affinity=r)[0]
 
     def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
         """One `wis_generate` call on replica r (the caller serialises access to r)."""

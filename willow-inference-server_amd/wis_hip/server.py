@@ -58,6 +58,10 @@ def parse_multipart(body, content_type, field="audio_file"):
     raise ValueError(f"multipart field {field!r} missing")
 
 
+class BadRequest(ValueError):
+    """A request parameter the engine cannot serve -> HTTP 400 with the message."""
+
+
 def _as_bool(v, default):
     if v is None:
         return default
@@ -95,7 +99,14 @@ def create_app(models=None, settings=None, max_workers=None):
         q = request.query_params
         model = q.get("model", s.whisper_model_default)
         beam = q.get("beam_size")
-        return dict(model=model, beam_size=int(beam) if beam not in (None, "") else s.beam_size,
+        try:
+            beam = int(beam) if beam not in (None, "") else s.beam_size
+        except ValueError:
+            raise BadRequest(f"Invalid beam_size {beam!r}")
+        # the engine's beam ceiling is a property of the request, not a server fault (the reference accepts any int, main.py:1180)
+        if not 1 <= beam <= s.max_beam:
+            raise BadRequest(f"beam_size {beam} outside 1..{s.max_beam}")
+        return dict(model=model, beam_size=beam,
                     detect_language=_as_bool(q.get("detect_language"), s.detect_language), force_language=q.get("force_language") or None,
                     translate=_as_bool(q.get("translate"), False))
 
@@ -113,7 +124,10 @@ def create_app(models=None, settings=None, max_workers=None):
 
     @app.post("/api/asr")
     async def asr(request: Request):
-        p = params(request)
+        try:
+            p = params(request)
+        except BadRequest as e:
+            return bad(str(e))
         if p["force_language"] and not check_language(p["force_language"]):
             return bad("Invalid force_language")
         try:
@@ -132,7 +146,10 @@ def create_app(models=None, settings=None, max_workers=None):
 
     @app.post("/api/willow")
     async def willow(request: Request):
-        p = params(request)
+        try:
+            p = params(request)
+        except BadRequest as e:
+            return bad(str(e))
         q = request.query_params
         save_audio, stats, voice_auth = _as_bool(q.get("save_audio"), False), _as_bool(q.get("stats"), False), _as_bool(q.get("voice_auth"), False)
         if p["force_language"] and not check_language(p["force_language"]):

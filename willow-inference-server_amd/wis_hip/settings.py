@@ -46,6 +46,9 @@ class APISettings:
     # mel -> host -> StorageView round trip; results are identical (same kernels)
     fuse_logmel: bool = True
     max_batch: int = 8
+    # largest beam_size a request may ask for (sizes the KV-cache slots: max_batch * max_beam); the engine's ceiling is 8
+    # (csrc/kernels.hpp MAX_R) - a larger per-request beam_size is answered with HTTP 400, not a 500
+    max_beam: int = 8
     # measurement convention for seeded synthetic weights, which never emit EOT: decode exactly this many tokens
     # (EOT masked until then, then forced).  0 = off: the product default, natural termination
     fixed_new_tokens: int = 0

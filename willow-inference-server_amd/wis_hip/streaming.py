@@ -6,7 +6,10 @@ done incrementally without changing results is the reference's own long-audio sc
 windows with 4 s of context either side, stepping 14 s.  A `StreamingSession` accepts PCM as it arrives and, as soon as
 the audio is known to need chunking (> 30 s buffered), transcribes every window whose 22 s are complete on a worker thread
 (through the model's micro-batcher, so several sessions share device batches); `stop()` then only has the tail window left
-and returns exactly what `do_whisper` returns for the complete recording.  `interim()` gives the hypothesis for what has
+and returns exactly what `do_whisper` returns for the complete recording.  A session with the incremental front-end is pinned
+to ONE GPU for its lifetime - the least-loaded replica at creation (`Whisper.acquire_replica`), so sessions spread over the
+replicas - because its features live in that GPU's HBM; its windows still go through the micro-batcher (replica affinity,
+`Whisper.generate_from_device`), so concurrent sessions on a GPU coalesce into device batches.  `interim()` gives the hypothesis for what has
 been heard so far (an extra decode; the final result never depends on it).  The log-mel front-end is incremental
 (`_IncrementalFront`, C-ABI wis_melstream_*): each window's spectrogram tiles are computed while its audio arrives, only the
 clamp / scaling is left when the window completes, and the features go to the encoder straight from HBM.
@@ -84,7 +87,7 @@ class StreamingSession:
         if force_language and not check_language(force_language):
             raise ValueError(f"unsupported language {force_language!r}")
         self._whisper = self.models.get(model)
-        self._pcm = np.zeros(0, np.float32)
+        self._chunks, self._n = [], 0   # PCM as it arrived; consolidated lazily (_audio) when a window is cut, not once per frame
         self._lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="wis-stream")
         self._windows = {}            # (start, length) -> Future[list[int]]   window token ids, computed eagerly
@@ -92,7 +95,16 @@ class StreamingSession:
         self._closed = False
         self.eager_windows = 0        # windows transcribed before stop() (stats / tests)
         self.front_windows = 0        # windows whose features came from the incremental front-end
-        self._front = _IncrementalFront(self._whisper._replicas[0].device) if incremental else None
+        # the session's GPU: the least-loaded replica now, held (counted in its load) until close()
+        self._replica = self._whisper.acquire_replica() if incremental else None
+        self._front = _IncrementalFront(self._replica.device) if incremental else None
+
+    def _audio(self):
+        """Everything received so far as one array (lock held).  The chunk list collapses into that array, so the cost is paid
+        once per cut window / interim / stop, not once per 20 ms frame."""
+        if len(self._chunks) != 1:
+            self._chunks = [np.concatenate(self._chunks) if self._chunks else np.zeros(0, np.float32)]
+        return self._chunks[0]
 
     # ---- audio in ----------------------------------------------------------------------------------------------------
     def feed(self, samples, sample_width=None):
@@ -105,7 +117,8 @@ class StreamingSession:
             samples = np.frombuffer(bytes(samples), "<i2").astype(np.float32) / 32768.0
         x = np.ascontiguousarray(samples, np.float32).reshape(-1)
         with self._lock:
-            self._pcm = np.concatenate([self._pcm, x])
+            self._chunks.append(x.copy())
+            self._n += x.shape[0]
             front = getattr(self, "_front", None)
             if front is not None:
                 front.feed(x, self.models.settings.support_chunking)
@@ -113,7 +126,7 @@ class StreamingSession:
 
     @property
     def buffered_ms(self):
-        return int(self._pcm.shape[0] / audio.SAMPLE_RATE * 1000)
+        return int(self._n / audio.SAMPLE_RATE * 1000)
 
     # ---- scheduling --------------------------------------------------------------------------------------------------
     def _prompt(self, language):
@@ -158,14 +171,14 @@ class StreamingSession:
         """Called with the lock held.  Once more than 30 s are buffered the final call WILL chunk (main.py:588), with the
         long-audio beam (>= 12 s, main.py:582-586); every window that already has its full 22 s has its final content."""
         s = self.models.settings
-        n = self._pcm.shape[0]
+        n = self._n
         if not s.support_chunking or n <= 30 * audio.SAMPLE_RATE:
             return
         start = 0
         while start + audio.chunk_len <= n:
             key = (start, audio.chunk_len)
             if key not in self._windows:
-                piece = self._pcm[start:start + audio.chunk_len].copy()
+                piece = self._audio()[start:start + audio.chunk_len].copy()
                 if self._language_job is None:         # start == 0 here: the chunked call detects on exactly this window
                     self._language_job = self._pool.submit(self._detect, piece)
                 front = getattr(self, "_front", None)
@@ -178,7 +191,7 @@ class StreamingSession:
     def _transcribe(self, final):
         t0 = time.perf_counter()
         with self._lock:
-            pcm = self._pcm.copy()
+            pcm = self._audio().copy()
         if pcm.shape[0] == 0:
             raise InvalidAudio("empty audio")
         s = self.models.settings
@@ -232,6 +245,9 @@ class StreamingSession:
         front = getattr(self, "_front", None)
         if front is not None:
             front.close()
+        r, self._replica = getattr(self, "_replica", None), None
+        if r is not None:
+            self._whisper.release_replica(r)
 
 
 class DataChannelProtocol:

@@ -33,7 +33,19 @@ class WhisperResult(tuple):
     translation_tokens = None
 
 
+def special_ids_from_tokenizer_json(path):
+    """`tokenizer.all_special_ids` as HF computes it for a fast tokenizer: the ids of the `added_tokens` entries flagged
+    `special: true` in tokenizer.json (for the Whisper checkpoints: <|endoftext|>, <|startoftranscript|>, the language and
+    task tokens, <|nospeech|>, <|notimestamps|> - NOT the <|0.00|>... timestamp tokens, which are added but not special).
+    The reference strips exactly this list before stitching windows (wis/audio.py:141-146)."""
+    import json
+    with open(path, "r", encoding="utf-8") as f:
+        tj = json.load(f)
+    return sorted({int(t["id"]) for t in tj.get("added_tokens", []) if t.get("special")})
+
+
 class _Tokenizer:
+    # id-only form (no tokenizer files, synthetic weights): every id from <|endoftext|> up is treated as special
     all_special_ids = SPECIAL_IDS
 
     def __init__(self, path=None):
@@ -41,6 +53,9 @@ class _Tokenizer:
         if path and os.path.exists(os.path.join(path, "tokenizer.json")):
             from tokenizers import Tokenizer
             self._tok = Tokenizer.from_file(os.path.join(path, "tokenizer.json"))
+            ids = special_ids_from_tokenizer_json(os.path.join(path, "tokenizer.json"))
+            if ids:                     # the checkpoint's own list, as `WhisperProcessor.tokenizer.all_special_ids` (wis/audio.py:141)
+                self.all_special_ids = ids
 
     @property
     def has_vocabulary(self):
@@ -95,7 +110,9 @@ class WhisperModels:
                     self.tokenizers[size] = tok
                 self._models[size] = ctranslate2.models.Whisper(path, device="cuda", compute_type=self.settings.compute_type,
                                                                 inter_threads=self.settings.ctranslate2_threads,
-                                                                device_index=self.device_index, max_batch=self.settings.max_batch)
+                                                                device_index=self.device_index, max_batch=self.settings.max_batch,
+                                                                max_beam=min(max(int(self.settings.max_beam), int(self.settings.beam_size),
+                                                                                 int(self.settings.long_beam_size)), ctranslate2.MAX_BEAM))
             return self._models[size]
 
     def tokenizer_for(self, size):
@@ -175,7 +192,9 @@ def do_whisper(audio_file, model, beam_size=None, task="transcribe", detect_lang
         features, kind = np.ascontiguousarray(windows, np.float32), ctranslate2._lib.WIS_IN_PCM_HOST
     else:
         # the reference's two-step form (main.py:606-614, 685): features to the host, then StorageView.from_array
-        features, kind = audio.log_mel_spectrogram(windows).numpy(), ctranslate2._lib.WIS_IN_MEL_HOST
+        # (on one of the model's own GPUs - never on a device the server was not configured to use)
+        dev = whisper_model._replicas[0].device if getattr(whisper_model, "_replicas", None) else None
+        features, kind = audio.log_mel_spectrogram(windows, device=dev).numpy(), ctranslate2._lib.WIS_IN_MEL_HOST
     total_chunk_count = features.shape[0]
     tokenizer = models.tokenizer_for(model)
 
