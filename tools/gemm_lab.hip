@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <vector>
 
@@ -409,6 +410,162 @@ static void launch_g(const P& p, hipStream_t st) {
   hipLaunchKernelGGL((gemm_g_kernel<BM, BN, WM, WN, NBUF>), dim3(nwg), dim3(64 * WM * WN), 0, st, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 8-phase 256 x 256 workgroup (cdna_hip_programming.md, "The 256^2 8-phase template"): 512 threads = 8 waves as 2 (M) x 4 (N), wave
+// tile 128 x 64 on v_mfma_f32_16x16x32_f16, BK = 64, LDS-DMA staging (global_load_lds_dwordx4) into two 64 KiB k-tile buffers.
+// A k-tile is staged as FOUR half-tiles of 128 rows x 128 B, in the order of first use:
+//   h0 = N-lo (weight rows wc*64 + 0..31 of every wave column), h1 = M-lo (activation rows wr*128 + 0..63 of both wave rows),
+//   h2 = N-hi (wc*64 + 32..63), h3 = M-hi (wr*128 + 64..127)
+// and computed in four phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile each over the 64-deep k-tile):
+//   phase 0: reads N-lo (4 x ds_read_b128) then M-lo (8), stages h3 of tile t+1    -> MFMA M-lo x N-lo
+//   phase 1: reads N-hi (4),                       stages h0 of tile t+2    -> MFMA M-lo x N-hi
+//   phase 2: reads M-hi (8),                       stages h1 of tile t+2    -> MFMA M-hi x N-hi
+//   phase 3: no reads,                             stages h2 of tile t+2, vmcnt(6) (tile t+1 landed) -> MFMA M-hi x N-lo
+// i.e. the staging runs SEVEN half-tiles ahead of the compute, three of them still in flight across the once-per-k-tile counted
+// wait; a phase is {reads + stage, s_barrier, lgkmcnt(0), setprio 1, 16 MFMAs, setprio 0, s_barrier} with RAW barriers (a
+// __syncthreads() would drain the LDS-DMA queue).  The two wave rows run staggered by one barrier (wave row 1 executes one extra
+// s_barrier up front): on every SIMD one wave is in its MFMA segment while the other reads / stages.  LDS image of a half-tile:
+// [128 rows][64 f16] unpadded (the DMA writes lane-linear), 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7): the swizzle is
+// applied to the per-lane SOURCE address and to the fragment read address (conflict-free for the four 16-lane groups a
+// ds_read_b128 is served in).  Restaging distances (with the stagger a region may be restaged two phases after its last read, or
+// one phase after when the read was retired before the reading phase's first barrier - N-lo, by the lgkmcnt(8) of phase 0).
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool STAGGER, bool PRIO>
+__global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
+  constexpr int BM_ = 256, BN_ = 256, HALF = 128 * 64, BUF = 4 * HALF;
+  __shared__ __attribute__((aligned(1024))) f16 smem[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
+  int wg;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN_;
+  const int nk = p.K / BK;
+  // ---- staging sources: wave w stages local rows (2 w + j) * 8 + (lane >> 3), j = 0, 1, of every half-tile
+  const f16 *sN[2][2], *sM[2][2];      // [lo / hi][j]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
+    const int n = n0 + (rl >> 5) * 64 + (rl & 31);
+    sN[0][j] = p.W + (int64_t)n * p.K + c * 8;
+    sN[1][j] = p.W + (int64_t)(n + 32) * p.K + c * 8;
+    int mlo = m0 + (rl >> 6) * 128 + (rl & 63), mhi = mlo + 64;
+    if (mlo > p.M - 1) mlo = p.M - 1;
+    if (mhi > p.M - 1) mhi = p.M - 1;
+    sM[0][j] = p.A + (int64_t)mlo * p.K + c * 8;
+    sM[1][j] = p.A + (int64_t)mhi * p.K + c * 8;
+  }
+#define WIS_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst), 16, 0, 0)
+  // half-tile h (0 N-lo, 1 M-lo, 2 N-hi, 3 M-hi) of the NEXT k-tile this pointer pair has not staged yet -> LDS buffer at element
+  // offset `bo`; every source pointer is used once per k-tile, so it simply advances by one k-tile per use
+#define WIS_STAGE(PA, PB, h, bo) do { \
+    f16* d_ = smem + (bo) + (h) * HALF + wave * 1024; \
+    WIS_DMA(PA, d_); WIS_DMA(PB, d_ + 512); PA += BK; PB += BK; } while (0)
+  // ---- fragment read offsets (f16 elements inside a half-tile region): row * 64 + ((4 kb + kq) ^ (l15 >> 1)) * 8
+  const int fo0 = l15 * 64 + ((kq ^ (l15 >> 1)) << 3);
+  const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;      // + buffer + region + blk * 1024 (immediates); k-block 1 = the same offset ^ 32 elements
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // ---- prologue: k-tile 0 complete, three half-tiles of k-tile 1 in flight (nk >= 2)
+  WIS_STAGE(sN[0][0], sN[0][1], 0, 0); WIS_STAGE(sM[0][0], sM[0][1], 1, 0); WIS_STAGE(sN[1][0], sN[1][1], 2, 0); WIS_STAGE(sM[1][0], sM[1][1], 3, 0);
+  WIS_STAGE(sN[0][0], sN[0][1], 0, BUF); WIS_STAGE(sM[0][0], sM[0][1], 1, BUF); WIS_STAGE(sN[1][0], sN[1][1], 2, BUF);
+  __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
+  f16x8v nlo[2][2], nhi[2][2], mlo[4][2], mhi[4][2];
+#define WIS_FRAG(base, h, blk, kb) (*reinterpret_cast<const f16x8v*>(smem + ((kb) ? base##1 : base##0) + (h) * HALF + (blk) * 1024))
+#define WIS_MMA16(MF, NF, MB0, NB0) do { \
+    __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); \
+    if (PRIO) __builtin_amdgcn_s_setprio(1); \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
+      _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+          acc[(MB0) + mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], MF[mb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0); \
+    if (PRIO) __builtin_amdgcn_s_setprio(0); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+  int cb = 0;      // element offset of the buffer holding k-tile t
+  for (int t = 0; t < nk; ++t) {
+    const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
+    const int nb_ = cb ^ BUF;      // the other buffer
+    // ---- phase 0
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mlo[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
+    if (t + 1 < nk) WIS_STAGE(sM[1][0], sM[1][1], 3, nb_);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8): the four N-lo reads are retired before the first barrier
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mlo, nlo, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
+    if (t + 2 < nk) WIS_STAGE(sN[0][0], sN[0][1], 0, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mlo, nhi, 0, 2);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mhi[mb][kb] = WIS_FRAG(rMb, 3, mb, kb);
+    if (t + 2 < nk) WIS_STAGE(sM[0][0], sM[0][1], 1, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mhi, nhi, 4, 2);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3
+    if (t + 2 < nk) { WIS_STAGE(sN[1][0], sN[1][1], 2, cb); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed (this wave's share), three half-tiles of t+2 fly on
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mhi, nlo, 4, 0);
+    __builtin_amdgcn_s_barrier();
+    cb = nb_;
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier
+#undef WIS_MMA16
+#undef WIS_FRAG
+#undef WIS_STAGE
+#undef WIS_DMA
+  // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int m = m0 + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
+    if (m < p.M) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int n = n0 + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq;
+        const f16x4 o = {(f16)acc[mb][nb][0], (f16)acc[mb][nb][1], (f16)acc[mb][nb][2], (f16)acc[mb][nb][3]};
+        *reinterpret_cast<f16x4*>(p.C + (size_t)m * p.N + n) = o;
+      }
+    }
+  }
+}
+template <bool STAGGER, bool PRIO>
+static void launch_8p(const P& p, hipStream_t st) {
+  const int nwg = ((p.M + 255) / 256) * (p.N / 256);
+  hipLaunchKernelGGL((gemm_8p_kernel<STAGGER, PRIO>), dim3(nwg), dim3(512), 0, st, p);
+}
+
 struct Shape { const char* name; int N, K; };
 
 template <int BM, int BN, int WM, int WN, int VAR, bool PROF>
@@ -485,6 +642,9 @@ int main(int argc, char** argv) {
     {"256x256 pp", launch_pp<256, false>, launch_pp<256, true>, 256, 256},
     {"256x256 v0", launch<256, 256, 2, 4, 0, false>, launch<256, 256, 2, 4, 0, true>, 256, 256},
     {"256x256 v1", launch<256, 256, 2, 4, 1, false>, launch<256, 256, 2, 4, 1, true>, 256, 256},
+    {"256x256 8p ", launch_8p<true, true>, nullptr, 256, 256},
+    {"256x256 8p-nostagger", launch_8p<false, true>, nullptr, 256, 256},
+    {"256x256 8p-noprio", launch_8p<true, false>, nullptr, 256, 256},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
   const bool stamps = argc > 2 ? atoi(argv[2]) != 0 : true;
@@ -514,9 +674,9 @@ int main(int argc, char** argv) {
       CK(hipMemsetAsync(dC, 0, (size_t)M * s.N * 2, st));
       vs[v].fn(q, st); CK(hipStreamSynchronize(st));
       std::vector<f16> c((size_t)M * s.N); CK(hipMemcpy(c.data(), dC, c.size() * 2, hipMemcpyDeviceToHost));
-      size_t bad = 0; for (size_t i = 0; i < c.size(); ++i) bad += memcmp(&c[i], &c0[i], 2) != 0;
+      size_t bad = 0; double maxd = 0; for (size_t i = 0; i < c.size(); ++i) { bad += memcmp(&c[i], &c0[i], 2) != 0; const double dd = fabs((double)(float)c[i] - (double)(float)c0[i]); if (!(dd <= maxd)) maxd = dd; }
       const double us = time_us(vs[v].fn, q, st, 40);
-      printf("  %s  tiles %4d  %7.2f us  %6.0f TFLOP/s  mismatches vs v0: %zu\n", vs[v].name, tiles, us, gflop / us * 1e3, bad);
+      printf("  %s  tiles %4d  %7.2f us  %6.0f TFLOP/s  mismatches vs v0: %zu (max abs diff %.4g)\n", vs[v].name, tiles, us, gflop / us * 1e3, bad, maxd);
       if (stamps && vs[v].fn_prof && (&s == &shapes[0] || &s == &shapes[3])) { q.probe_wg = tiles / 3; run_stamps(vs[v].fn_prof, q, st, vs[v].name); }
     }
     for (int i = 1; i < g_nrot; ++i) CK(hipFree((void*)g_wpool[i]));

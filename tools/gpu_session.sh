@@ -1,0 +1,60 @@
+#!/bin/bash
+# The gpurun command file of the build sessions (one documented script instead of one file per call):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <step> [<step> ...]'
+# Steps (each writes under gpurun_out/<tag>/, tag = $WIS_TAG or "r3"):
+#   lab [M ...]     tools/bin/gemm_lab at the given row counts (default 1500 3000 12000), stamps off, weights from HBM
+#   tests <expr>    pytest -m gpu -k <expr> (quote the expression); "tests all" = the whole GPU suite
+#   smoke           __graft_entry__.smoke()
+#   bench1 / bench8 [ENV=VAL ...]   bench.py at 1 / 8 utterances per device batch (no extras, no CPU baseline); extra words are
+#                   environment assignments for that run and become part of the output name
+#   benchfull       the default bench.py line (what the driver runs)
+#   prof1 / prof8   rocprofv3 --kernel-trace --stats of the eager bench at 1 / 8 utterances -> kernel_stats_b*.txt (+ by-grid table)
+#   pmc <counter>   one rocprofv3 --pmc pass of the eager batch-8 bench -> pmc_<counter>.csv (per-kernel sums)
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=${WIS_TAG:-r3}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
+R=$GRAFT_REPO_ROOT
+run_bench() {   # $1 = batch, rest = env assignments
+  local B=$1; shift
+  local name="bench_b${B}"; for kv in "$@"; do name="${name}_${kv//[^A-Za-z0-9=]/}"; done
+  env "$@" timeout 600 python bench.py --steps 20 --warmup 3 --batch "$B" --no-cpu-baseline --no-extras > "$O/$name.json" 2> "$O/$name.err"
+  python - "$O/$name.json" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    print(sys.argv[1].split("/")[-1], "ms/step", d["ms_per_step"], "x_rt", d["value"], "stages", d["stage_ms_last_step"], "roofline", (d.get("roofline") or {}).get("frac"),
+          "dec_step", ((d.get("roofline") or {}).get("decode_step") or {}).get("ms"), "enc_TF", ((d.get("roofline") or {}).get("encoder") or {}).get("achieved_TFLOPs"))
+except Exception as e:
+    print("bench output unreadable:", e)
+PY
+}
+while [ $# -gt 0 ]; do
+  step=$1; shift
+  case $step in
+    lab)
+      Ms=""; while [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; do Ms="$Ms $1"; shift; done
+      [ -z "$Ms" ] && Ms="1500 3000 12000"
+      for M in $Ms; do timeout 300 tools/bin/gemm_lab "$M" 0 1 > "$O/lab_M$M.txt" 2>&1; grep -v "^  stamps\|steady" "$O/lab_M$M.txt"; done ;;
+    tests)
+      expr=$1; shift
+      if [ "$expr" = all ]; then timeout 1500 python -m pytest tests -q -x -m gpu > "$O/tests_all.log" 2>&1; echo "rc=$?" >> "$O/tests_all.log"; tail -5 "$O/tests_all.log"
+      else timeout 1500 python -m pytest tests -q -x -m gpu -k "$expr" -s > "$O/tests_sel.log" 2>&1; echo "rc=$?" >> "$O/tests_sel.log"; grep -v "^$" "$O/tests_sel.log" | tail -60; fi ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -2 "$O/smoke.log" ;;
+    bench1|bench8)
+      B=${step#bench}; envs=(); while [ $# -gt 0 ] && [[ $1 == *=* ]]; do envs+=("$1"); shift; done
+      run_bench "$B" "${envs[@]}" ;;
+    benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; tail -c 600 "$O/bench_default.json" ;;
+    prof1|prof8)
+      B=${step#prof}
+      ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof_b$B" -o "b$B" -- python "$R/bench.py" --steps 5 --warmup 2 --batch "$B" --no-cpu-baseline --no-extras > "$O/bench_eager_b$B.log" 2>&1 )
+      DB=$(find "$O/prof_b$B" -name "*.db" | head -1)
+      python tools/prof_summary.py "$DB" 45 > "$O/kernel_stats_b$B.txt" 2>&1
+      python tools/prof_summary.py "$DB" 45 --by-grid > "$O/kernels_by_grid_b$B.txt" 2>&1
+      find "$O/prof_b$B" -name "*.db" -delete
+      head -30 "$O/kernel_stats_b$B.txt" ;;
+    pmc)
+      CNT=$1; shift
+      ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --pmc "$CNT" --kernel-trace -d "$O/pmc_$CNT" -o p --output-format csv -- python "$R/bench.py" --steps 3 --warmup 1 --batch 8 --no-cpu-baseline --no-extras --no-roofline > "$O/pmc_$CNT.log" 2>&1 )
+      python tools/pmc_sum.py "$O/pmc_$CNT" "$CNT" > "$O/pmc_$CNT.txt" 2>&1; find "$O/pmc_$CNT" -name "*.csv" -size +20M -delete; head -30 "$O/pmc_$CNT.txt" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

@@ -328,6 +328,160 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p, Epi epi) {
       }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// 8-phase 256 x 256 workgroup for the batched encoder (>= 150 tiles: two or more utterances), after the guide's plain-HIP template
+// (cdna_hip_programming.md "The 256^2 8-phase template"; tools/gemm_lab.hip carries the same loop for tuning).  512 threads = 8 waves
+// as 2 (M) x 4 (N), wave tile 128 x 64 on v_mfma_f32_16x16x32_f16, BK = 64, operands staged by LDS-DMA (global_load_lds_dwordx4: no
+// VGPR round trip, no ds_write pass) into two 64 KiB k-tile buffers.  A k-tile is staged as FOUR half-tiles of 128 rows x 128 B, in
+// the order of first use -
+//   h0 = N-lo (weight rows wc*64 + 0..31 of every wave column)     h1 = M-lo (activation rows wr*128 + 0..63 of both wave rows)
+//   h2 = N-hi (wc*64 + 32..63)                                      h3 = M-hi (wr*128 + 64..127)
+// - and computed in four phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile over the 64-deep k-tile each):
+//   phase 0: reads N-lo (4 x ds_read_b128), then M-lo (8); stages h3 of k-tile t+1              MFMA M-lo x N-lo
+//   phase 1: reads N-hi (4);                          stages h0 of k-tile t+2              MFMA M-lo x N-hi
+//   phase 2: reads M-hi (8);                          stages h1 of k-tile t+2              MFMA M-hi x N-hi
+//   phase 3: no reads;                                stages h2 of k-tile t+2, vmcnt(6)    MFMA M-hi x N-lo (N-lo kept in registers)
+// The staging runs SEVEN half-tiles ahead of the compute and three of them stay in flight across the one counted wait per k-tile
+// (never vmcnt(0) in the loop).  A phase is {fragment reads + one half-tile of DMA, s_barrier, lgkmcnt(0), s_setprio 1, 16 MFMAs,
+// s_setprio 0, s_barrier} with RAW barriers - __syncthreads() would drain the DMA queue.  The two wave rows run staggered by one
+// barrier (wave row 1 executes one extra s_barrier up front): wave w and wave w + 4 share a SIMD, so every SIMD has one wave in its
+// MFMA segment while the other reads / stages.  Ordering rules this relies on (guide, "Read a staged buffer one phase AFTER the wait
+// that retires it"): k-tile t+1 is read from phase 0 of t+1 on, its wait sits in phase 3 of t, and both wave rows pass a barrier in
+// between; with the stagger a region is restaged two phases after its last read (M-lo, N-hi, M-hi) or one phase after when the read
+// was retired before the reading phase's first barrier (N-lo: the lgkmcnt(8) of phase 0, its four reads being issued first).
+// LDS image of a half-tile: [128 rows][64 f16] unpadded (the DMA writes lane-linear); the 16-byte chunk c of row r sits in slot
+// c ^ ((r >> 1) & 7) - applied to the per-lane SOURCE address and to the fragment read address (the same involution on both sides),
+// conflict-free for the four 16-lane groups a ds_read_b128 is served in.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
+  constexpr int BM_ = 256, BN_ = 256, HALF = 128 * 64, BUF = 4 * HALF;
+  __shared__ __attribute__((aligned(1024))) f16 smem[2 * BUF];      // ONE LDS object (a second one makes hipcc drain vmcnt before fragment reads)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
+  int wg;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN_;
+  const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
+  const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
+  // staging sources: wave w stages local rows (2 w + j) * 8 + (lane >> 3), j = 0, 1, of every half-tile; each pointer is used once
+  // per k-tile and advances by one k-tile per use
+  const f16 *sNl0, *sNl1, *sNh0, *sNh1, *sMl0, *sMl1, *sMh0, *sMh1;
+  {
+    auto src = [&](int j, const f16** nl, const f16** nh, const f16** ml, const f16** mh) {
+      const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
+      const int n = n0 + (rl >> 5) * 64 + (rl & 31);
+      *nl = p.W + (int64_t)n * p.K + kbeg + c * 8;
+      *nh = p.W + (int64_t)(n + 32) * p.K + kbeg + c * 8;
+      int mlo = m0 + (rl >> 6) * 128 + (rl & 63), mhi = mlo + 64;
+      if (mlo > p.M - 1) mlo = p.M - 1;
+      if (mhi > p.M - 1) mhi = p.M - 1;
+      *ml = p.A + (int64_t)(mlo / p.a_rpb) * p.a_bs + (int64_t)(mlo % p.a_rpb) * p.a_rs + kbeg + c * 8;
+      *mh = p.A + (int64_t)(mhi / p.a_rpb) * p.a_bs + (int64_t)(mhi % p.a_rpb) * p.a_rs + kbeg + c * 8;
+    };
+    src(0, &sNl0, &sNh0, &sMl0, &sMh0);
+    src(1, &sNl1, &sNh1, &sMl1, &sMh1);
+  }
+#define WIS_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst), 16, 0, 0)
+#define WIS_STAGE(PA, PB, h, bo) do { \
+    f16* d_ = smem + (bo) + (h) * HALF + wave * 1024; \
+    WIS_DMA(PA, d_); WIS_DMA(PB, d_ + 512); PA += BK; PB += BK; } while (0)
+  // fragment read offsets (f16 elements inside a half-tile region): row * 64 + ((4 kb + kq) ^ (l15 >> 1)) * 8; k-block 1 = offset ^ 32
+  const int fo0 = l15 * 64 + ((kq ^ (l15 >> 1)) << 3);
+  const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // prologue: k-tile 0 complete, three half-tiles of k-tile 1 in flight (the launcher guarantees nk >= 2)
+  WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sMl0, sMl1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0); WIS_STAGE(sMh0, sMh1, 3, 0);
+  WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sMl0, sMl1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF);
+  __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
+  f16x8 nlo[2][2], nhi[2][2], mlo[4][2], mhi[4][2];
+#define WIS_FRAG(base, h, blk, kb) (*reinterpret_cast<const f16x8*>(smem + ((kb) ? base##1 : base##0) + (h) * HALF + (blk) * 1024))
+#define WIS_MMA16(MF, NF, MB0, NB0) do { \
+    __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_setprio(1); \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
+      _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+          acc[(MB0) + mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], MF[mb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+  int cb = 0;      // element offset of the buffer holding k-tile t
+  for (int t = 0; t < nk; ++t) {
+    const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
+    const int ob = cb ^ BUF;      // the other buffer
+    // ---- phase 0
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mlo[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
+    if (t + 1 < nk) WIS_STAGE(sMh0, sMh1, 3, ob);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8): the four N-lo reads are retired before the first barrier
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mlo, nlo, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
+    if (t + 2 < nk) WIS_STAGE(sNl0, sNl1, 0, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mlo, nhi, 0, 2);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mhi[mb][kb] = WIS_FRAG(rMb, 3, mb, kb);
+    if (t + 2 < nk) WIS_STAGE(sMl0, sMl1, 1, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mhi, nhi, 4, 2);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3
+    if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, cb); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed (this wave's share); three half-tiles of t+2 fly on
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16(mhi, nlo, 4, 0);
+    __builtin_amdgcn_s_barrier();
+    cb = ob;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier
+#undef WIS_MMA16
+#undef WIS_FRAG
+#undef WIS_STAGE
+#undef WIS_DMA
+  // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int m = m0 + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
+    if (m < p.M) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) epi(m, n0 + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq, acc[mb][nb]);
+    }
+  }
+}
+
 // 128-256 ping-pong tiles: every tile has a CU of its own and at least half of the CUs have one (medium, M = 1500: QKV at 144
 // tiles 21.8 us against 24.0 for 288 tiles of 128 x 128)
 static bool gemm_pp_fits(const GemmP& p, int splits) {
@@ -354,7 +508,11 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   if (p.N % 128 || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
   int bm, bn; gemm_pick_tile(p, &bm, &bn);
   const dim3 grid((p.N / bn) * cdiv(p.M, bm), 1, p.klen > 0 ? p.K / p.klen : 1);
-  if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
+  // 256 x 256: the 8-phase LDS-DMA kernel (WIS_GEMM_8P=0: the register-staged 2 x 4-wave tile, A/B tuning switch); it needs two k-tiles
+  static const bool use_8p = !(getenv("WIS_GEMM_8P") && atoi(getenv("WIS_GEMM_8P")) == 0);
+  const int nk_ = (p.klen > 0 ? p.klen : p.K) / BK;
+  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) hipLaunchKernelGGL((gemm_8p_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
+  else if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
