@@ -111,7 +111,7 @@ def decode_step_bytes(a, B, beam, P, steps, w8=False):
     return W + B * C + B * beam * t_avg * s_row
 
 
-def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms):
+def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms, rest_batch=8):
     """The reference's own load shape, client/jmeter-asr.jmx:53-90: `clients` threads, each looping
     POST /api/asr?task=transcribe&output=json&model=large&beam_size=5&detect_language=False with the 3.84 s clip as the
     multipart field `audio_file`.  Served by the re-hosted endpoint (wis_hip/server.py) in this process over the ASGI transport
@@ -124,9 +124,9 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     from wis_hip.whisper import WhisperModels
     s = APISettings()
     s.whisper_model_path = "synthetic:{size}"
-    s.max_batch, s.fixed_new_tokens = 8, fixed_new
+    s.max_batch, s.fixed_new_tokens = rest_batch, fixed_new
     models = WhisperModels(s, device_index=[dev])
-    model = ct2.Whisper.from_handles([(handle, dev)], a, max_batch=8, max_beam=5)
+    model = ct2.Whisper.from_handles([(handle, dev)], a, max_batch=rest_batch, max_beam=5)
     models._models["large"] = model
     app = create_app(models=models, max_workers=max(64, clients))
     b = "wisBenchBoundary"
@@ -144,7 +144,7 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
 
     async def go():
         async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis", timeout=600) as c:
-            await asyncio.gather(*[client(c) for _ in range(min(clients, 8))])        # warm-up: one device batch
+            await asyncio.gather(*[client(c) for _ in range(min(clients, rest_batch))])        # warm-up: one device batch
             lat.clear()
             n0 = len(model._batcher.batches)
             t0 = time.perf_counter()
@@ -155,9 +155,93 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     n = clients * iterations
     model.close()
     model._replicas = []          # the handle belongs to the caller
-    return {"load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport",
+    return {"load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport, device batches of up to {rest_batch}",
             "utterances_per_s": round(n / elapsed, 2), "aggregate_x_realtime": round(n * audio_ms / 1e3 / elapsed, 1),
             "p50_request_ms": round(p50(lat), 2), "max_request_ms": round(max(lat), 2), "device_batches": sizes[:32], "mean_device_batch": round(float(np.mean(sizes)), 2)}
+
+
+def streaming_bench(handle, a, dev, clip_path):
+    """BASELINE configs[4]: long-form / streaming (the reference records the whole WebRTC track and then makes ONE do_whisper call,
+    main.py:963-971).  client/30sec.flac is fed to a StreamingSession as 20 ms int16 frames back to back (no real-time pacing) and
+    the time from stop() to the result is reported, with the incremental log-mel front-end (features built in HBM while the audio
+    arrives) and without it (log-mel of the whole window at stop()); then 64 s of seeded noise, which crosses the 30 s chunking
+    threshold: windows whose 22 s are complete are transcribed while the audio is still arriving (eager windows), stop() only has
+    the tail left.  Same engine handle as the headline (large-v2); the reference's long-audio beam (3) applies from 12 s on."""
+    from wis_hip import audio, ctranslate2 as ct2
+    from wis_hip.settings import APISettings
+    from wis_hip.streaming import StreamingSession
+    from wis_hip.whisper import WhisperModels, do_whisper
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.max_batch = 8
+    models = WhisperModels(s, device_index=[dev])
+    model = ct2.Whisper.from_handles([(handle, dev)], a, max_batch=8, max_beam=5)
+    models._models["large"] = model
+    pcm, _ = audio.load_audio(clip_path)
+    i16 = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2")
+    frames = [i16[i:i + 320].tobytes() for i in range(0, i16.shape[0], 320)]
+    out = {"clip": "client/30sec.flac as 20 ms int16 frames, large-v2, beam 3 (long-audio beam), S=96"}
+    try:
+        for inc in (True, False):
+            lat = []
+            for _ in range(4):
+                sess = StreamingSession("large", 5, models=models, fixed_new_tokens=96, incremental=inc)
+                for f in frames:
+                    sess.feed(f, 2)
+                t0 = time.perf_counter()
+                r = sess.stop()
+                lat.append(1e3 * (time.perf_counter() - t0))
+                assert len(r.tokens) == 96
+            out["stop_to_result_ms_incremental_front_end" if inc else "stop_to_result_ms_logmel_at_stop"] = round(p50(lat[1:]), 3)
+        t0 = time.perf_counter()
+        ref = do_whisper(pcm, "large", 5, models=models, fixed_new_tokens=96)
+        out["offline_do_whisper_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+        out["same_tokens_as_offline"] = bool(ref.tokens == r.tokens)
+        rng = np.random.default_rng(1234)
+        noise = (0.1 * rng.standard_normal(64 * 16000)).astype(np.float32)
+        sess = StreamingSession("large", 5, models=models, fixed_new_tokens=48, incremental=True)
+        t_feed = time.perf_counter()
+        for i in range(0, noise.shape[0], 320):
+            sess.feed(noise[i:i + 320])
+        t0 = time.perf_counter()
+        r = sess.stop()
+        out["noise_64s"] = {"feed_wall_ms (back to back, eager windows decode meanwhile)": round(1e3 * (t0 - t_feed), 1), "stop_to_result_ms": round(1e3 * (time.perf_counter() - t0), 3),
+                            "eager_windows": sess.eager_windows, "windows_from_incremental_front_end": sess.front_windows, "tokens": len(r.tokens)}
+    finally:
+        model.close()
+        model._replicas = []      # the handle belongs to the caller
+    return out
+
+
+def rest_base_beam1(dev, clip_bytes, audio_ms):
+    """BASELINE configs[0] shape on the GPU: Whisper base, beam 1, client/3sec.flac through the re-hosted REST endpoint, one request at a time."""
+    import asyncio
+    import httpx
+    from wis_hip.server import create_app
+    from wis_hip.settings import APISettings
+    from wis_hip.whisper import WhisperModels
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.max_batch, s.fixed_new_tokens = 8, FIXED_NEW["3sec"]
+    models = WhisperModels(s, device_index=[dev])
+    app = create_app(models=models)
+    b = "wisBenchBoundary"
+    body = (f"--{b}\r\nContent-Disposition: form-data; name=\"audio_file\"; filename=\"3sec.flac\"\r\nContent-Type: audio/flac\r\n\r\n").encode() + clip_bytes + f"\r\n--{b}--\r\n".encode()
+    hdr = {"content-type": f"multipart/form-data; boundary={b}"}
+    lat = []
+
+    async def go():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis", timeout=600) as c:
+            for i in range(23):
+                t = time.perf_counter()
+                r = await c.post("/api/asr?model=base&beam_size=1&detect_language=False", content=body, headers=hdr)
+                assert r.status_code == 200, r.text
+                if i >= 3:
+                    lat.append(1e3 * (time.perf_counter() - t))
+    asyncio.run(go())
+    models.get("base").close()
+    return {"config": "base beam 1, 3sec.flac over REST /api/asr, serial requests (configs[0] shape on the GPU; container decode + HTTP handling included)",
+            "p50_request_ms": round(p50(lat), 3), "x_realtime": round(audio_ms / p50(lat), 1)}
 
 
 def main():
@@ -211,7 +295,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     a = W.arch(args.model)
-    max_batch = max(args.batch, 8 if extras else 1)
+    max_batch = max(args.batch, 16 if extras else 1)
     t0 = time.perf_counter()
     weights = None
     if not use_dist:
@@ -371,7 +455,8 @@ def main():
         cfgs = []
         for name, clip, beam, Bc in (("large-v2 beam 5, 10sec.flac (configs[2], README row)", "10sec", 5, 1), ("large-v2 beam 5, 30sec.flac (S=96)", "30sec", 5, 1),
                                      ("large-v2 beam 3, 30sec.flac (the reference's long-audio beam, main.py:582-586)", "30sec", 3, 1),
-                                     ("large-v2 beam 5, 8 x 3sec.flac per device batch (configs[3] shape on one GPU)", "3sec", 5, 8)):
+                                     ("large-v2 beam 5, 8 x 3sec.flac per device batch (configs[3] shape on one GPU)", "3sec", 5, 8),
+                                     ("large-v2 beam 5, 12 x 3sec.flac per device batch", "3sec", 5, 12), ("large-v2 beam 5, 16 x 3sec.flac per device batch", "3sec", 5, 16)):
             try:
                 pc, ams, _p = clip_pcm(clip)
                 S = FIXED_NEW[clip]
@@ -400,11 +485,19 @@ def main():
             lib.wis_model_destroy(hm)
         except Exception as e:
             cfgs.append({"config": "medium beam 1, 3sec.flac (configs[1])", "failed": repr(e)})
+        try:
+            cfgs.append(rest_base_beam1(dev, open(clip_path, "rb").read(), audio_ms))
+        except Exception as e:
+            cfgs.append({"config": "base beam 1 over REST (configs[0] shape)", "failed": repr(e)})
         extra["other_baseline_configs"] = cfgs
         try:
             extra["rest_load"] = rest_load(handle, a, dev, args.rest_clients, 2, fixed_new, open(clip_path, "rb").read(), audio_ms)
         except Exception as e:
             extra["rest_load"] = {"failed": repr(e)}
+        try:
+            extra["streaming"] = streaming_bench(handle, a, dev, os.path.join(ROOT, "tests", "golden", "clips", "30sec.flac"))
+        except Exception as e:
+            extra["streaming"] = {"failed": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -445,3 +445,49 @@ def test_generate_refuses_concurrent_entry_on_one_handle(base, mels):
     print(f"concurrent entry refused {refused} times in 6 attempts")
     assert refused >= 1
     assert model._generate_chunk(r, x, [PROMPT], 4, 5, 224, 1.0, 1.0, True, True, 120, 0)[0].sequences_ids == want
+
+
+def test_sixteen_utterances_per_device_batch_vs_oracle(mels, lib):
+    """Device batches beyond 48 decoder rows (csrc/kernels.hpp MAX_ROWS = 96: 16 utterances x beam 5 = 80 rows, 5 row blocks of the
+    fragment-image skinny GEMM; the merged prompt pass has 64 rows): teacher-forced logits at 64 / 80 / 96 rows per pass and a
+    16-utterance beam-5 generate, every utterance against the oracle's answer for ITS features."""
+    import ctypes as C
+    from oracle.whisper_ref import WhisperRef
+    from wis_hip import _lib, ctranslate2 as ct2, weights as W
+    w = W.synthetic_weights("tiny", seed=1234, std=0.02, emb_std=0.06, ln_jitter=0.1)
+    a = W.arch("tiny")
+    model = ct2.Whisper("unused", weights=w, arch=a, max_batch=16, max_beam=5)
+    ref = WhisperRef(w, a["d_model"], a["n_layers"], a["n_heads"])
+    mem = ref.encode(mels)
+    rng = np.random.default_rng(9)
+    for B, R in ((4, 16), (5, 16), (6, 16)):          # 64, 80, 96 rows per pass
+        T = 16
+        m = np.ascontiguousarray(mels[[i % 2 for i in range(B)]])
+        dec_in = np.ascontiguousarray(np.concatenate([np.tile(np.array(PROMPT, np.int32), (B, 1)), rng.integers(0, 50000, size=(B, T - 4)).astype(np.int32)], axis=1))
+        out = np.zeros((B, T, a["n_vocab"]), np.float32)
+        _lib.check(lib.wis_debug_logits_rows(_handle(model), _lib.ptr(m), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T, R,
+                                             out.ctypes.data_as(C.POINTER(C.c_float))))
+        exp = ref.decode_logits(dec_in, mem[[i % 2 for i in range(B)]]).numpy()
+        e, mx = _relerr(out, exp), np.abs(out - exp).max()
+        print(f"logits at {B * R} rows per pass: rel-L2 {e:.3e}, max abs {mx:.3e}")
+        assert mx <= 5e-2 and e <= 5e-3
+    S = 10
+    order = [i % 2 for i in range(16)]
+    res = model.generate(ct2.StorageView.from_array(np.ascontiguousarray(mels[order])), [PROMPT] * 16, beam_size=5, fixed_new_tokens=S)
+    want = {}
+    for c in (0, 1):
+        ids, score, trace = ref.generate(None, PROMPT, beam_size=5, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN, fixed_new=S,
+                                         memory=mem[c].numpy(), return_trace=True)
+        want[c] = (ids, score, min(trace))
+    exact = 0
+    for i, r in enumerate(res):
+        ids, score, margin = want[order[i]]
+        got, gscore = r.sequences_ids[0], r.scores[0]
+        rescored = _oracle_rescore(ref, mem[order[i]].numpy(), got, S)
+        assert len(got) == S and abs(gscore - rescored) <= 3e-3 and rescored >= score - 1e-2, (i, gscore, rescored, score)
+        if margin > MARGIN:
+            assert got == ids, (i, got, ids)
+        exact += got == ids
+    print(f"16 utterances x beam 5: {exact} of 16 identical to the oracle (decision margins {want[0][2]:.4f} / {want[1][2]:.4f})")
+    assert exact >= 8
+    model.close()

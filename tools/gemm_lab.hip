@@ -432,7 +432,9 @@ static void launch_g(const P& p, hipStream_t st) {
 // one phase after when the read was retired before the reading phase's first barrier - N-lo, by the lgkmcnt(8) of phase 0).
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool STAGGER, bool PRIO>
+// EP: 0 = every lane stores its 4-column pieces (8 B) straight from the accumulators; 1 = no stores (ablation: what the epilogue costs);
+// 2 = the wave tile goes through LDS (XOR-swizzled [128][64] f16 image per wave) and leaves as 16-byte stores of whole 128-byte row segments
+template <bool STAGGER, bool PRIO, int EP>
 __global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
   constexpr int BM_ = 256, BN_ = 256, HALF = 128 * 64, BUF = 4 * HALF;
   __shared__ __attribute__((aligned(1024))) f16 smem[2 * BUF];
@@ -547,6 +549,36 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
 #undef WIS_STAGE
 #undef WIS_DMA
   // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
+  if (EP == 1) {
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) asm volatile("" :: "v"(acc[mb][nb][0]), "v"(acc[mb][nb][1]), "v"(acc[mb][nb][2]), "v"(acc[mb][nb][3]));
+    return;
+  }
+  if (EP == 2) {
+    // every wave has passed its last fragment read (the closing barriers), so the k-tile buffers are free: wave w takes 16 KiB
+    f16* reg = smem + wave * 8192;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int row = (mb >> 2) * 64 + (mb & 3) * 16 + l15;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int col = (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq;
+        const f16x4 o = {(f16)acc[mb][nb][0], (f16)acc[mb][nb][1], (f16)acc[mb][nb][2], (f16)acc[mb][nb][3]};
+        *reinterpret_cast<f16x4*>(reg + row * 64 + (((col >> 3) ^ ((row >> 1) & 7)) << 3) + (col & 7)) = o;
+      }
+    }
+    // (the same wave reads what it wrote: LDS operations of a wave complete in order)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 8 + (lane >> 3), ch = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+      const int m = m0 + wr * 128 + row;
+      if (m < p.M) *reinterpret_cast<uint4*>(p.C + (size_t)m * p.N + n0 + wc * 64 + ch * 8) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {
     const int m = m0 + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
@@ -560,10 +592,10 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
     }
   }
 }
-template <bool STAGGER, bool PRIO>
+template <bool STAGGER, bool PRIO, int EP = 0>
 static void launch_8p(const P& p, hipStream_t st) {
   const int nwg = ((p.M + 255) / 256) * (p.N / 256);
-  hipLaunchKernelGGL((gemm_8p_kernel<STAGGER, PRIO>), dim3(nwg), dim3(512), 0, st, p);
+  hipLaunchKernelGGL((gemm_8p_kernel<STAGGER, PRIO, EP>), dim3(nwg), dim3(512), 0, st, p);
 }
 
 struct Shape { const char* name; int N, K; };
@@ -645,6 +677,8 @@ int main(int argc, char** argv) {
     {"256x256 8p ", launch_8p<true, true>, nullptr, 256, 256},
     {"256x256 8p-nostagger", launch_8p<false, true>, nullptr, 256, 256},
     {"256x256 8p-noprio", launch_8p<true, false>, nullptr, 256, 256},
+    {"256x256 8p-nostore (ablation: wrong)", launch_8p<true, true, 1>, nullptr, 256, 256},
+    {"256x256 8p-ldsep", launch_8p<true, true, 2>, nullptr, 256, 256},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
   const bool stamps = argc > 2 ? atoi(argv[2]) != 0 : true;

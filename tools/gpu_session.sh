@@ -5,7 +5,7 @@
 #   lab [M ...]     tools/bin/gemm_lab at the given row counts (default 1500 3000 12000), stamps off, weights from HBM
 #   tests <expr>    pytest -m gpu -k <expr> (quote the expression); "tests all" = the whole GPU suite
 #   smoke           __graft_entry__.smoke()
-#   bench1 / bench8 [ENV=VAL ...]   bench.py at 1 / 8 utterances per device batch (no extras, no CPU baseline); extra words are
+#   bench<N> [ENV=VAL ...]   bench.py at N utterances per device batch (no extras, no CPU baseline); extra words are
 #                   environment assignments for that run and become part of the output name
 #   benchfull       the default bench.py line (what the driver runs)
 #   prof1 / prof8   rocprofv3 --kernel-trace --stats of the eager bench at 1 / 8 utterances -> kernel_stats_b*.txt (+ by-grid table)
@@ -39,7 +39,7 @@ while [ $# -gt 0 ]; do
       if [ "$expr" = all ]; then timeout 1500 python -m pytest tests -q -x -m gpu > "$O/tests_all.log" 2>&1; echo "rc=$?" >> "$O/tests_all.log"; tail -5 "$O/tests_all.log"
       else timeout 1500 python -m pytest tests -q -x -m gpu -k "$expr" -s > "$O/tests_sel.log" 2>&1; echo "rc=$?" >> "$O/tests_sel.log"; grep -v "^$" "$O/tests_sel.log" | tail -60; fi ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; tail -2 "$O/smoke.log" ;;
-    bench1|bench8)
+    bench[0-9]*)
       B=${step#bench}; envs=(); while [ $# -gt 0 ] && [[ $1 == *=* ]]; do envs+=("$1"); shift; done
       run_bench "$B" "${envs[@]}" ;;
     benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; tail -c 600 "$O/bench_default.json" ;;

@@ -2,7 +2,7 @@
 // (the reference runs these inside ctranslate2 Whisper.generate,
 // call site reference main.py:687-693, semantics SURVEY §3.4 + Appendix C).
 //
-// A decode step has M = B*beam <= 48 rows: every projection is a weight-streaming, HBM-bound
+// A decode step has M = B*beam <= 96 rows: every projection is a weight-streaming, HBM-bound
 // skinny GEMM.  MI355X mapping:
 //  * weights are re-packed once at load into MFMA A-fragment order ([N/16][K/32][64 lanes][8 f16])
 //    so every wave-level load is ONE fully coalesced 1 KiB global_load_dwordx4 that feeds
@@ -514,7 +514,7 @@ int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
 }
 
 int launch_gemv(hipStream_t st, const GemvP& p) {
-  if (p.M < 1 || p.M > MAX_ROWS || p.K % 128 || p.N % 4) { set_error("gemv: M=%d N=%d K=%d unsupported", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
+  if (p.M < 1 || p.M > 48 || p.K % 128 || p.N % 4) { set_error("gemv: M=%d N=%d K=%d unsupported (the LDS-staged form holds <= 48 rows; more rows take launch_gemv_frag)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
   const int MB = cdiv(p.M, 16);
   // largest K-chunk (multiple of 128 dividing K) whose f16 image of M rows fits the LDS: 64 KiB for <= 16 rows (several
   // workgroups per CU), the whole 160 KiB CU array (minus slack) for the batched-decode row counts
@@ -575,7 +575,7 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 }
 
 // =======================================================================================
-// Batched decode rows (8 < M <= 48): skinny GEMM on activation FRAGMENT images.  grid = Npad/16 workgroups of 4 waves; wave w owns
+// Batched decode rows (8 < M <= 96): skinny GEMM on activation FRAGMENT images.  grid = Npad/16 workgroups of 4 waves; wave w owns
 // the k-steps [w*S, (w+1)*S), S = K/128.  Per k-step a wave issues ONE 1 KiB weight fragment load (HBM, non-temporal) and MB
 // 1 KiB activation fragment loads (L2: the image is 40-120 KiB and every workgroup reads it), PF k-steps ahead of the MFMAs -
 // no LDS staging of the activations, no staging barrier, 12 KiB of LDS (the cross-wave reduction) so several workgroups share a CU
@@ -587,6 +587,7 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 template <int MB, int PF, bool W8>
 __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   typedef typename WFrag<W8>::T WT;
+  constexpr int EPN = (MB + 3) / 4;      // row blocks a wave finishes in the epilogue: wave w owns blocks w, w + 4 (up to 96 rows = 6 blocks)
   __shared__ __attribute__((aligned(16))) float red[4 * MB * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockIdx.x;
   const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps >> 2;
@@ -621,114 +622,125 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
     }
   }
   // epilogue operands: requested behind the whole stream, covered by the reduction barrier
-  const int ep_mb = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-  const bool ep_act = tid < MB * 64;
-  const int ep_m = ep_mb * 16 + l15, ep_n = 16 * nt + 4 * kq;
-  const bool ep_ok = ep_act && ep_m < M && ep_n < p.N;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ep_n = 16 * nt + 4 * kq;
   const bool ln = p.flags & GV_LN;
-  float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
-  int ep_slot = 0, ep_pos = 0;
+  const int nq = K >> 6;                                      // (K/16) partial pairs per row, a quarter per lane
   // LayerNorm statistics from the row's per-16-column partials (sum, M2 about the tile's own mean - see the residual epilogue
   // below): pairs merge like Welford / Chan states, so a row whose mean is large against its spread loses nothing to the
   // E[x^2] - mu^2 cancellation (the <= 8-row kernel shifts by x[r][0] for the same reason).  K = 1280 keeps the lane's 20 pairs
-  // in registers between the two passes; other widths re-read them (L1 hits).
-  constexpr int NQR = PF == 10 ? 20 : 1;
+  // in registers between the two passes; other widths and the > 64-row forms re-read them (L1 hits).
+  constexpr bool SREG = PF == 10 && EPN == 1;
+  constexpr int NQR = SREG ? 20 : 1;
   float2 spr[NQR];
-  float s1 = 0.f, s2 = 0.f;
-  const int nq = K >> 6;                                      // (K/16) partial pairs per row, a quarter per lane
-  const float2* sp = nullptr;
-  if (ep_act) {
-    const int mm = ep_m < M ? ep_m : M - 1;
-    if (ln) {       // this lane sums a quarter of the row's partials (rows >= M: a clamped duplicate, discarded)
-      sp = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4) + (size_t)kq * nq;
-      if (PF == 10) {
+  bool ep_act[EPN], ep_ok[EPN]; int ep_m[EPN];
+  float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 ep_res[EPN]; int ep_slot[EPN], ep_pos[EPN]; float s1[EPN]; const float2* sp[EPN];
+  if (ep_n < p.N) {
+    if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
+    if (ln) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);
+    if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);
+  }
 #pragma unroll
-        for (int i = 0; i < NQR; ++i) { spr[i] = sp[i]; s1 += spr[i].x; }
-      } else {
+  for (int e = 0; e < EPN; ++e) {
+    const int mb = wave + 4 * e;
+    ep_act[e] = mb < MB; ep_m[e] = mb * 16 + l15; ep_ok[e] = ep_act[e] && ep_m[e] < M && ep_n < p.N;
+    ep_res[e] = make_float4(0.f, 0.f, 0.f, 0.f); ep_slot[e] = 0; ep_pos[e] = 0; s1[e] = 0.f; sp[e] = nullptr;
+    if (ep_act[e]) {
+      const int mm = ep_m[e] < M ? ep_m[e] : M - 1;
+      if (ln) {       // this lane sums a quarter of the row's partials (rows >= M: a clamped duplicate, discarded)
+        sp[e] = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4) + (size_t)kq * nq;
+        if (SREG) {
+#pragma unroll
+          for (int i = 0; i < NQR; ++i) { spr[i] = sp[e][i]; s1[e] += spr[i].x; }
+        } else {
 #pragma unroll 4
-        for (int i = 0; i < nq; ++i) s1 += sp[i].x;
+          for (int i = 0; i < nq; ++i) s1[e] += sp[e][i].x;
+        }
       }
-    }
-    if (ep_ok) {
-      if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
-      if (ln) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);
-      if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);
-      if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }
-      else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n);
+      if (ep_ok[e]) {
+        if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot[e] = p.slot[ep_m[e]]; ep_pos[e] = p.pos[ep_m[e]]; } }
+        else if (p.flags & GV_RESID) ep_res[e] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m[e] * p.N + ep_n);
+      }
     }
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
     *reinterpret_cast<float4*>(red + ((size_t)(wave * MB + mb) * 64 + lane) * 4) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
-  if (!ep_act) return;                                        // whole waves: MB * 64 is a multiple of the wave size
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + ep_mb) * 64 + lane) * 4);
-    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-  }
-  if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
-  if (ln) {     // the four lanes of a row (kq = 0..3) hold a quarter of its sums each: ((q0 + q1) + (q2 + q3)) on every lane
-    s1 += __shfl_xor(s1, 16);
-    s1 += __shfl_xor(s1, 32);
-    const float invK = 1.0f / (float)K;
-    const float mu = s1 * invK;
-    // second pass over the partials: M2 = sum_tiles ( M2_tile + 16 (mean_tile - mu)^2 )
-    if (PF == 10) {
+  for (int e = 0; e < EPN; ++e) {
+    if (!ep_act[e]) continue;                                   // whole waves: a row block belongs to one wave
+    const int ep_mb = wave + 4 * e;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < NQR; ++i) { const float dm = spr[i].x * 0.0625f - mu; s2 += spr[i].y + 16.0f * dm * dm; }
-    } else {
-#pragma unroll 4
-      for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; const float dm = v.x * 0.0625f - mu; s2 += v.y + 16.0f * dm * dm; }
+    for (int w = 0; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + ep_mb) * 64 + lane) * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    s2 += __shfl_xor(s2, 16);
-    s2 += __shfl_xor(s2, 32);
-    const float rs = 1.0f / sqrtf(s2 * invK + 1e-5f);
-    s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
-  }
-  s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
-  const int m = ep_m, n = ep_n;
-  if (p.flags & GV_QKV) {
-    if (ep_ok) {
-      const int d = p.d;
-      if (n < d) {
-        *reinterpret_cast<float4*>(p.q + (size_t)m * d + n) = s;
-      } else {
-        const bool isk = n < 2 * d;
-        f16* dst = (isk ? p.kc : p.vc) + ((size_t)ep_slot * p.ctx + ep_pos) * d + (n - (isk ? d : 2 * d));
-        const f16x4 o = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
-        *reinterpret_cast<f16x4*>(dst) = o;
-      }
-    }
-    return;
-  }
-  if (p.flags & GV_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
-  if (p.flags & GV_RESID) {
-    const float4 r = make_float4(ep_res.x + s.x, ep_res.y + s.y, ep_res.z + s.z, ep_res.w + s.w);
-    float t1 = 0.f, t2 = 0.f;
-    if (ep_ok) {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = r;
-      if (p.y_xf) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y_xf + xf_index(m, n, p.ymb)) = h; }
-      t1 = (r.x + r.y) + (r.z + r.w);
-    }
-    if (p.stat_out) {      // partials of this workgroup's 16 columns of row m: (sum, M2 about the tile mean); all four kq lanes take part in the shuffles
+    if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
+    if (ln) {     // the four lanes of a row (kq = 0..3) hold a quarter of its sums each: ((q0 + q1) + (q2 + q3)) on every lane
+      float t1 = s1[e];
       t1 += __shfl_xor(t1, 16);
       t1 += __shfl_xor(t1, 32);
-      if (ep_ok) { const float ml = t1 * 0.0625f, a = r.x - ml, b = r.y - ml, c = r.z - ml, e = r.w - ml; t2 = (a * a + b * b) + (c * c + e * e); }
-      t2 += __shfl_xor(t2, 16);
-      t2 += __shfl_xor(t2, 32);
-      if (kq == 0 && ep_m < M && 16 * nt < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt) * 2) = make_float2(t1, t2);
+      const float invK = 1.0f / (float)K;
+      const float mu = t1 * invK;
+      float s2 = 0.f;      // second pass over the partials: M2 = sum_tiles ( M2_tile + 16 (mean_tile - mu)^2 )
+      if (SREG) {
+#pragma unroll
+        for (int i = 0; i < NQR; ++i) { const float dm = spr[i].x * 0.0625f - mu; s2 += spr[i].y + 16.0f * dm * dm; }
+      } else {
+#pragma unroll 4
+        for (int i = 0; i < nq; ++i) { const float2 v = sp[e][i]; const float dm = v.x * 0.0625f - mu; s2 += v.y + 16.0f * dm * dm; }
+      }
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      const float rs = 1.0f / sqrtf(s2 * invK + 1e-5f);
+      s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
     }
-    return;
-  }
-  if (!ep_ok) return;
-  if (p.flags & GV_OUT_F32) {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = s;
-  } else {
-    const f16x4 h = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
-    f16* yo = reinterpret_cast<f16*>(p.y);
-    *reinterpret_cast<f16x4*>(yo + (p.ymb ? xf_index(m, n, p.ymb) : (size_t)m * p.N + n)) = h;
+    s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
+    const int m = ep_m[e], n = ep_n;
+    if (p.flags & GV_QKV) {
+      if (ep_ok[e]) {
+        const int d = p.d;
+        if (n < d) {
+          *reinterpret_cast<float4*>(p.q + (size_t)m * d + n) = s;
+        } else {
+          const bool isk = n < 2 * d;
+          f16* dst = (isk ? p.kc : p.vc) + ((size_t)ep_slot[e] * p.ctx + ep_pos[e]) * d + (n - (isk ? d : 2 * d));
+          const f16x4 o = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
+          *reinterpret_cast<f16x4*>(dst) = o;
+        }
+      }
+      continue;
+    }
+    if (p.flags & GV_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
+    if (p.flags & GV_RESID) {
+      const float4 r = make_float4(ep_res[e].x + s.x, ep_res[e].y + s.y, ep_res[e].z + s.z, ep_res[e].w + s.w);
+      float t1 = 0.f, t2 = 0.f;
+      if (ep_ok[e]) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = r;
+        if (p.y_xf) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y_xf + xf_index(m, n, p.ymb)) = h; }
+        t1 = (r.x + r.y) + (r.z + r.w);
+      }
+      if (p.stat_out) {      // partials of this workgroup's 16 columns of row m: (sum, M2 about the tile mean); all four kq lanes take part in the shuffles
+        t1 += __shfl_xor(t1, 16);
+        t1 += __shfl_xor(t1, 32);
+        if (ep_ok[e]) { const float ml = t1 * 0.0625f, a_ = r.x - ml, b_ = r.y - ml, c_ = r.z - ml, e_ = r.w - ml; t2 = (a_ * a_ + b_ * b_) + (c_ * c_ + e_ * e_); }
+        t2 += __shfl_xor(t2, 16);
+        t2 += __shfl_xor(t2, 32);
+        if (kq == 0 && m < M && 16 * nt < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt) * 2) = make_float2(t1, t2);
+      }
+      continue;
+    }
+    if (!ep_ok[e]) continue;
+    if (p.flags & GV_OUT_F32) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = s;
+    } else {
+      const f16x4 h = {(f16)s.x, (f16)s.y, (f16)s.z, (f16)s.w};
+      f16* yo = reinterpret_cast<f16*>(p.y);
+      *reinterpret_cast<f16x4*>(yo + (p.ymb ? xf_index(m, n, p.ymb) : (size_t)m * p.N + n)) = h;
+    }
   }
 }
 
@@ -739,10 +751,20 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   const int npad = cdiv(p.N, 16) * 16;
   dim3 grid(npad / 16), block(256);
   const bool s10 = p.K == 1280;          // ten k-steps per wave: the whole stream of a wave is requested up front
-#define WIS_GF(MBv) do { \
-    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, 10, true>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, 8, true>), grid, block, 0, st, p); } \
-    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, 10, false>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, 8, false>), grid, block, 0, st, p); } } while (0)
-  if (p.xmb == 1) WIS_GF(1); else if (p.xmb == 2) WIS_GF(2); else WIS_GF(3);
+  // up to three row blocks: the whole wave stream (ten k-steps) or eight k-steps in flight; four to six row blocks (49-96 rows):
+  // a six-deep ring, so that weight + activation fragments stay inside the register file ((MB + 1) x 4 VGPRs per k-step)
+#define WIS_GF(MBv, PFA, PFB) do { \
+    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, true>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, true>), grid, block, 0, st, p); } \
+    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, false>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, false>), grid, block, 0, st, p); } } while (0)
+  switch (p.xmb) {
+    case 1: WIS_GF(1, 10, 8); break;
+    case 2: WIS_GF(2, 10, 8); break;
+    case 3: WIS_GF(3, 10, 8); break;
+    case 4: WIS_GF(4, 6, 6); break;
+    case 5: WIS_GF(5, 6, 6); break;
+    case 6: WIS_GF(6, 6, 6); break;
+    default: set_error("gemv_frag: %d row blocks unsupported", p.xmb); return WIS_E_UNSUPPORTED;
+  }
 #undef WIS_GF
   return WIS_OK;
 }
@@ -944,11 +966,29 @@ constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16
 // workgroups of an 8-utterance batch ran in two rounds; with CM = 6 it needs 88 (five per CU).
 // FOLD: the folded-query prologue (B = 1-sized row counts only; its own instantiation so that the batched kernel keeps its
 // register budget).
-template <int TPW, int CM, bool FOLD>
+// SPIN (small grids: B * H <= 128, <= 6 chunks, <= 8 rows): the chunk partials travel as 8-byte {tag, value} GRANULES, one write-through
+// store each (guide G16 form R2: "the data is the flag") - a producing workgroup stores and leaves: no drain, no barrier, no ticket.
+// The workgroup of the LAST chunk of every (utterance, head) is its combiner: it keeps its own partial in LDS and re-reads the other
+// chunks' granules (relaxed agent-scope loads) until every tag equals this launch's epoch, then combines in the fixed chunk order
+// (the same arithmetic, in the same order, as the ticket form: bit-identical results).  The epoch of an (utterance, head) is a word
+// in device memory that its combiner advances at the end of the launch (launches on a stream are ordered, so the next launch
+// reads the new value; tags only grow, so a slot's old contents can never match) - nothing is reset between launches, and graph
+// replays stay valid.  Progress: producers never wait; at most B * H <= 128 workgroups spin, fewer than the chip's 256 CUs, so a
+// producer always finds a slot.  The spin is bounded: on exhaustion the combiner raises a flag (checked by wis_generate) instead of
+// hanging.  What it removes from the hand-off: the store drain, the returning ticket atomic and the agent-scope acquire (1.7 us).
+typedef unsigned long long gran_t;
+__device__ __forceinline__ void st_gran(gran_t* p, unsigned tag, float v) {
+  __hip_atomic_store(p, ((gran_t)tag << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ gran_t ld_gran(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned CA_SPIN_LIMIT = 1u << 17;      // sweeps before the combiner gives up (~0.1 s)
+
+template <int TPW, int CM, bool FOLD, bool SPIN>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
                                                              int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb,
-                                                             const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb) {
+                                                             const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb,
+                                                             gran_t* gran, unsigned* epoch) {
   __shared__ float ssc[16][257];
   __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
   __shared__ float smax[16][16];
@@ -967,6 +1007,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   const float* qp = q + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
   const float4 qa0_ = *reinterpret_cast<const float4*>(qp), qa1_ = *reinterpret_cast<const float4*>(qp + 4);
   const float4 qb0_ = *reinterpret_cast<const float4*>(qp + 32), qb1_ = *reinterpret_cast<const float4*>(qp + 36);
+  unsigned ep_now = 0;
+  if (SPIN) ep_now = __hip_atomic_load(epoch + 1 + b * H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // requested with everything else (word 0 is the flag)
   // Folded query (model.hip fused_out_cq): `q` holds q_raw = W'x0 + (W'Wo) a + W'bo of the LayerNorm-folded cross-attention query
   // projection, computed one stage early from the layer input and the self-attention output; the LayerNorm statistics belong
   // to the rows the out-projection has produced SINCE (xres = x1, fp32 [B*R][d]).  Every workgroup reduces its utterance's R
@@ -1104,6 +1146,73 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     }
     return;
   }
+  if (SPIN) {
+    const unsigned tag = ep_now + 1u;
+    gran_t* gbase = gran + ((size_t)(b * H + h) * C) * R * 66;
+    if (c != C - 1) {      // producer: one granule per value, no drain, no ticket
+      if (l15 < R) {
+        gran_t* gp = gbase + ((size_t)c * R + l15) * 66;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) st_gran(gp + dh0 + r4, tag, oacc[r4]);
+        if (wave == 0 && kq == 0) { st_gran(gp + 64, tag, smx[l15]); st_gran(gp + 65, tag, ssum[l15]); }
+      }
+      stamp(pf, 5);
+      if (tid == 0) tl_end(prof);
+      return;
+    }
+    // combiner: own partial through LDS (the score buffer is free), the other chunks' from their granules
+    if (l15 < R) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) ssc[l15][dh0 + r4] = oacc[r4];
+      if (wave == 0 && kq == 0) { ssc[l15][64] = smx[l15]; ssc[l15][65] = ssum[l15]; }
+    }
+    __syncthreads();
+    stamp(pf, 5);
+    for (int item = tid; item < R * 32; item += 256) {
+      const int r = item >> 5, dp = item & 31;
+      float2 ml[CM], ov[CM];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int cc = 0; cc < CM - 1; ++cc) {
+          if (cc < C - 1) {
+            const gran_t* gp = gbase + ((size_t)cc * R + r) * 66;
+            const gran_t g0 = ld_gran(gp + 64), g1 = ld_gran(gp + 65), g2 = ld_gran(gp + 2 * dp), g3 = ld_gran(gp + 2 * dp + 1);
+            ok = ok & ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag) & ((unsigned)(g2 >> 32) == tag) & ((unsigned)(g3 >> 32) == tag);
+            ml[cc] = make_float2(__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1));
+            ov[cc] = make_float2(__uint_as_float((unsigned)g2), __uint_as_float((unsigned)g3));
+          }
+        }
+        if (ok) break;
+        if (++spins > CA_SPIN_LIMIT) { atomicOr(epoch, 1u); break; }      // word 0: the give-up flag
+        __builtin_amdgcn_s_sleep(1);
+      }
+      float M_ = ssc[r][64];
+#pragma unroll
+      for (int cc = 0; cc < CM - 1; ++cc) if (cc < C - 1) M_ = fmaxf(M_, ml[cc].x);
+      float L = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < CM - 1; ++cc) {
+        if (cc < C - 1) {
+          const float w = __expf(ml[cc].x - M_);
+          L = fmaf(ml[cc].y, w, L); O0 = fmaf(ov[cc].x, w, O0); O1 = fmaf(ov[cc].y, w, O1);
+        }
+      }
+      {      // own chunk last: the fixed chunk order 0 .. C-1 of the ticket form
+        const float w = __expf(ssc[r][64] - M_);
+        L = fmaf(ssc[r][65], w, L); O0 = fmaf(ssc[r][2 * dp], w, O0); O1 = fmaf(ssc[r][2 * dp + 1], w, O1);
+      }
+      const float inv = 1.0f / L;
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      const f16x2 o2 = {(f16)(O0 * inv), (f16)(O1 * inv)};
+      *reinterpret_cast<f16x2*>(out + (out_mb ? xf_index(b * R + r, h * 64 + 2 * dp, out_mb) : (size_t)(b * R + r) * d + h * 64 + 2 * dp)) = o2;
+    }
+    if (tid == 0) __hip_atomic_store(epoch + 1 + b * H + h, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // next launch's epoch
+    stamp(pf, 7);
+    if (tid == 0) tl_end(prof);
+    return;
+  }
   // ---- split-T: publish the partial with write-through stores; the last-arriving workgroup combines
   float* pbase = part + ((size_t)(b * H + h) * C) * R * 66;
   if (l15 < R) {
@@ -1166,16 +1275,20 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
-                          const float* xres, const float* qcs, const float* qb) {
+                          const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch) {
   if (xres && (!qcs || !qb || R > 8 || d > 1280)) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
-#define WIS_CA(TPWv, CMv, FOLDv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, \
-                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb)
-  if (xres) { if (CL <= 128) WIS_CA(2, 16, true); else if (used <= 6) WIS_CA(4, 6, true); else WIS_CA(4, 16, true); }
-  else { if (CL <= 128) WIS_CA(2, 16, false); else if (used <= 6) WIS_CA(4, 6, false); else WIS_CA(4, 16, false); }
+  static const int env_spin = getenv("WIS_CA_SPIN") ? atoi(getenv("WIS_CA_SPIN")) : 1;      // 0: always the ticket form (A/B switch)
+  // granule hand-off: small grids only (fewer spinning combiners than CUs), the default 256-key chunking, <= 8 rows per utterance
+  const bool spin = env_spin && gran && epoch && B * H <= CA_SPIN_MAX_BH && CL == 256 && used >= 2 && used <= 6 && R <= 8;
+#define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, \
+                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb, gran, epoch)
+  if (spin) { if (xres) WIS_CA(4, 6, true, true); else WIS_CA(4, 6, false, true); }
+  else if (xres) { if (CL <= 128) WIS_CA(2, 16, true, false); else if (used <= 6) WIS_CA(4, 6, true, false); else WIS_CA(4, 16, true, false); }
+  else { if (CL <= 128) WIS_CA(2, 16, false, false); else if (used <= 6) WIS_CA(4, 6, false, false); else WIS_CA(4, 16, false, false); }
 #undef WIS_CA
   return WIS_OK;
 }

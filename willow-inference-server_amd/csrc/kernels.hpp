@@ -32,7 +32,7 @@ int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out,
 size_t enc_attention_part_floats(int B, int T, int H);
 
 // ---- decoder ---------------------------------------------------------------------------
-constexpr int MAX_ROWS = 48;      // decoder rows per pass: B*beam (decode) or B*P (merged prefill + first step); wis_hip/ctranslate2.py MAX_DECODER_ROWS
+constexpr int MAX_ROWS = 96;      // decoder rows per pass: B*beam (decode) or B*P (merged prefill + first step): 16 utterances x beam 5 + slack; wis_hip/ctranslate2.py MAX_DECODER_ROWS
 constexpr int MAX_R = 8;          // rows per utterance (beam or prompt prefix length)
 constexpr int MAX_CAND = 2 * MAX_R;
 
@@ -69,7 +69,7 @@ struct GemvP {
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
 int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // two f16-activation skinny GEMMs in one launch
-// Batched decode rows (8 < M <= 48).  The skinny GEMM reads its activations as ready-made MFMA B fragments straight from L2
+// Batched decode rows (8 < M <= 96).  The skinny GEMM reads its activations as ready-made MFMA B fragments straight from L2
 // (written in that order by the producing kernel: no per-workgroup LDS staging, no staging barrier, many workgroups per CU), and
 // the pre-LN LayerNorm needs no launch of its own: every residual epilogue leaves per-16-column partial sums of the rows it
 // produced, the folded projection that follows (W o gamma, b + W.beta, column sums) turns them into mean / rstd in its epilogue.
@@ -97,9 +97,13 @@ int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f1
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr, int out_mb = 0);
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
+// gran / epoch (optional): the granule hand-off of small grids (dec_kernels.hip, SPIN): gran = 8-byte slots [B*H][6][8][66], epoch =
+// ONE flag word (non-zero: a combiner's bounded spin ran out) followed by [B*H] monotonic epoch words, all zero-initialised once
+constexpr int CA_SPIN_MAX_BH = 128;
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0,
-                          const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr);   // folded query: see the kernel
+                          const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr,   // folded query: see the kernel
+                          unsigned long long* gran = nullptr, unsigned* epoch = nullptr);
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

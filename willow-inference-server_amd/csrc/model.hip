@@ -141,6 +141,7 @@ struct wis_model {
   size_t kx_lstride = 0, vx_lstride = 0;
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
+  unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
   f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
@@ -452,6 +453,13 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * 66));
   WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
   WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bm * H * 4, m->st));
+  {
+    const int bh = Bm * H < CA_SPIN_MAX_BH ? Bm * H : CA_SPIN_MAX_BH;
+    WIS_RET(dalloc(m, &m->ca_gran, (size_t)bh * 6 * 8 * 66));
+    WIS_RET(dalloc(m, &m->ca_epoch, (size_t)bh + 1));
+    WIS_HIP_CHECK(hipMemsetAsync(m->ca_gran, 0, (size_t)bh * 6 * 8 * 66 * 8, m->st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->ca_epoch, 0, ((size_t)bh + 1) * 4, m->st));
+  }
   WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
   WIS_RET(dalloc(m, &m->rm.slot, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.lslot, MAX_ROWS));
   const int max_new = 256, max_hyp = 2 * MAX_R;
@@ -586,7 +594,8 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     g = base(m->dxf, w.p_cq, w.s_cq, w.b_cq, d, d, GV_LN | GV_OUT_F32);
     g.csum = w.c_cq; g.stat_in = m->dstat; g.y = m->dq;
     WIS_RET(launch_gemv_frag(st, g));
-    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, nullptr, nullptr, nullptr,
+                                  m->ca_gran, m->ca_epoch));
     g = base(m->daoxf, w.p_cout, w.s_cout, w.b_cout, d, d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
     WIS_RET(launch_gemv_frag(st, g));
@@ -637,7 +646,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
       gb.x = m->dxh; gb.x2 = m->dao; gb.xsplit = d; gb.Wp = w.p_cqo; gb.bias = w.b_cqo; gb.y = m->dq; gb.M = M; gb.N = d; gb.K = 2 * d; gb.flags = GV_OUT_F32;
       WIS_RET(launch_gemv_dual(st, ga, gb));
       WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
-                                    m->dx, w.c_cq, w.b_cq));
+                                    m->dx, w.c_cq, w.b_cq, m->ca_gran, m->ca_epoch));
     } else {
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.wscale = w.s_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
@@ -648,7 +657,8 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.x = m->dx; g.csum = w.c_cq; g.Wp = w.p_cq; g.wscale = w.s_cq; g.bias = w.b_cq; g.y = m->dq; g.M = M; g.N = d; g.K = d; g.flags = GV_LN | GV_OUT_F32; g.prof = pr ? pr + 48 : nullptr;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
-    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr));
+    WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0, nullptr, nullptr, nullptr,
+                                  m->ca_gran, m->ca_epoch));
     }
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
@@ -876,7 +886,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   int sync_every = o->sync_every > 0 ? o->sync_every : 4;
   int steps = 1;            // the first step ran with the prefill pass
   int* h_done = m->h_pin;   // pinned
-  *h_done = 0;
+  h_done[0] = 0; h_done[1] = 0;
   // with the measurement convention the step count is known: fixed_new tokens + the forced EOT
   const int known = (sc.fixed_new > 0) ? std::min(max_new, sc.fixed_new + 1) : 0;
   const int limit = known ? known : max_new;
@@ -889,10 +899,13 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
       steps += burst;
     }
     WIS_HIP_CHECK(hipMemcpyAsync(h_done, m->bs.all_done, 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipMemcpyAsync(h_done + 1, m->ca_epoch, 4, hipMemcpyDeviceToHost, st));      // (word 0 of the epoch block: the hand-off's give-up flag)
     WIS_HIP_CHECK(hipStreamSynchronize(st));
     if (*h_done >= B || steps >= limit) break;
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
+  // the granule hand-off's give-up flag (a combiner's bounded spin ran out: never expected; results would be garbage)
+  if (h_done[1]) { hipMemsetAsync(m->ca_epoch, 0, 4, st); set_error("decoder cross-attention hand-off timed out (granule sweep exhausted)"); return WIS_E_HIP; }
   if (*h_done < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, *h_done, B); return WIS_E_STATE; }
   // results
   std::vector<int32_t> ids((size_t)B * 256);
@@ -1281,18 +1294,26 @@ int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void
   std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
   if (!q || !kx || !vt || !out || B < 1 || H < 1 || T < 1) { set_error("wis_op_dec_cross_attn: bad argument"); return WIS_E_ARG; }
   hipStream_t st = ctx_stream(c);
-  float* part = nullptr; unsigned* counters = nullptr;
+  float* part = nullptr; unsigned* counters = nullptr; unsigned long long* gran = nullptr; unsigned* epoch = nullptr;
   int rc = WIS_OK;
+  const bool small = B * H <= CA_SPIN_MAX_BH;      // the product's rule: the granule hand-off on small grids (launch_dec_cross_attn decides by chunking / rows)
   if (hipMalloc(reinterpret_cast<void**>(&part), (size_t)B * H * 16 * 16 * 66 * 4) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&counters), (size_t)B * H * 4) != hipSuccess) { set_error("wis_op_dec_cross_attn: out of device memory"); rc = WIS_E_NOMEM; }
+      hipMalloc(reinterpret_cast<void**>(&counters), (size_t)B * H * 4) != hipSuccess ||
+      (small && (hipMalloc(reinterpret_cast<void**>(&gran), (size_t)B * H * 6 * 8 * 66 * 8) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&epoch), ((size_t)B * H + 1) * 4) != hipSuccess))) {
+    set_error("wis_op_dec_cross_attn: out of device memory"); rc = WIS_E_NOMEM; }
+  unsigned flag = 0;
   if (!rc) {
     hipMemsetAsync(counters, 0, (size_t)B * H * 4, st);
-    rc = launch_dec_cross_attn(st, q, reinterpret_cast<const f16*>(kx), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), part, counters,
-                               B, R, H, 64 * H, T, cdiv(T, 64) * 64, chunks);
+    if (small) { hipMemsetAsync(gran, 0, (size_t)B * H * 6 * 8 * 66 * 8, st); hipMemsetAsync(epoch, 0, ((size_t)B * H + 1) * 4, st); }
+    for (int rep = 0; rep < 3 && !rc; ++rep)      // three launches: the epochs of the granule form advance from launch to launch
+      rc = launch_dec_cross_attn(st, q, reinterpret_cast<const f16*>(kx), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), part, counters,
+                                 B, R, H, 64 * H, T, cdiv(T, 64) * 64, chunks, nullptr, 0, nullptr, nullptr, nullptr, gran, epoch);
+    if (small && !rc) hipMemcpyAsync(&flag, epoch, 4, hipMemcpyDeviceToHost, st);
   }
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(part); hipFree(counters);
+  hipFree(part); hipFree(counters); hipFree(gran); hipFree(epoch);
   if (rc) return rc;
+  if (flag) { set_error("wis_op_dec_cross_attn: granule hand-off timed out"); return WIS_E_HIP; }
   if (e != hipSuccess) { set_error("wis_op_dec_cross_attn: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;
 }

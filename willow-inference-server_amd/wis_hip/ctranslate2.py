@@ -170,7 +170,7 @@ def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_bl
 
 
 
-MAX_DECODER_ROWS = 48      # csrc/kernels.hpp MAX_ROWS: decoder rows per device pass
+MAX_DECODER_ROWS = 96      # csrc/kernels.hpp MAX_ROWS: decoder rows per device pass
 MAX_BEAM = 8               # csrc/kernels.hpp MAX_R: rows per utterance (beam size)
 MAX_PROMPT = 16            # wis_generate: prompt tokens per utterance
 
