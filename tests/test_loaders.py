@@ -175,10 +175,11 @@ def test_settings_default_is_the_reference_layout_and_fails_loudly(tmp_path, mon
 
 
 def test_batch_capacity_uses_the_prefill_row_count():
-    """wis_generate prefills all P prompt rows (B * P <= 48); the batcher's capacity must use the same bound."""
+    """wis_generate prefills all P prompt rows (B * P <= MAX_ROWS); the batcher's capacity must use the same bound
+    (96 rows since round 3: 16 utterances x beam 5)."""
     from wis_hip.ctranslate2 import MAX_DECODER_ROWS, _capacity
-    assert MAX_DECODER_ROWS == 48
-    assert _capacity(16, (4, 1)) == 12 and _capacity(16, (4, 3)) == 12 and _capacity(16, (4, 5)) == 9 and _capacity(8, (4, 5)) == 8
-    assert _capacity(48, (1, 1)) == 48 and _capacity(16, (16, 1)) == 3
+    assert MAX_DECODER_ROWS == 96
+    assert _capacity(32, (4, 1)) == 24 and _capacity(32, (4, 3)) == 24 and _capacity(32, (4, 5)) == 19 and _capacity(16, (4, 5)) == 16 and _capacity(8, (4, 5)) == 8
+    assert _capacity(96, (1, 1)) == 96 and _capacity(16, (16, 1)) == 6
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "willow-inference-server_amd", "csrc", "kernels.hpp")).read()
-    assert "constexpr int MAX_ROWS = 48;" in src
+    assert "constexpr int MAX_ROWS = 96;" in src

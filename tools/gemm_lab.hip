@@ -433,7 +433,10 @@ static void launch_g(const P& p, hipStream_t st) {
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // EP: 0 = every lane stores its 4-column pieces (8 B) straight from the accumulators; 1 = no stores (ablation: what the epilogue costs);
-// 2 = the wave tile goes through LDS (XOR-swizzled [128][64] f16 image per wave) and leaves as 16-byte stores of whole 128-byte row segments
+// 2 = the wave tile goes through LDS (XOR-swizzled [128][64] f16 image per wave) and leaves as 16-byte stores of whole 128-byte row segments.
+// The kernel loops over output tiles (tile = virtual workgroup id, + gridDim.x per round): launched with one workgroup per tile it is the
+// one-tile-per-workgroup form, launched with min(tiles, 256) workgroups it is PERSISTENT - the next tile's prologue DMAs are requested
+// before this tile's stores (EP 0), which then drain while the matrix cores work on the next tile.
 template <bool STAGGER, bool PRIO, int EP>
 __global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
   constexpr int BM_ = 256, BN_ = 256, HALF = 128 * 64, BUF = 4 * HALF;
@@ -442,47 +445,37 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
   const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
-  int wg;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN_;
   const int nk = p.K / BK;
-  // ---- staging sources: wave w stages local rows (2 w + j) * 8 + (lane >> 3), j = 0, 1, of every half-tile
-  const f16 *sN[2][2], *sM[2][2];      // [lo / hi][j]
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
-    const int n = n0 + (rl >> 5) * 64 + (rl & 31);
-    sN[0][j] = p.W + (int64_t)n * p.K + c * 8;
-    sN[1][j] = p.W + (int64_t)(n + 32) * p.K + c * 8;
-    int mlo = m0 + (rl >> 6) * 128 + (rl & 63), mhi = mlo + 64;
-    if (mlo > p.M - 1) mlo = p.M - 1;
-    if (mhi > p.M - 1) mhi = p.M - 1;
-    sM[0][j] = p.A + (int64_t)mlo * p.K + c * 8;
-    sM[1][j] = p.A + (int64_t)mhi * p.K + c * 8;
-  }
+  const f16 *sNl0, *sNl1, *sNh0, *sNh1, *sMl0, *sMl1, *sMh0, *sMh1;
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int v) {
+    const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    m0 = (wg % nmt) * BM_; n0 = (wg / nmt) * BN_;
+    auto src = [&](int j, const f16** nl, const f16** nh, const f16** ml, const f16** mh) {
+      const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
+      const int n = n0 + (rl >> 5) * 64 + (rl & 31);
+      *nl = p.W + (int64_t)n * p.K + c * 8;
+      *nh = p.W + (int64_t)(n + 32) * p.K + c * 8;
+      int mlo = m0 + (rl >> 6) * 128 + (rl & 63), mhi = mlo + 64;
+      if (mlo > p.M - 1) mlo = p.M - 1;
+      if (mhi > p.M - 1) mhi = p.M - 1;
+      *ml = p.A + (int64_t)mlo * p.K + c * 8;
+      *mh = p.A + (int64_t)mhi * p.K + c * 8;
+    };
+    src(0, &sNl0, &sNh0, &sMl0, &sMh0);
+    src(1, &sNl1, &sNh1, &sMl1, &sMh1);
+  };
 #define WIS_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst), 16, 0, 0)
-  // half-tile h (0 N-lo, 1 M-lo, 2 N-hi, 3 M-hi) of the NEXT k-tile this pointer pair has not staged yet -> LDS buffer at element
-  // offset `bo`; every source pointer is used once per k-tile, so it simply advances by one k-tile per use
 #define WIS_STAGE(PA, PB, h, bo) do { \
     f16* d_ = smem + (bo) + (h) * HALF + wave * 1024; \
     WIS_DMA(PA, d_); WIS_DMA(PB, d_ + 512); PA += BK; PB += BK; } while (0)
-  // ---- fragment read offsets (f16 elements inside a half-tile region): row * 64 + ((4 kb + kq) ^ (l15 >> 1)) * 8
+#define WIS_PROLOGUE() do { \
+    WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sMl0, sMl1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0); WIS_STAGE(sMh0, sMh1, 3, 0); \
+    WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sMl0, sMl1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF); } while (0)
   const int fo0 = l15 * 64 + ((kq ^ (l15 >> 1)) << 3);
-  const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;      // + buffer + region + blk * 1024 (immediates); k-block 1 = the same offset ^ 32 elements
+  const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;
   f32x4v acc[8][4];
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  // ---- prologue: k-tile 0 complete, three half-tiles of k-tile 1 in flight (nk >= 2)
-  WIS_STAGE(sN[0][0], sN[0][1], 0, 0); WIS_STAGE(sM[0][0], sM[0][1], 1, 0); WIS_STAGE(sN[1][0], sN[1][1], 2, 0); WIS_STAGE(sM[1][0], sM[1][1], 3, 0);
-  WIS_STAGE(sN[0][0], sN[0][1], 0, BUF); WIS_STAGE(sM[0][0], sM[0][1], 1, BUF); WIS_STAGE(sN[1][0], sN[1][1], 2, BUF);
-  __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
-  __builtin_amdgcn_s_barrier();
-  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
   f16x8v nlo[2][2], nhi[2][2], mlo[4][2], mhi[4][2];
 #define WIS_FRAG(base, h, blk, kb) (*reinterpret_cast<const f16x8v*>(smem + ((kb) ? base##1 : base##0) + (h) * HALF + (blk) * 1024))
 #define WIS_MMA16(MF, NF, MB0, NB0) do { \
@@ -494,107 +487,119 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(P p) {
           acc[(MB0) + mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], MF[mb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0); \
     if (PRIO) __builtin_amdgcn_s_setprio(0); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
-  int cb = 0;      // element offset of the buffer holding k-tile t
-  for (int t = 0; t < nk; ++t) {
-    const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
-    const int nb_ = cb ^ BUF;      // the other buffer
-    // ---- phase 0
+  int v = blockIdx.x;
+  setup(v);
+  WIS_PROLOGUE();
+  for (;;) {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6): at most 6 operations outstanding => k-tile 0's eight DMAs are done
+    __builtin_amdgcn_s_barrier();
+    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
+    int cb = 0;      // element offset of the buffer holding k-tile t
+    for (int t = 0; t < nk; ++t) {
+      const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
+      const int ob = cb ^ BUF;      // the other buffer
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) mlo[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
-    if (t + 1 < nk) WIS_STAGE(sM[1][0], sM[1][1], 3, nb_);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8): the four N-lo reads are retired before the first barrier
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mlo, nlo, 0, 0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1
+        for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
-    if (t + 2 < nk) WIS_STAGE(sN[0][0], sN[0][1], 0, cb);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mlo, nhi, 0, 2);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 2
+        for (int kb = 0; kb < 2; ++kb) mlo[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
+      if (t + 1 < nk) WIS_STAGE(sMh0, sMh1, 3, ob);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8)
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mlo, nlo, 0, 0);
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) mhi[mb][kb] = WIS_FRAG(rMb, 3, mb, kb);
-    if (t + 2 < nk) WIS_STAGE(sM[0][0], sM[0][1], 1, cb);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mhi, nhi, 4, 2);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 3
-    if (t + 2 < nk) { WIS_STAGE(sN[1][0], sN[1][1], 2, cb); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed (this wave's share), three half-tiles of t+2 fly on
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mhi, nlo, 4, 0);
-    __builtin_amdgcn_s_barrier();
-    cb = nb_;
+        for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
+      if (t + 2 < nk) WIS_STAGE(sNl0, sNl1, 0, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mlo, nhi, 0, 2);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) mhi[mb][kb] = WIS_FRAG(rMb, 3, mb, kb);
+      if (t + 2 < nk) WIS_STAGE(sMl0, sMl1, 1, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mhi, nhi, 4, 2);
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, cb); __builtin_amdgcn_s_waitcnt(0x0F76); }
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mhi, nlo, 4, 0);
+      __builtin_amdgcn_s_barrier();
+      cb = ob;
+    }
+    if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier
+    const int mt = m0, ntl = n0, vn = v + (int)gridDim.x;
+    const bool more = vn < nwg;
+    if (more && EP != 2) { setup(vn); WIS_PROLOGUE(); }      // (the LDS epilogue needs the buffers itself: its prologue follows it)
+    // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
+    if (EP == 1) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) asm volatile("" :: "v"(acc[mb][nb][0]), "v"(acc[mb][nb][1]), "v"(acc[mb][nb][2]), "v"(acc[mb][nb][3]));
+    } else if (EP == 2) {
+      f16* reg = smem + wave * 8192;
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        const int row = (mb >> 2) * 64 + (mb & 3) * 16 + l15;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int col = (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq;
+          const f16x4 o = {(f16)acc[mb][nb][0], (f16)acc[mb][nb][1], (f16)acc[mb][nb][2], (f16)acc[mb][nb][3]};
+          *reinterpret_cast<f16x4*>(reg + row * 64 + (((col >> 3) ^ ((row >> 1) & 7)) << 3) + (col & 7)) = o;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = i * 8 + (lane >> 3), ch = lane & 7;
+        const uint4 vv = *reinterpret_cast<const uint4*>(reg + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+        const int m = mt + wr * 128 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(p.C + (size_t)m * p.N + ntl + wc * 64 + ch * 8) = vv;
+      }
+      if (more) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); setup(vn); WIS_PROLOGUE(); }      // every wave's LDS reads are done before the DMAs overwrite them
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        const int m = mt + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
+        if (m < p.M) {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            const int n = ntl + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq;
+            const f16x4 o = {(f16)acc[mb][nb][0], (f16)acc[mb][nb][1], (f16)acc[mb][nb][2], (f16)acc[mb][nb][3]};
+            *reinterpret_cast<f16x4*>(p.C + (size_t)m * p.N + n) = o;
+          }
+        }
+      }
+    }
+    if (!more) break;
+    v = vn;
   }
-  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier
 #undef WIS_MMA16
 #undef WIS_FRAG
+#undef WIS_PROLOGUE
 #undef WIS_STAGE
 #undef WIS_DMA
-  // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
-  if (EP == 1) {
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) asm volatile("" :: "v"(acc[mb][nb][0]), "v"(acc[mb][nb][1]), "v"(acc[mb][nb][2]), "v"(acc[mb][nb][3]));
-    return;
-  }
-  if (EP == 2) {
-    // every wave has passed its last fragment read (the closing barriers), so the k-tile buffers are free: wave w takes 16 KiB
-    f16* reg = smem + wave * 8192;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      const int row = (mb >> 2) * 64 + (mb & 3) * 16 + l15;
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const int col = (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq;
-        const f16x4 o = {(f16)acc[mb][nb][0], (f16)acc[mb][nb][1], (f16)acc[mb][nb][2], (f16)acc[mb][nb][3]};
-        *reinterpret_cast<f16x4*>(reg + row * 64 + (((col >> 3) ^ ((row >> 1) & 7)) << 3) + (col & 7)) = o;
-      }
-    }
-    // (the same wave reads what it wrote: LDS operations of a wave complete in order)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = i * 8 + (lane >> 3), ch = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
-      const int m = m0 + wr * 128 + row;
-      if (m < p.M) *reinterpret_cast<uint4*>(p.C + (size_t)m * p.N + n0 + wc * 64 + ch * 8) = v;
-    }
-    return;
-  }
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) {
-    const int m = m0 + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
-    if (m < p.M) {
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const int n = n0 + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq;
-        const f16x4 o = {(f16)acc[mb][nb][0], (f16)acc[mb][nb][1], (f16)acc[mb][nb][2], (f16)acc[mb][nb][3]};
-        *reinterpret_cast<f16x4*>(p.C + (size_t)m * p.N + n) = o;
-      }
-    }
-  }
 }
-template <bool STAGGER, bool PRIO, int EP = 0>
+template <bool STAGGER, bool PRIO, int EP = 0, bool PERSIST = false>
 static void launch_8p(const P& p, hipStream_t st) {
-  const int nwg = ((p.M + 255) / 256) * (p.N / 256);
+  int nwg = ((p.M + 255) / 256) * (p.N / 256);
+  if (PERSIST && nwg > 256) nwg = 256;
   hipLaunchKernelGGL((gemm_8p_kernel<STAGGER, PRIO, EP>), dim3(nwg), dim3(512), 0, st, p);
 }
 
@@ -679,6 +684,9 @@ int main(int argc, char** argv) {
     {"256x256 8p-noprio", launch_8p<true, false>, nullptr, 256, 256},
     {"256x256 8p-nostore (ablation: wrong)", launch_8p<true, true, 1>, nullptr, 256, 256},
     {"256x256 8p-ldsep", launch_8p<true, true, 2>, nullptr, 256, 256},
+    {"256x256 8p-persist", launch_8p<true, true, 0, true>, nullptr, 256, 256},
+    {"256x256 8p-persist-ldsep", launch_8p<true, true, 2, true>, nullptr, 256, 256},
+    {"256x256 8p-persist-nostore (ablation: wrong)", launch_8p<true, true, 1, true>, nullptr, 256, 256},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
   const bool stamps = argc > 2 ? atoi(argv[2]) != 0 : true;

@@ -362,18 +362,20 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
   const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
-  int wg;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int m0 = (wg % nmt) * BM_, n0 = (wg / nmt) * BN_;
   const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
   const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
+  // PERSISTENT over output tiles: the grid is min(tiles, CUs) workgroups and workgroup g computes the tiles g, g + grid, ...  The
+  // stores of a tile (128 KiB per workgroup; with one tile per workgroup every CU of a round wrote at the same time and the chip
+  // sat on its HBM write bandwidth: 20 % of the GEMM at 8 utterances, tools/gemm_lab.hip "8p-nostore") are issued and left to drain
+  // while the matrix cores are already on the next tile, whose first seven half-tiles were requested BEFORE those stores.
   // staging sources: wave w stages local rows (2 w + j) * 8 + (lane >> 3), j = 0, 1, of every half-tile; each pointer is used once
   // per k-tile and advances by one k-tile per use
   const f16 *sNl0, *sNl1, *sNh0, *sNh1, *sMl0, *sMl1, *sMh0, *sMh1;
-  {
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int v) {      // virtual workgroup id -> tile (XCD-aware, bijective regrouping: guide T1; then m-fastest) and its sources
+    const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    m0 = (wg % nmt) * BM_; n0 = (wg / nmt) * BN_;
     auto src = [&](int j, const f16** nl, const f16** nh, const f16** ml, const f16** mh) {
       const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
       const int n = n0 + (rl >> 5) * 64 + (rl & 31);
@@ -387,25 +389,19 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
     };
     src(0, &sNl0, &sNh0, &sMl0, &sMh0);
     src(1, &sNl1, &sNh1, &sMl1, &sMh1);
-  }
+  };
 #define WIS_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst), 16, 0, 0)
 #define WIS_STAGE(PA, PB, h, bo) do { \
     f16* d_ = smem + (bo) + (h) * HALF + wave * 1024; \
     WIS_DMA(PA, d_); WIS_DMA(PB, d_ + 512); PA += BK; PB += BK; } while (0)
+  // k-tile 0 complete, three half-tiles of k-tile 1 in flight (the launcher guarantees nk >= 2)
+#define WIS_PROLOGUE() do { \
+    WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sMl0, sMl1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0); WIS_STAGE(sMh0, sMh1, 3, 0); \
+    WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sMl0, sMl1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF); } while (0)
   // fragment read offsets (f16 elements inside a half-tile region): row * 64 + ((4 kb + kq) ^ (l15 >> 1)) * 8; k-block 1 = offset ^ 32
   const int fo0 = l15 * 64 + ((kq ^ (l15 >> 1)) << 3);
   const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;
   f32x4 acc[8][4];
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // prologue: k-tile 0 complete, three half-tiles of k-tile 1 in flight (the launcher guarantees nk >= 2)
-  WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sMl0, sMl1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0); WIS_STAGE(sMh0, sMh1, 3, 0);
-  WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sMl0, sMl1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF);
-  __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
   f16x8 nlo[2][2], nhi[2][2], mlo[4][2], mhi[4][2];
 #define WIS_FRAG(base, h, blk, kb) (*reinterpret_cast<const f16x8*>(smem + ((kb) ? base##1 : base##0) + (h) * HALF + (blk) * 1024))
 #define WIS_MMA16(MF, NF, MB0, NB0) do { \
@@ -417,69 +413,91 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
           acc[(MB0) + mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], MF[mb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
-  int cb = 0;      // element offset of the buffer holding k-tile t
-  for (int t = 0; t < nk; ++t) {
-    const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
-    const int ob = cb ^ BUF;      // the other buffer
-    // ---- phase 0
+  int v = blockIdx.x;
+  setup(v);
+  WIS_PROLOGUE();
+  for (;;) {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // at most 6 vector-memory operations outstanding => at least 8 of the 14 prologue DMAs are done, i.e. k-tile 0 (loads complete
+    // in order among themselves; the previous tile's stores, requested after the prologue, may complete in any order: they can only
+    // make this wait longer, never shorter)
+    __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
+    int cb = 0;      // element offset of the buffer holding k-tile t
+    for (int t = 0; t < nk; ++t) {
+      const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
+      const int ob = cb ^ BUF;      // the other buffer
+      // ---- phase 0
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) mlo[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
-    if (t + 1 < nk) WIS_STAGE(sMh0, sMh1, 3, ob);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8): the four N-lo reads are retired before the first barrier
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mlo, nlo, 0, 0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1
+        for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
-    if (t + 2 < nk) WIS_STAGE(sNl0, sNl1, 0, cb);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mlo, nhi, 0, 2);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 2
+        for (int kb = 0; kb < 2; ++kb) mlo[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
+      if (t + 1 < nk) WIS_STAGE(sMh0, sMh1, 3, ob);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8): the four N-lo reads are retired before the first barrier
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mlo, nlo, 0, 0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 1
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) mhi[mb][kb] = WIS_FRAG(rMb, 3, mb, kb);
-    if (t + 2 < nk) WIS_STAGE(sMl0, sMl1, 1, cb);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mhi, nhi, 4, 2);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 3
-    if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, cb); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed (this wave's share); three half-tiles of t+2 fly on
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    WIS_MMA16(mhi, nlo, 4, 0);
-    __builtin_amdgcn_s_barrier();
-    cb = ob;
+        for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
+      if (t + 2 < nk) WIS_STAGE(sNl0, sNl1, 0, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mlo, nhi, 0, 2);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) mhi[mb][kb] = WIS_FRAG(rMb, 3, mb, kb);
+      if (t + 2 < nk) WIS_STAGE(sMl0, sMl1, 1, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mhi, nhi, 4, 2);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 3
+      if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, cb); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed (this wave's share); three half-tiles of t+2 fly on
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      WIS_MMA16(mhi, nlo, 4, 0);
+      __builtin_amdgcn_s_barrier();
+      cb = ob;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier: every wave is past its last fragment read
+    // next tile's prologue first (the k-tile buffers are free), then this tile's stores
+    const int mt = m0, ntl = n0, vn = v + (int)gridDim.x;
+    const bool more = vn < nwg;
+    if (more) { setup(vn); WIS_PROLOGUE(); }
+    // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int m = mt + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
+      if (m < p.M) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) epi(m, ntl + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq, acc[mb][nb]);
+      }
+    }
+    if (!more) break;
+    v = vn;
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier
 #undef WIS_MMA16
 #undef WIS_FRAG
+#undef WIS_PROLOGUE
 #undef WIS_STAGE
 #undef WIS_DMA
-  // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) {
-    const int m = m0 + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
-    if (m < p.M) {
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) epi(m, n0 + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq, acc[mb][nb]);
-    }
-  }
 }
 
 // 128-256 ping-pong tiles: every tile has a CU of its own and at least half of the CUs have one (medium, M = 1500: QKV at 144
@@ -511,7 +529,15 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   // 256 x 256: the 8-phase LDS-DMA kernel (WIS_GEMM_8P=0: the register-staged 2 x 4-wave tile, A/B tuning switch); it needs two k-tiles
   static const bool use_8p = !(getenv("WIS_GEMM_8P") && atoi(getenv("WIS_GEMM_8P")) == 0);
   const int nk_ = (p.klen > 0 ? p.klen : p.K) / BK;
-  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) hipLaunchKernelGGL((gemm_8p_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
+  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) {
+    // persistent over tiles: at most one workgroup per CU (a multiple of 8, so that a workgroup's tiles stay on its XCD's share)
+    static const bool persist = !(getenv("WIS_GEMM_PERSIST") && atoi(getenv("WIS_GEMM_PERSIST")) == 0);
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256; n_cu = v & ~7; }
+    dim3 g8 = grid;
+    if (persist && (int)grid.x > n_cu) g8.x = n_cu;
+    hipLaunchKernelGGL((gemm_8p_kernel<Epi>), g8, dim3(512), 0, st, p, epi);
+  }
   else if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
