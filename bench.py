@@ -111,7 +111,38 @@ def decode_step_bytes(a, B, beam, P, steps, w8=False):
     return W + B * C + B * beam * t_avg * s_row
 
 
-def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms, rest_batch=8):
+def concurrent_batches(lib, handles, dev, pcm, beam, B, fixed_new, audio_ms, iters=6):
+    """Utterances per second with 1 .. len(handles) device batches of B utterances in flight on ONE GPU: every handle is a replica
+    with its own stream, activations and KV caches over the SAME weight copy (wis_model_clone), driven by its own host thread -
+    what `inter_threads` > 1 does in the reference's CTranslate2 model (main.py:341-355).  A decode chain is latency-bound (tens of
+    small dependent launches per layer), so a second and third batch in flight run in the gaps of the first."""
+    import threading
+    from wis_hip import _lib, audio
+    win = np.ascontiguousarray(np.tile(audio.pad_or_trim(pcm)[None], (B, 1)).astype(np.float32))
+    keep = _lib.DevBuf.from_numpy(win, dev)
+    prompt = np.ascontiguousarray(np.tile(np.array(PROMPT, np.int32), (B, 1)))
+    rows = []
+    for R in range(1, len(handles) + 1):
+        def worker(h, n):
+            opts = _lib.GenOpts(_lib.WIS_IN_PCM_DEV, beam, 0, 1.0, 1.0, 1, 1, fixed_new, 0)
+            ids = np.zeros((B, 224), np.int32); lens = np.zeros(B, np.int32); scores = np.zeros(B, np.float32)
+            for _ in range(n):
+                _lib.check(lib.wis_generate(h, keep.ptr, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), len(PROMPT), C.byref(opts),
+                                            ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)), scores.ctypes.data_as(C.POINTER(C.c_float))))
+        for phase, n in (("warm", 2), ("timed", iters)):
+            th = [threading.Thread(target=worker, args=(handles[i], n)) for i in range(R)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+        rows.append({"batches_in_flight": R, "utterances_per_s": round(R * iters * B / dt, 1), "aggregate_x_realtime": round(R * iters * B * audio_ms / 1e3 / dt, 1),
+                     "ms_per_device_batch": round(1e3 * dt / iters, 2)})
+    return {"workload": f"{B} x 3sec.flac per device batch, beam {beam}, replicas on one GPU sharing one weight copy, one host thread each", "rows": rows}
+
+
+def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms, rest_batch=8, extra_handles=()):
     """The reference's own load shape, client/jmeter-asr.jmx:53-90: `clients` threads, each looping
     POST /api/asr?task=transcribe&output=json&model=large&beam_size=5&detect_language=False with the 3.84 s clip as the
     multipart field `audio_file`.  Served by the re-hosted endpoint (wis_hip/server.py) in this process over the ASGI transport
@@ -126,7 +157,7 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     s.whisper_model_path = "synthetic:{size}"
     s.max_batch, s.fixed_new_tokens = rest_batch, fixed_new
     models = WhisperModels(s, device_index=[dev])
-    model = ct2.Whisper.from_handles([(handle, dev)], a, max_batch=rest_batch, max_beam=5)
+    model = ct2.Whisper.from_handles([(handle, dev)] + [(h, dev) for h in extra_handles], a, max_batch=rest_batch, max_beam=5)
     models._models["large"] = model
     app = create_app(models=models, max_workers=max(64, clients))
     b = "wisBenchBoundary"
@@ -155,7 +186,8 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     n = clients * iterations
     model.close()
     model._replicas = []          # the handle belongs to the caller
-    return {"load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport, device batches of up to {rest_batch}",
+    return {"load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport, device batches of up to {rest_batch}, "
+                    f"{1 + len(extra_handles)} replica(s) on the GPU",
             "utterances_per_s": round(n / elapsed, 2), "aggregate_x_realtime": round(n * audio_ms / 1e3 / elapsed, 1),
             "p50_request_ms": round(p50(lat), 2), "max_request_ms": round(max(lat), 2), "device_batches": sizes[:32], "mean_device_batch": round(float(np.mean(sizes)), 2)}
 
@@ -490,10 +522,22 @@ def main():
         except Exception as e:
             cfgs.append({"config": "base beam 1 over REST (configs[0] shape)", "failed": repr(e)})
         extra["other_baseline_configs"] = cfgs
+        clones = []
+        try:
+            for _ in range(2):
+                c = C.c_void_p()
+                _lib.check(lib.wis_model_clone(handle, C.byref(c)))
+                clones.append(c)
+            extra["concurrent_device_batches"] = concurrent_batches(lib, [handle] + clones, dev, pcm, args.beam, 8, fixed_new, audio_ms)
+        except Exception as e:
+            extra["concurrent_device_batches"] = {"failed": repr(e)}
         try:
             extra["rest_load"] = rest_load(handle, a, dev, args.rest_clients, 2, fixed_new, open(clip_path, "rb").read(), audio_ms)
+            extra["rest_load_3_replicas"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones)
         except Exception as e:
             extra["rest_load"] = {"failed": repr(e)}
+        for c in clones:
+            lib.wis_model_destroy(c)
         try:
             extra["streaming"] = streaming_bench(handle, a, dev, os.path.join(ROOT, "tests", "golden", "clips", "30sec.flac"))
         except Exception as e:

@@ -121,6 +121,11 @@ int  wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_b
                       int device, wis_model_t** out);
 void wis_model_destroy(wis_model_t* m);
 size_t wis_model_device_bytes(const wis_model_t* m);
+/* Another replica on the SAME GPU that shares `parent`'s converted weights (read-only device memory, reference-counted: either
+ * handle may be destroyed first) and owns its stream, activations and KV caches.  CTranslate2's `inter_threads` (reference
+ * main.py:341-355: parallel batches per model) maps onto this: several device batches in flight on one GPU, each decode chain
+ * filling the gaps of the others. */
+int  wis_model_clone(wis_model_t* parent, wis_model_t** out);
 
 /* ---- a7-a13: generate (replaces whisper_model.generate(features, [prompt]*B,
  * beam_size=.., return_scores=False) and results[i].sequences_ids[0], main.py:685-693,707,713;

@@ -491,3 +491,45 @@ def test_sixteen_utterances_per_device_batch_vs_oracle(mels, lib):
     print(f"16 utterances x beam 5: {exact} of 16 identical to the oracle (decision margins {want[0][2]:.4f} / {want[1][2]:.4f})")
     assert exact >= 8
     model.close()
+
+
+def test_replicas_per_device_share_one_weight_copy(mels, lib):
+    """`inter_threads` (reference main.py:341-355: batches a CTranslate2 model runs in parallel) -> replicas PER GPU that share one
+    weight copy (wis_model_clone) and own their stream, activations and KV caches: every replica answers like a lone model,
+    concurrent calls spread over them, and the shared weights live until the LAST replica is destroyed (whichever goes first)."""
+    import ctypes as C
+    import threading
+    from wis_hip import _lib, ctranslate2 as ct2, weights as W
+    w = W.synthetic_weights("tiny", seed=1234, emb_std=0.06, ln_jitter=0.1)
+    a = W.arch("tiny")
+    lone = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5)
+    pool = ct2.Whisper("unused", weights=w, arch=a, max_batch=2, max_beam=5, inter_threads=3)
+    assert len(pool._replicas) == 3 and len({r.device for r in pool._replicas}) == 1
+    own = [lib.wis_model_device_bytes(r.handle) for r in pool._replicas]
+    assert own[1] == own[2] and own[1] < own[0]            # a clone carries buffers only
+    f = ct2.StorageView.from_array(mels)
+    exp = [r.sequences_ids for r in lone.generate(f, [PROMPT] * 2, beam_size=5, fixed_new_tokens=6)]
+    for r in pool._replicas:
+        got = pool._generate_chunk(r, mels, [PROMPT] * 2, 4, 5, 224, 1.0, 1.0, True, True, 6, 0)
+        assert [x.sequences_ids for x in got] == exp
+    out = {}
+
+    def client(i):
+        out[i] = pool.generate(ct2.StorageView.from_array(mels[i % 2:i % 2 + 1]), [PROMPT], beam_size=5, fixed_new_tokens=6)[0].sequences_ids
+
+    th = [threading.Thread(target=client, args=(i,)) for i in range(18)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len({idx for idx, _ in pool._batcher.batches}) >= 2
+    single = [lone.generate(ct2.StorageView.from_array(mels[k:k + 1]), [PROMPT], beam_size=5, fixed_new_tokens=6)[0].sequences_ids for k in range(2)]
+    assert sum(out[i] != single[i % 2] for i in range(18)) <= 2
+    # the parent goes first: its clones keep the weights alive
+    pool.close()
+    parent = pool._replicas[0]
+    lib.wis_model_destroy(parent.handle); parent.handle = None
+    for r in pool._replicas[1:]:
+        got = ct2._generate_chunk(r, mels, [PROMPT] * 2, 4, 5, 224, 1.0, 1.0, True, True, 6, 0)
+        assert [x.sequences_ids for x in got] == exp
+    lone.close()

@@ -8,7 +8,7 @@
 #   bench<N> [ENV=VAL ...]   bench.py at N utterances per device batch (no extras, no CPU baseline); extra words are
 #                   environment assignments for that run and become part of the output name
 #   benchfull       the default bench.py line (what the driver runs)
-#   prof1 / prof8   rocprofv3 --kernel-trace --stats of the eager bench at 1 / 8 utterances -> kernel_stats_b*.txt (+ by-grid table)
+#   prof<N>         rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
 #   pmc <counter>   one rocprofv3 --pmc pass of the eager batch-8 bench -> pmc_<counter>.csv (per-kernel sums)
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${WIS_TAG:-r3}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
@@ -43,7 +43,7 @@ while [ $# -gt 0 ]; do
       B=${step#bench}; envs=(); while [ $# -gt 0 ] && [[ $1 == *=* ]]; do envs+=("$1"); shift; done
       run_bench "$B" "${envs[@]}" ;;
     benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; tail -c 600 "$O/bench_default.json" ;;
-    prof1|prof8)
+    prof[0-9]*)
       B=${step#prof}
       ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof_b$B" -o "b$B" -- python "$R/bench.py" --steps 5 --warmup 2 --batch "$B" --no-cpu-baseline --no-extras > "$O/bench_eager_b$B.log" 2>&1 )
       DB=$(find "$O/prof_b$B" -name "*.db" | head -1)

@@ -966,14 +966,14 @@ constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16
 // workgroups of an 8-utterance batch ran in two rounds; with CM = 6 it needs 88 (five per CU).
 // FOLD: the folded-query prologue (B = 1-sized row counts only; its own instantiation so that the batched kernel keeps its
 // register budget).
-// SPIN (small grids: B * H <= 128, <= 6 chunks, <= 8 rows): the chunk partials travel as 8-byte {tag, value} GRANULES, one write-through
+// SPIN (small grids: B * H <= 192, <= 6 chunks, <= 8 rows): the chunk partials travel as 8-byte {tag, value} GRANULES, one write-through
 // store each (guide G16 form R2: "the data is the flag") - a producing workgroup stores and leaves: no drain, no barrier, no ticket.
 // The workgroup of the LAST chunk of every (utterance, head) is its combiner: it keeps its own partial in LDS and re-reads the other
 // chunks' granules (relaxed agent-scope loads) until every tag equals this launch's epoch, then combines in the fixed chunk order
 // (the same arithmetic, in the same order, as the ticket form: bit-identical results).  The epoch of an (utterance, head) is a word
 // in device memory that its combiner advances at the end of the launch (launches on a stream are ordered, so the next launch
 // reads the new value; tags only grow, so a slot's old contents can never match) - nothing is reset between launches, and graph
-// replays stay valid.  Progress: producers never wait; at most B * H <= 128 workgroups spin, fewer than the chip's 256 CUs, so a
+// replays stay valid.  Progress: producers never wait; at most B * H <= 192 workgroups spin, fewer than the chip's 256 CUs, so a
 // producer always finds a slot.  The spin is bounded: on exhaustion the combiner raises a flag (checked by wis_generate) instead of
 // hanging.  What it removes from the hand-off: the store drain, the returning ticket atomic and the agent-scope acquire (1.7 us).
 typedef unsigned long long gran_t;

@@ -99,7 +99,7 @@ int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f1
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 // gran / epoch (optional): the granule hand-off of small grids (dec_kernels.hip, SPIN): gran = 8-byte slots [B*H][6][8][66], epoch =
 // ONE flag word (non-zero: a combiner's bounded spin ran out) followed by [B*H] monotonic epoch words, all zero-initialised once
-constexpr int CA_SPIN_MAX_BH = 128;
+constexpr int CA_SPIN_MAX_BH = 192;      // spinning combiners per launch: fewer than the chip's 256 CUs, so a producer always finds a slot (8 utterances x 20 heads = 160)
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0,
                           const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr,   // folded query: see the kernel

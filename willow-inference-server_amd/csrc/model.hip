@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -115,12 +116,20 @@ struct GraphKey {
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
+// the device slabs that hold a model's converted weights: shared by every replica cloned from it on the same GPU (wis_model_clone),
+// freed when the last of them is destroyed
+struct WeightSlabs {
+  int device; std::vector<void*> slabs; size_t bytes = 0;
+  ~WeightSlabs() { hipSetDevice(device); for (void* p : slabs) hipFree(p); }
+};
+
 struct wis_model {
   wis_config_t cfg;
   int device;
   DeviceCtx* ctx;
   hipStream_t st;
-  std::vector<void*> allocs;    // slabs (hipMalloc'ed), carved by dalloc()
+  std::shared_ptr<WeightSlabs> wslabs;      // weights (read-only after load): possibly shared with clones
+  std::vector<void*> allocs;    // this replica's own slabs (activations, caches, state), carved by dalloc()
   char* slab_cur = nullptr; size_t slab_left = 0;
   size_t bytes = 0;
   // weights
@@ -771,6 +780,10 @@ int wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_by
       if (cfg->n_lang > 0) hipMemcpy(m->d_lang_ids, cfg->lang_ids, (size_t)cfg->n_lang * 4, hipMemcpyHostToDevice);
     }
     m->cfg.suppress_ids = nullptr; m->cfg.suppress_ids_begin = nullptr; m->cfg.lang_ids = nullptr;   // caller-owned memory is not retained
+    // everything carved so far is the (read-only) weight set: it moves into a shareable block; the buffers start on fresh slabs
+    m->wslabs = std::make_shared<WeightSlabs>();
+    m->wslabs->device = device; m->wslabs->slabs.swap(m->allocs); m->wslabs->bytes = m->bytes;
+    m->slab_cur = nullptr; m->slab_left = 0;
     if ((rc = alloc_buffers(m))) break;
     if (hipStreamSynchronize(m->st) != hipSuccess) { set_error("model init failed"); rc = WIS_E_HIP; break; }
   } while (0);
@@ -792,6 +805,33 @@ void wis_model_destroy(wis_model_t* m) {
   delete m;
 }
 size_t wis_model_device_bytes(const wis_model_t* m) { return m ? m->bytes : 0; }
+
+int wis_model_clone(wis_model_t* parent, wis_model_t** out) {
+  if (!parent || !out || !parent->wslabs) { set_error("wis_model_clone: bad argument"); return WIS_E_ARG; }
+  WIS_HIP_CHECK(hipSetDevice(parent->device));
+  wis_model* m = new wis_model();
+  m->cfg = parent->cfg; m->device = parent->device; m->ctx = parent->ctx;
+  m->wslabs = parent->wslabs;
+  // the weight set (device pointers into the shared slabs)
+  m->w_conv1 = parent->w_conv1; m->w_conv2 = parent->w_conv2; m->b_conv1 = parent->b_conv1; m->b_conv2 = parent->b_conv2;
+  m->enc_pos = parent->enc_pos; m->enc_ln_g = parent->enc_ln_g; m->enc_ln_b = parent->enc_ln_b;
+  m->enc = parent->enc; m->dec = parent->dec;
+  m->emb = parent->emb; m->dec_pos = parent->dec_pos; m->p_proj = parent->p_proj; m->dec_ln_g = parent->dec_ln_g; m->dec_ln_b = parent->dec_ln_b;
+  m->bias_all = parent->bias_all; m->bias_begin = parent->bias_begin; m->d_lang_ids = parent->d_lang_ids; m->n_vocab_pad = parent->n_vocab_pad;
+  m->w_ckv_all = parent->w_ckv_all; m->b_ckv_all = parent->b_ckv_all;
+  m->s_proj = parent->s_proj; m->c_proj = parent->c_proj; m->b_proj = parent->b_proj; m->w8 = parent->w8; m->cq_fold = parent->cq_fold;
+  m->use_graph = parent->use_graph;
+  memset(&m->timing, 0, sizeof(m->timing));
+  int rc = WIS_OK;
+  do {
+    if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess) { set_error("stream create failed"); rc = WIS_E_HIP; break; }
+    if ((rc = alloc_buffers(m))) break;
+    if (hipStreamSynchronize(m->st) != hipSuccess) { set_error("clone init failed"); rc = WIS_E_HIP; break; }
+  } while (0);
+  if (rc) { wis_model_destroy(m); return rc; }
+  *out = m;
+  return WIS_OK;
+}
 
 int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
                  const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score) {

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("wis_model_create", _i, [C.POINTER(Config), _vp, _sz, _i, C.POINTER(Tensor), _i, _i, C.POINTER(_vp)]),
     ("wis_model_destroy", None, [_vp]),
     ("wis_model_device_bytes", _sz, [_vp]),
+    ("wis_model_clone", _i, [_vp, C.POINTER(_vp)]),
     ("wis_generate", _i, [_vp, _vp, _i, C.POINTER(C.c_int32), _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),
     ("wis_detect_language", _i, [_vp, _vp, _i, _i, _fp]),
     ("wis_debug_encode", _i, [_vp, _vp, _i, _i, _fp]),

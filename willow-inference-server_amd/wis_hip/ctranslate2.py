@@ -116,6 +116,13 @@ def create_handle(a, arena, index, device, max_batch=8, max_beam=5, arena_device
     return h
 
 
+def clone_handle(h):
+    """Another replica on the same GPU sharing `h`'s weights (wis_model_clone): own stream, activations and KV caches."""
+    c = C.c_void_p()
+    _lib.check(_lib.load().wis_model_clone(h, C.byref(c)))
+    return c
+
+
 def create_replicas(a, arena, index, devices, max_batch=8, max_beam=5, **cfgkw):
     """One replica per entry of `devices` from ONE host upload: the arena goes to the first device over PCIe, every other
     replica receives it device-to-device (wis_dev_copy_peer: xGMI between peers) in a doubling tree - 0 -> 1, then {0 -> 2,
@@ -172,6 +179,7 @@ def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_bl
 
 MAX_DECODER_ROWS = 96      # csrc/kernels.hpp MAX_ROWS: decoder rows per device pass
 MAX_BEAM = 8               # csrc/kernels.hpp MAX_R: rows per utterance (beam size)
+MAX_REPLICAS_PER_DEVICE = 3   # default ceiling for inter_threads -> replicas per GPU (measured: bench.py "concurrent_device_batches")
 MAX_PROMPT = 16            # wis_generate: prompt tokens per utterance
 
 
@@ -213,7 +221,7 @@ class Whisper:
     is_multilingual = True
 
     def __init__(self, model_path, device="cuda", device_index=0, compute_type="default", inter_threads=1, intra_threads=0,
-                 max_batch=8, max_beam=5, weights=None, arch=None, **_ignored):
+                 max_batch=8, max_beam=5, weights=None, arch=None, replicas_per_device=None, **_ignored):
         if device not in ("cuda", "auto", "hip", "gpu"):
             raise ValueError(f"wis_hip runs on MI355X GPUs only (device={device!r}); there is no CPU path")
         _lib.require_gpu()
@@ -238,6 +246,15 @@ class Whisper:
         kw = dict(suppress_ids=cfg.get("suppress_ids"), suppress_begin=cfg.get("suppress_ids_begin"), lang_ids=cfg.get("lang_ids"),
                   weight_bits=8 if self.compute_type == "int8_float16" else 16)
         self._replicas = [_Replica(h, d) for h, d in zip(create_replicas(arch, arena, index, devs, max_batch, max_beam, **kw), devs)]
+        # CTranslate2's `inter_threads` = batches a model runs in parallel (reference main.py:341-355 passes ctranslate2_threads).  Here:
+        # replicas PER GPU that share one weight copy (wis_model_clone) and run their device batches concurrently on their own
+        # streams - a decode chain is latency-bound and leaves most of the chip idle, a second batch in flight fills it.  The count is
+        # bounded by `replicas_per_device` (each replica owns its activations and KV caches: ~0.7 GB per utterance slot for large-v2).
+        per_dev = MAX_REPLICAS_PER_DEVICE if replicas_per_device is None else int(replicas_per_device)
+        per_dev = max(1, min(int(inter_threads) if inter_threads else 1, per_dev))
+        for r in list(self._replicas):
+            for _ in range(per_dev - 1):
+                self._replicas.append(_Replica(clone_handle(r.handle), r.device))
         self.max_batch, self.max_beam = max_batch, max_beam
         self._pick = threading.Lock()
         # concurrent generate() calls coalesce into device batches, one worker per GPU replica (wis_hip/batching.py)

@@ -111,6 +111,7 @@ class WhisperModels:
                 self._models[size] = ctranslate2.models.Whisper(path, device="cuda", compute_type=self.settings.compute_type,
                                                                 inter_threads=self.settings.ctranslate2_threads,
                                                                 device_index=self.device_index, max_batch=self.settings.max_batch,
+                                                                replicas_per_device=self.settings.replicas_per_gpu,
                                                                 max_beam=min(max(int(self.settings.max_beam), int(self.settings.beam_size),
                                                                                  int(self.settings.long_beam_size)), ctranslate2.MAX_BEAM))
             return self._models[size]
