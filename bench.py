@@ -111,7 +111,7 @@ def decode_step_bytes(a, B, beam, P, steps, w8=False):
     return W + B * C + B * beam * t_avg * s_row
 
 
-def concurrent_batches(lib, handles, dev, pcm, beam, B, fixed_new, audio_ms, iters=6):
+def concurrent_batches(lib, handles, dev, pcm, beam, B, fixed_new, audio_ms, iters=6, max_r=None):
     """Utterances per second with 1 .. len(handles) device batches of B utterances in flight on ONE GPU: every handle is a replica
     with its own stream, activations and KV caches over the SAME weight copy (wis_model_clone), driven by its own host thread -
     what `inter_threads` > 1 does in the reference's CTranslate2 model (main.py:341-355).  A decode chain is latency-bound (tens of
@@ -122,7 +122,7 @@ def concurrent_batches(lib, handles, dev, pcm, beam, B, fixed_new, audio_ms, ite
     keep = _lib.DevBuf.from_numpy(win, dev)
     prompt = np.ascontiguousarray(np.tile(np.array(PROMPT, np.int32), (B, 1)))
     rows = []
-    for R in range(1, len(handles) + 1):
+    for R in range(1, (max_r or len(handles)) + 1):
         def worker(h, n):
             opts = _lib.GenOpts(_lib.WIS_IN_PCM_DEV, beam, 0, 1.0, 1.0, 1, 1, fixed_new, 0)
             ids = np.zeros((B, 224), np.int32); lens = np.zeros(B, np.int32); scores = np.zeros(B, np.float32)
@@ -524,16 +524,18 @@ def main():
         extra["other_baseline_configs"] = cfgs
         clones = []
         try:
-            for _ in range(2):
+            for _ in range(4):
                 c = C.c_void_p()
                 _lib.check(lib.wis_model_clone(handle, C.byref(c)))
                 clones.append(c)
             extra["concurrent_device_batches"] = concurrent_batches(lib, [handle] + clones, dev, pcm, args.beam, 8, fixed_new, audio_ms)
+            extra["concurrent_device_batches_of_16"] = concurrent_batches(lib, [handle] + clones, dev, pcm, args.beam, 16, fixed_new, audio_ms, iters=4, max_r=3)
         except Exception as e:
             extra["concurrent_device_batches"] = {"failed": repr(e)}
         try:
             extra["rest_load"] = rest_load(handle, a, dev, args.rest_clients, 2, fixed_new, open(clip_path, "rb").read(), audio_ms)
-            extra["rest_load_3_replicas"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones)
+            extra["rest_load_3_replicas"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:2])
+            extra["rest_load_4_replicas_128_clients"] = rest_load(handle, a, dev, 128, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:3])
         except Exception as e:
             extra["rest_load"] = {"failed": repr(e)}
         for c in clones:

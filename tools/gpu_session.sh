@@ -9,7 +9,7 @@
 #                   environment assignments for that run and become part of the output name
 #   benchfull       the default bench.py line (what the driver runs)
 #   prof<N>         rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
-#   pmc <counter>   one rocprofv3 --pmc pass of the eager batch-8 bench -> pmc_<counter>.csv (per-kernel sums)
+#   pmc <tag> "<COUNTER ...>" [batch]   one rocprofv3 --pmc pass of the eager bench (default 8 utterances) -> pmc_<tag>_b<batch>.txt (per kernel and grid: launches, mean per launch)
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${WIS_TAG:-r3}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
 R=$GRAFT_REPO_ROOT
@@ -51,10 +51,10 @@ while [ $# -gt 0 ]; do
       python tools/prof_summary.py "$DB" 45 --by-grid > "$O/kernels_by_grid_b$B.txt" 2>&1
       find "$O/prof_b$B" -name "*.db" -delete
       head -30 "$O/kernel_stats_b$B.txt" ;;
-    pmc)
-      CNT=$1; shift
-      ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --pmc "$CNT" --kernel-trace -d "$O/pmc_$CNT" -o p --output-format csv -- python "$R/bench.py" --steps 3 --warmup 1 --batch 8 --no-cpu-baseline --no-extras --no-roofline > "$O/pmc_$CNT.log" 2>&1 )
-      python tools/pmc_sum.py "$O/pmc_$CNT" "$CNT" > "$O/pmc_$CNT.txt" 2>&1; find "$O/pmc_$CNT" -name "*.csv" -size +20M -delete; head -30 "$O/pmc_$CNT.txt" ;;
+    pmc)      # pmc <tag> "<COUNTER ...>" [batch]: ONE rocprofv3 --pmc pass (counters only with --kernel-trace, as gpurun requires) of the eager bench
+      PT=$1; CNT=$2; shift 2; PB=8; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then PB=$1; shift; fi
+      ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc_$PT" -o p --output-format csv -- python "$R/bench.py" --steps 2 --warmup 1 --batch "$PB" --no-cpu-baseline --no-extras --no-roofline > "$O/pmc_$PT.log" 2>&1 )
+      python tools/pmc_sum.py "$O/pmc_$PT" "${CNT// /,}" > "$O/pmc_${PT}_b$PB.txt" 2>&1; rm -rf "$O/pmc_$PT"; head -40 "$O/pmc_${PT}_b$PB.txt" ;;
     *) echo "unknown step $step" ;;
   esac
 done

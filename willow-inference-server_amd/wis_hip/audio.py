@@ -10,6 +10,7 @@ semantics exactly (wis/audio.py:28-51, 119-134, 139-159).  `load_audio` replaces
 `librosa.load(audio_file, sr=16000, mono=True)` call of main.py:579 (container decode in C, channel mix, resampling to 16 kHz).
 """
 import ctypes as C
+import threading
 import math
 
 import numpy as np
@@ -162,11 +163,22 @@ class MelStream:
     the address of the f32 [80, 3000] features in HBM (valid until reset / close): `Whisper.generate_from_device` consumes it
     without the features ever visiting the host."""
 
+    # idle native handles per device: creating one costs five device allocations, a stream and a pinned block, destroying one as
+    # many (synchronising) frees - milliseconds each, and a streaming session opens a window every 14 s of audio and closes it on the
+    # latency path of stop().  close() therefore parks the handle here (reset) and the next MelStream on that GPU takes it over.
+    _idle, _idle_lock, _IDLE_MAX = {}, threading.Lock(), 16
+
     def __init__(self, device=0):
         _lib.require_gpu()
         self.device = int(device)
-        self._h = C.c_void_p()
-        _lib.check(_lib.load().wis_melstream_create(self.device, C.byref(self._h)))
+        self._h = None
+        with MelStream._idle_lock:
+            pool = MelStream._idle.get(self.device)
+            if pool:
+                self._h = pool.pop()
+        if self._h is None:
+            self._h = C.c_void_p()
+            _lib.check(_lib.load().wis_melstream_create(self.device, C.byref(self._h)))
         self.device_ptr = None
 
     def feed(self, samples):
@@ -194,9 +206,21 @@ class MelStream:
         return int(_lib.load().wis_melstream_tiles_done(self._h))
 
     def close(self):
-        if self._h:
-            _lib.load().wis_melstream_destroy(self._h)
-            self._h = C.c_void_p()
+        """Give the window up: its features (device_ptr) are no longer valid.  The native handle is reset and parked for reuse."""
+        h, self._h = self._h, None
+        self.device_ptr = None
+        if not h:
+            return
+        try:
+            if _lib.load().wis_melstream_reset(h) == 0:
+                with MelStream._idle_lock:
+                    pool = MelStream._idle.setdefault(self.device, [])
+                    if len(pool) < MelStream._IDLE_MAX:
+                        pool.append(h)
+                        return
+        except Exception:
+            pass
+        _lib.load().wis_melstream_destroy(h)
 
     def __del__(self):
         try:
