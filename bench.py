@@ -444,7 +444,7 @@ def main():
         per_launch_us = 1e3 * ms.value / (passes * nl.value)
         achieved = nb.value / nl.value / (per_launch_us * 1e-6) / 1e9
         traffic = None
-        for name in ("r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/pmc_gemv.sh)
+        for name in ("r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -459,6 +459,9 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "bytes_per_launch": round(nb.value / nl.value), "avg_launch_us": round(per_launch_us, 3),
                     "launches_per_decode_step": nl.value,
+                    "how": "wis_bench_weight_stream: one launch of the skinny GEMM per decoder weight matrix (6 per layer + the vocabulary projection = one decode step's weight stream, 1.6 GB), "
+                           "captured into a HIP graph and replayed like the product's decode step, HIP events on the model's stream; the tap launches the un-folded matrix set on zero rows "
+                           "(the product's step fuses the out-projection with the folded cross-Q in gemv_dual_kernel: same kernel body, 6.6 instead of 3.3 + 3.3 MB in that launch)",
                     "decode_step": {"ms": round(step_ms, 4), "algorithmic_bytes": round(step_bytes), "achieved_GBps": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
                                     "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                     "encoder": {"bound": "mfma", "gflop": 2587.3 if args.model == "large" else None,
@@ -502,6 +505,13 @@ def main():
                     row["utterances_per_s"] = round(1e3 * Bc / p50(lc), 1)
                     row["decode_step"] = {"ms": round(tm["decode_ms"] / sd, 4), "algorithmic_bytes": round(sb),
                                           "frac_of_hbm_peak": round(sb / (tm["decode_ms"] / sd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    if Bc == 8:
+                        try:      # HBM traffic of the step's two byte-heavy kernels from the --pmc passes (profiles/r03_pmc_decode.json)
+                            b8 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_decode.json")))["batch_8"]
+                            row["decode_step"]["traffic_over_algorithmic"] = {"skinny_gemm (gemv_frag_kernel)": b8["skinny_gemm_traffic_over_algorithmic"],
+                                                                              "cross_attention": b8["per_kernel"]["dec_cross_attn_kernel 245760"]["traffic_over_algorithmic"]}
+                        except Exception:
+                            pass
                 cfgs.append(row)
             except Exception as e:
                 cfgs.append({"config": name, "failed": repr(e)})

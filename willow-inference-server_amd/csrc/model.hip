@@ -1184,10 +1184,26 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   WIS_HIP_CHECK(hipMemsetAsync(m->dx, 0, (size_t)MAX_ROWS * d * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->dh, 0, (size_t)MAX_ROWS * 4 * d * 2, st));
   WIS_RET(pass(true));   // warm-up pass (also counts launches / bytes)
-  WIS_HIP_CHECK(hipEventRecord(m->ev[6], st));
-  for (int i = 0; i < passes; ++i) WIS_RET(pass(false));
-  WIS_HIP_CHECK(hipEventRecord(m->ev[7], st));
-  WIS_HIP_CHECK(hipStreamSynchronize(st));
+  // the timed passes run the way the product runs these kernels: captured once into a HIP graph and replayed (wis_generate replays
+  // its decode step as a graph); WIS_NO_GRAPH=1 (profilers that cannot follow a capture) falls back to eager launches
+  hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+  if (m->use_graph) {
+    WIS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = pass(false);
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc || e != hipSuccess) { if (graph) hipGraphDestroy(graph); if (rc) return rc; set_error("weight-stream tap: graph capture failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+    if (hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(graph); set_error("weight-stream tap: graph instantiate failed"); return WIS_E_HIP; }
+    hipGraphDestroy(graph);
+    if (hipGraphLaunch(gexec, st) != hipSuccess) { hipGraphExecDestroy(gexec); set_error("weight-stream tap: graph launch failed"); return WIS_E_HIP; }      // untimed first replay
+  }
+  int rc2 = WIS_OK;
+  hipError_t e2 = hipEventRecord(m->ev[6], st);
+  for (int i = 0; i < passes && !rc2 && e2 == hipSuccess; ++i) { if (gexec) e2 = hipGraphLaunch(gexec, st); else rc2 = pass(false); }
+  if (e2 == hipSuccess) e2 = hipEventRecord(m->ev[7], st);
+  if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+  if (gexec) hipGraphExecDestroy(gexec);
+  WIS_RET(rc2);
+  WIS_HIP_CHECK(e2);
   WIS_HIP_CHECK(hipEventElapsedTime(total_ms, m->ev[6], m->ev[7]));
   if (launches_per_pass) *launches_per_pass = launches;
   if (bytes_per_pass) *bytes_per_pass = bytes;

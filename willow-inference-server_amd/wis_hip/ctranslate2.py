@@ -179,7 +179,7 @@ def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_bl
 
 MAX_DECODER_ROWS = 96      # csrc/kernels.hpp MAX_ROWS: decoder rows per device pass
 MAX_BEAM = 8               # csrc/kernels.hpp MAX_R: rows per utterance (beam size)
-MAX_REPLICAS_PER_DEVICE = 3   # default ceiling for inter_threads -> replicas per GPU (measured: bench.py "concurrent_device_batches")
+MAX_REPLICAS_PER_DEVICE = 4   # default ceiling for inter_threads -> replicas per GPU (measured on MI355X, bench.py "concurrent_device_batches": 118 / 152 / 165 / 173 / 160 utterances/s with 1..5 batches of 8 in flight)
 MAX_PROMPT = 16            # wis_generate: prompt tokens per utterance
 
 

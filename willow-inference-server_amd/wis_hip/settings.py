@@ -48,7 +48,7 @@ class APISettings:
     max_batch: int = 8
     # replicas per GPU sharing one weight copy, each with its own stream / activations / KV caches: `ctranslate2_threads` (the
     # reference's inter_threads) device batches run concurrently per GPU, up to this many
-    replicas_per_gpu: int = 3
+    replicas_per_gpu: int = 4
     # largest beam_size a request may ask for (sizes the KV-cache slots: max_batch * max_beam); the engine's ceiling is 8
     # (csrc/kernels.hpp MAX_R) - a larger per-request beam_size is answered with HTTP 400, not a 500
     max_beam: int = 8
