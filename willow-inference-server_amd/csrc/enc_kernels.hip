@@ -354,7 +354,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p, Epi epi) {
 // conflict-free for the four 16-lane groups a ds_read_b128 is served in.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-template <class Epi>
+// TR: the MFMA operands are swapped - D[i = row][j = feature] - and the tile leaves through Epi::store_t (4 consecutive ROWS of one feature per
+// lane): the transposed V images of the QKV and cross-K/V projections, whose plain layout would scatter single 2-byte stores.  A launch is
+// either all plain or all transposed tiles (GemmP::n_span / n_period / n_phase select its output columns).
+template <class Epi, bool TR>
 __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
   constexpr int BM_ = 256, BN_ = 256, HALF = 128 * 64, BUF = 4 * HALF;
   __shared__ __attribute__((aligned(1024))) f16 smem[2 * BUF];      // ONE LDS object (a second one makes hipcc drain vmcnt before fragment reads)
@@ -376,9 +379,14 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
     const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
     m0 = (wg % nmt) * BM_; n0 = (wg / nmt) * BN_;
+    if (p.n_span) n0 = (n0 / p.n_span) * p.n_period + p.n_phase + n0 % p.n_span;      // (n_span is a multiple of the tile width)
     auto src = [&](int j, const f16** nl, const f16** nh, const f16** ml, const f16** mh) {
       const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
-      const int n = n0 + (rl >> 5) * 64 + (rl & 31);
+      // which weight row feeds MFMA row i of 16-row block nb of a wave's 32-row half: 8 (i >> 2) + 4 nb + (i & 3), so that the lane
+      // holding MFMA rows 4 kq .. 4 kq + 3 of BOTH blocks of a half owns the 8 consecutive features 8 kq .. 8 kq + 7 - its two
+      // accumulator quads leave as one 16-byte store (the epilogue is store-issue-bound: half the instructions for the f16 outputs)
+      const int i16 = rl & 15, nb16 = (rl >> 4) & 1;
+      const int n = n0 + (rl >> 5) * 64 + 8 * (i16 >> 2) + 4 * nb16 + (i16 & 3);
       *nl = p.W + (int64_t)n * p.K + kbeg + c * 8;
       *nh = p.W + (int64_t)(n + 32) * p.K + kbeg + c * 8;
       int mlo = m0 + (rl >> 6) * 128 + (rl & 63), mhi = mlo + 64;
@@ -410,7 +418,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
       _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) \
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
-          acc[(MB0) + mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], MF[mb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0); \
+          acc[(MB0) + mb][(NB0) + nb] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(MF[mb][kb], NF[nb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0) \
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], MF[mb][kb], acc[(MB0) + mb][(NB0) + nb], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
   int v = blockIdx.x;
@@ -481,13 +490,27 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
     const int mt = m0, ntl = n0, vn = v + (int)gridDim.x;
     const bool more = vn < nwg;
     if (more) { setup(vn); WIS_PROLOGUE(); }
-    // D[i = n][j = m]: lane holds m = l15, n = 4 kq + r
+    if (TR) {
+      // D[i = row][j = MFMA column]: lane holds rows 4 kq + r of row block mb and MFMA column l15 of block nb = feature 8 (l15 >> 2) + 4 (nb & 1) + (l15 & 3) of half nb >> 1
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        const int m = mt + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + 4 * kq;
+        if (m < p.M) {      // (M is a multiple of 4 wherever a transposed epilogue exists: M = utterances x 1500)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) epi.store_t(m, ntl + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3), acc[mb][nb]);
+        }
+      }
+      if (!more) break;
+      v = vn;
+      continue;
+    }
+    // D[i = MFMA row][j = m]: lane holds m = l15 and MFMA rows 4 kq + r of the blocks 2 h, 2 h + 1 = features 8 kq + 4 (nb & 1) + r of half h
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       const int m = mt + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
       if (m < p.M) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) epi(m, ntl + wc * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + 4 * kq, acc[mb][nb]);
+        for (int h = 0; h < 2; ++h) epi(m, ntl + wc * 64 + h * 32 + 8 * kq, acc[mb][2 * h], acc[mb][2 * h + 1]);
       }
     }
     if (!more) break;
@@ -521,6 +544,33 @@ static void gemm_pick_tile(const GemmP& p, int* bm, int* bn) {
   *bm = small ? 64 : 128; *bn = 128;
 }
 
+// One launch of the 8-phase kernel over `q`'s columns (persistent over tiles: at most one workgroup per CU, a multiple of 8 so that a
+// workgroup's tiles stay on its XCD's share)
+template <class Epi, bool TR>
+static void launch_8p_part(hipStream_t st, const GemmP& q, const Epi& epi) {
+  static const bool persist = !(getenv("WIS_GEMM_PERSIST") && atoi(getenv("WIS_GEMM_PERSIST")) == 0);
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256; n_cu = v & ~7; }
+  dim3 g8((q.N / 256) * cdiv(q.M, 256), 1, q.klen > 0 ? q.K / q.klen : 1);
+  if (persist && (int)g8.x > n_cu) g8.x = n_cu;
+  hipLaunchKernelGGL((gemm_8p_kernel<Epi, TR>), g8, dim3(512), 0, st, q, epi);
+}
+// Functors with a transposed part (Epi::HAS_T: the V images) get TWO launches - their plain columns, then their transposed columns with
+// swapped MFMA operands; Epi::split describes the two column sets.
+template <class Epi>
+static int launch_gemm_8p(hipStream_t st, const GemmP& p, const Epi& epi) {
+  if constexpr (Epi::HAS_T) {
+    GemmP a = p, b = p;
+    epi.split(p.N, &a, &b);
+    if (a.N % 256 || b.N % 256 || a.n_span % 256 || b.n_span % 256) { set_error("gemm_8p: column split %d / %d not tile aligned", a.N, b.N); return WIS_E_UNSUPPORTED; }
+    launch_8p_part<Epi, false>(st, a, epi);
+    launch_8p_part<Epi, true>(st, b, epi);
+  } else {
+    launch_8p_part<Epi, false>(st, p, epi);
+  }
+  return WIS_OK;
+}
+
 template <class Epi>
 static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   if (p.N % 128 || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
@@ -529,15 +579,7 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   // 256 x 256: the 8-phase LDS-DMA kernel (WIS_GEMM_8P=0: the register-staged 2 x 4-wave tile, A/B tuning switch); it needs two k-tiles
   static const bool use_8p = !(getenv("WIS_GEMM_8P") && atoi(getenv("WIS_GEMM_8P")) == 0);
   const int nk_ = (p.klen > 0 ? p.klen : p.K) / BK;
-  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) {
-    // persistent over tiles: at most one workgroup per CU (a multiple of 8, so that a workgroup's tiles stay on its XCD's share)
-    static const bool persist = !(getenv("WIS_GEMM_PERSIST") && atoi(getenv("WIS_GEMM_PERSIST")) == 0);
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256; n_cu = v & ~7; }
-    dim3 g8 = grid;
-    if (persist && (int)grid.x > n_cu) g8.x = n_cu;
-    hipLaunchKernelGGL((gemm_8p_kernel<Epi>), g8, dim3(512), 0, st, p, epi);
-  }
+  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) return launch_gemm_8p(st, p, epi);
   else if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
@@ -548,10 +590,16 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return f32x4{t.x, t.y, t.z, t.w}; }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void st4h(f16* p, f32x4 v) { f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; *reinterpret_cast<f16x4*>(p) = o; }
+__device__ __forceinline__ void st8h(f16* p, f32x4 a, f32x4 b) {      // 8 consecutive f16 = one 16-byte store
+  f16x8 o = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
+  *reinterpret_cast<f16x8*>(p) = o;
+}
 __device__ __forceinline__ f32x4 gelu4(f32x4 v) { return f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])}; }
 
 // generic runtime-flag epilogue (wis_op_gemm, FFN, out-proj)
 struct EpiGeneric {
+  static constexpr bool HAS_T = false;
+  __device__ void store_t(int, int, f32x4) const {}
   const float* bias; const float* resid; void* C; int N; int flags;  // 1 gelu, 2 resid, 4 out f32
   __device__ void operator()(int m, int n, f32x4 v) const {
     if (bias) v += ld4(bias + n);
@@ -560,18 +608,35 @@ struct EpiGeneric {
     if (flags & 2) v += ld4(resid + o);
     if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
   }
+  // 8 consecutive features of one row (the 8-phase kernel: n % 8 == 0): f16 outputs leave as ONE 16-byte store
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const {
+    if (bias) { a += ld4(bias + n); b += ld4(bias + n + 4); }
+    if (flags & 1) { a = gelu4(a); b = gelu4(b); }
+    const size_t o = (size_t)m * N + n;
+    if (flags & 2) { a += ld4(resid + o); b += ld4(resid + o + 4); }
+    if (flags & 4) { st4(reinterpret_cast<float*>(C) + o, a); st4(reinterpret_cast<float*>(C) + o + 4, b); } else st8h(reinterpret_cast<f16*>(C) + o, a, b);
+  }
 };
 // conv1: GELU(acc + b) -> f16 time-major padded image [B][T+2][N], row t+1
 struct EpiConv1 {
+  static constexpr bool HAS_T = false;
+  __device__ void store_t(int, int, f32x4) const {}
   const float* bias; f16* C; int N; int T;
   __device__ void operator()(int m, int n, f32x4 v) const {
     v = gelu4(v + ld4(bias + n));
     const int b = m / T, t = m - b * T;
     st4h(C + ((size_t)b * (T + 2) + t + 1) * N + n, v);
   }
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 c) const {
+    a = gelu4(a + ld4(bias + n)); c = gelu4(c + ld4(bias + n + 4));
+    const int b = m / T, t = m - b * T;
+    st8h(C + ((size_t)b * (T + 2) + t + 1) * N + n, a, c);
+  }
 };
 // conv2: GELU(acc + b) + pos[t] -> fp32 residual stream [B*T][N]
 struct EpiConv2 {
+  static constexpr bool HAS_T = false;
+  __device__ void store_t(int, int, f32x4) const {}
   const float* bias; const float* pos; float* X; int N; int T;
   __device__ void operator()(int m, int n, f32x4 v) const {
     v = gelu4(v + ld4(bias + n));
@@ -579,9 +644,23 @@ struct EpiConv2 {
     v += ld4(pos + (size_t)t * N + n);
     st4(X + (size_t)m * N + n, v);
   }
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
 };
 // fused QKV: [Q*s | K] -> f16 [M][2d]; V -> V^T f16 [B][H][64][Tpad]
 struct EpiQKV {
+  // V tiles of the 8-phase kernel run their MFMAs with the operands swapped (D transposed): a lane then holds 4 CONSECUTIVE rows (keys) of
+  // one feature, i.e. 8 contiguous bytes of the transposed V image instead of four scattered 2-byte stores
+  static constexpr bool HAS_T = true;
+  void split(int N, GemmP* plain, GemmP* tr) const {      // [Q | K] = columns [0, 2d) plain, V = [2d, 3d) transposed
+    plain->N = 2 * d; plain->n_span = 2 * d; plain->n_period = 0; plain->n_phase = 0;
+    tr->N = N - 2 * d; tr->n_span = N - 2 * d; tr->n_period = 0; tr->n_phase = 2 * d;
+  }
+  __device__ void store_t(int m, int n, f32x4 v) const {      // rows m .. m + 3 (m % 4 == 0: one utterance, one 4-group of the key swizzle) of feature n
+    const float bv = bias[n];
+    const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
+    const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+    st4h(vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+  }
   const float* bias; f16* qk; f16* vt; int d; int T; int Tpad; int H;
   __device__ void operator()(int m, int n, f32x4 v) const {
     v += ld4(bias + n);
@@ -595,6 +674,10 @@ struct EpiQKV {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
   }
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const {
+    // only reached for the Q | K tiles (the 8-phase kernel sends the V tiles through store_t)
+    a += ld4(bias + n); b += ld4(bias + n + 4); st8h(qk + (size_t)m * 2 * d + n, a, b);
+  }
 };
 // cross-attention K/V projection of the encoder memory for ONE decoder layer:
 //   K -> Kx f16 [B][H][8][T][8]    (16-byte dh-groups contiguous along T = the MFMA A-fragment rows of the decode kernel)
@@ -604,6 +687,16 @@ struct EpiQKV {
 // 256-wide tile never straddles layers because 2d is a multiple of 256 for every Whisper size but tiny (768: multiple of 128
 // and of 256).
 struct EpiCrossKV {
+  static constexpr bool HAS_T = true;
+  void split(int N, GemmP* plain, GemmP* tr) const {      // per layer: K = columns [0, d) plain, V = [d, 2d) transposed; N = layers x 2d
+    plain->N = N / 2; plain->n_span = d; plain->n_period = 2 * d; plain->n_phase = 0;
+    tr->N = N / 2; tr->n_span = d; tr->n_period = 2 * d; tr->n_phase = d;
+  }
+  __device__ void store_t(int m, int n_all, f32x4 v) const {
+    const float bv = bias[n_all];
+    const int l = n_all / (2 * d), nn = n_all - l * 2 * d - d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
+    st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+  }
   const float* bias; f16* kx; f16* vt; int d; int T; int Tpad; int H; int64_t kx_lstride, vt_lstride;
   __device__ void operator()(int m, int n_all, f32x4 v) const {
     v += ld4(bias + n_all);
@@ -620,12 +713,22 @@ struct EpiCrossKV {
       for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
     }
   }
+  __device__ void operator()(int m, int n_all, f32x4 a, f32x4 c) const {
+    // only reached for the K tiles (the V tiles go through store_t): the 8 values are one (t, dh-group) cell of the K image - a single 16-byte store
+    const int l = n_all / (2 * d), n = n_all - l * 2 * d;
+    a += ld4(bias + n_all); c += ld4(bias + n_all + 4);
+    const int b = m / T, t = m - b * T, h = n >> 6, g = (n & 63) >> 3;
+    st8h(kx + l * kx_lstride + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8), a, c);
+  }
 };
 
 // split-K partial tile: fp32 [blockIdx.z][M][N]
 struct EpiPartial {
+  static constexpr bool HAS_T = false;
+  __device__ void store_t(int, int, f32x4) const {}
   float* C; int N; int64_t zstride;
   __device__ void operator()(int m, int n, f32x4 v) const { st4(C + (int64_t)blockIdx.z * zstride + (size_t)m * N + n, v); }
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
 };
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t zstride, const float* __restrict__ bias,
                                      const float* resid, float* X, int64_t n4, int N) {

@@ -10,6 +10,9 @@ struct GemmP {
   const f16* W;                                      // [N][K] row-major
   int M, N, K;
   int klen;                                          // split-K: K range per blockIdx.z slice (0 = whole K, gridDim.z = 1)
+  // column sub-ranges (the 8-phase kernel's separate launches for plain and transposed tiles): the launch covers N columns, column c of it
+  // is output feature (c / n_span) * n_period + n_phase + c % n_span (n_span = 0: the identity)
+  int n_span = 0, n_period = 0, n_phase = 0;
 };
 static inline GemmP gemm_plain(const f16* A, int lda, const f16* W, int M, int N, int K) {
   GemmP p; p.A = A; p.a_bs = 0; p.a_rs = lda; p.a_rpb = 0x7fffffff; p.W = W; p.M = M; p.N = N; p.K = K; p.klen = 0; return p;
