@@ -562,7 +562,7 @@ static int launch_gemm_8p(hipStream_t st, const GemmP& p, const Epi& epi) {
   if constexpr (Epi::HAS_T) {
     GemmP a = p, b = p;
     epi.split(p.N, &a, &b);
-    if (a.N % 256 || b.N % 256 || a.n_span % 256 || b.n_span % 256) { set_error("gemm_8p: column split %d / %d not tile aligned", a.N, b.N); return WIS_E_UNSUPPORTED; }
+    if (a.N % 256 || b.N % 256 || a.n_span % 256 || b.n_span % 256) return 1;      // column sets not tile aligned (d = 384): the caller takes the register-staged tile
     launch_8p_part<Epi, false>(st, a, epi);
     launch_8p_part<Epi, true>(st, b, epi);
   } else {
@@ -579,14 +579,16 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   // 256 x 256: the 8-phase LDS-DMA kernel (WIS_GEMM_8P=0: the register-staged 2 x 4-wave tile, A/B tuning switch); it needs two k-tiles
   static const bool use_8p = !(getenv("WIS_GEMM_8P") && atoi(getenv("WIS_GEMM_8P")) == 0);
   const int nk_ = (p.klen > 0 ? p.klen : p.K) / BK;
-  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) return launch_gemm_8p(st, p, epi);
-  else if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
+  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) {
+    const int rc = launch_gemm_8p(st, p, epi);
+    if (rc <= 0) return rc;
+  }
+  if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
   else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   return WIS_OK;
 }
-
 __device__ __forceinline__ f32x4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return f32x4{t.x, t.y, t.z, t.w}; }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void st4h(f16* p, f32x4 v) { f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; *reinterpret_cast<f16x4*>(p) = o; }
