@@ -49,6 +49,7 @@ while [ $# -gt 0 ]; do
       DB=$(find "$O/prof_b$B" -name "*.db" | head -1)
       python tools/prof_summary.py "$DB" 45 > "$O/kernel_stats_b$B.txt" 2>&1
       python tools/prof_summary.py "$DB" 45 --by-grid > "$O/kernels_by_grid_b$B.txt" 2>&1
+      [ "$B" = 1 ] && python tools/spread.py "$DB" 32 > "$O/spread_b1.txt" 2>&1
       find "$O/prof_b$B" -name "*.db" -delete
       head -30 "$O/kernel_stats_b$B.txt" ;;
     pmc)      # pmc <tag> "<COUNTER ...>" [batch]: ONE rocprofv3 --pmc pass (counters only with --kernel-trace, as gpurun requires) of the eager bench
