@@ -244,6 +244,11 @@ int wis_op_dec_self_attn(int device, const float* q, const void* kc_f16, const v
  * vt f16 [B][H][64][Tpad] (V transposed, zero padded to Tpad = T rounded up to 64) -> out f16 [B*R][d]. */
 int wis_op_dec_cross_attn(int device, const float* q, const void* kx_f16, const void* vt_f16, void* out_f16,
                           int B, int R, int H, int T, int chunks);
+/* the same with the LayerNorm-folded query of the one-utterance decode step (model.hip fused_out_cq): q_raw f32 [B*R][d] is the folded
+ * projection of the UN-normalised rows, xres f32 [B*R][d] the rows themselves; the kernel reduces mean / rstd of every row and
+ * finishes q = rstd (q_raw - mean qcs) + qb (qcs, qb f32 [d]: column sums and bias of the folded projection).  R <= 8, d <= 1280. */
+int wis_op_dec_cross_attn_folded(int device, const float* q_raw, const float* xres, const float* qcs, const float* qb,
+                                 const void* kx_f16, const void* vt_f16, void* out_f16, int B, int R, int H, int T, int chunks);
 
 #ifdef __cplusplus
 }

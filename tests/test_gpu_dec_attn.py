@@ -96,3 +96,42 @@ def test_dec_cross_attn_vs_fp64(H, B, R, chunks, lib):
     print(f"cross-attn H={H} B={B} R={R} chunks={chunks}: max abs err {err:.2e}")
     # P is rounded to f16 before the P.V MFMA (relative 5e-4 per term, averaged over the keys) + the f16 output rounding
     assert err <= 3e-3, (H, B, R, chunks, err)
+
+
+@pytest.mark.parametrize("offset", [0.0, 1000.0])
+@pytest.mark.parametrize("B,R", [(1, 5), (1, 8), (3, 5)])
+def test_dec_cross_attn_folded_query_vs_fp64(B, R, offset, lib):
+    """The one-utterance decode step's cross-attention finishes its own query: q = rstd (q_raw - mean qcs) + qb from the
+    un-normalised rows `xres` (model.hip fused_out_cq).  With offset = 1000 the rows have |mean| = 1000 against a spread of 2.4: an
+    unshifted E[x^2] - mean^2 loses the variance in fp32 (rstd off by ~10 %); the kernel shifts by the row's first element."""
+    from wis_hip import _lib
+    H, T = 20, 1500
+    d = 64 * H
+    Tpad = (T + 63) // 64 * 64
+    rng = np.random.default_rng(91 + 7 * B + R + int(offset))
+    K = (rng.standard_normal((B, T, d)) * 0.6).astype(np.float16)
+    V = rng.standard_normal((B, T, d)).astype(np.float16)
+    xres = (offset + rng.integers(-16, 17, size=(B * R, d)) / 4.0).astype(np.float32)
+    xres[:, ::5] += 6.0
+    qcs = rng.standard_normal(d).astype(np.float32)
+    qb = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    mu = xres.astype(np.float64).mean(1, keepdims=True)
+    rs = 1.0 / np.sqrt(xres.astype(np.float64).var(1, keepdims=True) + 1e-5)
+    q_want = rng.standard_normal((B * R, d)) * 0.5
+    q_raw = ((q_want - qb) / rs + mu * qcs).astype(np.float32)
+    q = rs * (q_raw.astype(np.float64) - mu * qcs.astype(np.float64)) + qb          # what the fp32 inputs define
+    kx, vt = _cross_layouts(K, V, T, Tpad)
+    bufs = [_lib.DevBuf.from_numpy(a) for a in (q_raw, xres, qcs, qb, kx, vt)]
+    d_out = _lib.DevBuf(B * R * d * 2)
+    _lib.check(lib.wis_op_dec_cross_attn_folded(0, *[b.ptr for b in bufs], d_out.ptr, B, R, H, T, 6))
+    got = d_out.to_numpy(np.float16, (B * R, d)).astype(np.float64)
+    exp = np.zeros((B * R, d))
+    for b in range(B):
+        for h in range(H):
+            sl = slice(64 * h, 64 * h + 64)
+            s = q[b * R:(b + 1) * R, sl] @ K[b, :, sl].astype(np.float64).T
+            exp[b * R:(b + 1) * R, sl] = _softmax(s) @ V[b, :, sl].astype(np.float64)
+    err = np.abs(got - exp).max()
+    print(f"folded-query cross-attn B={B} R={R} offset={offset}: max abs err {err:.2e}")
+    # the unfolded tap's 3e-3 + the f16 cast of the finished query (the other tap's q is f16-representable by construction)
+    assert err <= 5e-3, (B, R, offset, err)

@@ -627,15 +627,14 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   const bool ln = p.flags & GV_LN;
   const int nq = K >> 6;                                      // (K/16) partial pairs per row, a quarter per lane
   // LayerNorm statistics from the row's per-16-column partials (sum, M2 about the tile's own mean - see the residual epilogue
-  // below): pairs merge like Welford / Chan states, so a row whose mean is large against its spread loses nothing to the
-  // E[x^2] - mu^2 cancellation (the <= 8-row kernel shifts by x[r][0] for the same reason).  K = 1280 keeps the lane's 20 pairs
-  // in registers between the two passes; other widths and the > 64-row forms re-read them (L1 hits).
-  constexpr bool SREG = PF == 10 && EPN == 1;
-  constexpr int NQR = SREG ? 20 : 1;
-  float2 spr[NQR];
+  // below): pairs merge like Welford / Chan states, in ONE pass about a shift c = the mean of the row's first tile:
+  //   mu = c + mean_t(m_t - c),   M2 = sum_t (M2_t + 16 (m_t - c)^2) - K (mu - c)^2
+  // so a row whose mean is large against its spread loses nothing to the E[x^2] - mu^2 cancellation (|mu - c| is of the order of
+  // the row's own spread; the <= 8-row kernel shifts by x[r][0] for the same reason), and both sums are ready before the reduction
+  // barrier (a second pass about the exact mean put a dependent lane exchange + 20 more reads behind it).
   bool ep_act[EPN], ep_ok[EPN]; int ep_m[EPN];
   float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
-  float4 ep_res[EPN]; int ep_slot[EPN], ep_pos[EPN]; float s1[EPN]; const float2* sp[EPN];
+  float4 ep_res[EPN]; int ep_slot[EPN], ep_pos[EPN]; float s1[EPN], s2[EPN], sc0[EPN];
   if (ep_n < p.N) {
     if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);
     if (ln) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);
@@ -645,17 +644,23 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   for (int e = 0; e < EPN; ++e) {
     const int mb = wave + 4 * e;
     ep_act[e] = mb < MB; ep_m[e] = mb * 16 + l15; ep_ok[e] = ep_act[e] && ep_m[e] < M && ep_n < p.N;
-    ep_res[e] = make_float4(0.f, 0.f, 0.f, 0.f); ep_slot[e] = 0; ep_pos[e] = 0; s1[e] = 0.f; sp[e] = nullptr;
+    ep_res[e] = make_float4(0.f, 0.f, 0.f, 0.f); ep_slot[e] = 0; ep_pos[e] = 0; s1[e] = 0.f; s2[e] = 0.f; sc0[e] = 0.f;
     if (ep_act[e]) {
       const int mm = ep_m[e] < M ? ep_m[e] : M - 1;
       if (ln) {       // this lane sums a quarter of the row's partials (rows >= M: a clamped duplicate, discarded)
-        sp[e] = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4) + (size_t)kq * nq;
-        if (SREG) {
+        const float2* row = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4);
+        const float2* sp = row + (size_t)kq * nq;
+        const float c = row[0].x * 0.0625f;
+        sc0[e] = c;
+        if (PF == 10) {      // K = 1280: the lane's 20 pairs, all requested at once
+          float2 spr[20];
 #pragma unroll
-          for (int i = 0; i < NQR; ++i) { spr[i] = sp[e][i]; s1[e] += spr[i].x; }
+          for (int i = 0; i < 20; ++i) spr[i] = sp[i];
+#pragma unroll
+          for (int i = 0; i < 20; ++i) { const float dm = spr[i].x * 0.0625f - c; s1[e] += dm; s2[e] += spr[i].y + 16.0f * dm * dm; }
         } else {
 #pragma unroll 4
-          for (int i = 0; i < nq; ++i) s1[e] += sp[e][i].x;
+          for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; const float dm = v.x * 0.0625f - c; s1[e] += dm; s2[e] += v.y + 16.0f * dm * dm; }
         }
       }
       if (ep_ok[e]) {
@@ -680,22 +685,12 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
     }
     if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
     if (ln) {     // the four lanes of a row (kq = 0..3) hold a quarter of its sums each: ((q0 + q1) + (q2 + q3)) on every lane
-      float t1 = s1[e];
-      t1 += __shfl_xor(t1, 16);
-      t1 += __shfl_xor(t1, 32);
+      float t1 = s1[e], t2 = s2[e];
+      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
       const float invK = 1.0f / (float)K;
-      const float mu = t1 * invK;
-      float s2 = 0.f;      // second pass over the partials: M2 = sum_tiles ( M2_tile + 16 (mean_tile - mu)^2 )
-      if (SREG) {
-#pragma unroll
-        for (int i = 0; i < NQR; ++i) { const float dm = spr[i].x * 0.0625f - mu; s2 += spr[i].y + 16.0f * dm * dm; }
-      } else {
-#pragma unroll 4
-        for (int i = 0; i < nq; ++i) { const float2 v = sp[e][i]; const float dm = v.x * 0.0625f - mu; s2 += v.y + 16.0f * dm * dm; }
-      }
-      s2 += __shfl_xor(s2, 16);
-      s2 += __shfl_xor(s2, 32);
-      const float rs = 1.0f / sqrtf(s2 * invK + 1e-5f);
+      const float dmu = t1 * 16.0f * invK, mu = sc0[e] + dmu;      // K / 16 tiles
+      const float rs = 1.0f / sqrtf(fmaxf(t2 * invK - dmu * dmu, 0.f) + 1e-5f);
       s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
     }
     s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
@@ -1023,7 +1018,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       const int r = wave + 4 * j;
       const float4* xr = reinterpret_cast<const float4*>(xres) + (size_t)(b * R + (r < R ? r : R - 1)) * d4;
 #pragma unroll
-      for (int i = 0; i < NXS; ++i) { const int c4 = lane + 64 * i; xs4[j][i] = make_float4(0.f, 0.f, 0.f, 0.f); if (c4 < d4) xs4[j][i] = xr[c4]; }
+      for (int i = 0; i < NXS; ++i) { const int c4 = lane + 64 * i; xs4[j][i] = xr[c4 < d4 ? c4 : d4 - 1]; }      // unconditional (clamped; masked in the sums): no exec-masked branch between the loads
     }
     const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
     cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
@@ -1050,22 +1045,23 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     // barrier - `__syncthreads()` would first wait for every outstanding load, i.e. for the K / V fragments this prologue is
     // supposed to run in the shadow of (measured with three `__syncthreads()` here: cross-attention 9.0 -> 12.1 us)
     __shared__ float srow[16][2];
+    __builtin_amdgcn_sched_barrier(0);      // every load of the kernel is requested above this line: the statistics wait for their rows only
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = wave + 4 * j;
       float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < NXS; ++i) { const float4 v = xs4[j][i]; a1 += (v.x + v.y) + (v.z + v.w); }
-      a1 = wave_sum(a1);
-      const float mu = a1 / (float)d;       // two passes over the registers: no E[x^2] - mu^2 cancellation for rows with a large mean
+      // ONE pass, shifted by the row's first element: no E[x^2] - mu^2 cancellation for rows with a large common offset, and both
+      // wave reductions issue together (a second pass over the registers about the exact mean measured +2.3 us per launch)
+      const float c0 = readlane_f(xs4[j][0].x, 0);
 #pragma unroll
       for (int i = 0; i < NXS; ++i) {
         const float4 v = xs4[j][i];
-        const float a = v.x - mu, b = v.y - mu, c = v.z - mu, e = v.w - mu;
-        a2 += (lane + 64 * i < d4) ? (a * a + b * b) + (c * c + e * e) : 0.f;
+        const bool in = lane + 64 * i < d4;
+        const float a = in ? v.x - c0 : 0.f, b = in ? v.y - c0 : 0.f, c = in ? v.z - c0 : 0.f, e = in ? v.w - c0 : 0.f;
+        a1 += (a + b) + (c + e); a2 += (a * a + b * b) + (c * c + e * e);
       }
-      a2 = wave_sum(a2);
-      if (lane == 0 && r < R) { srow[r][0] = mu; srow[r][1] = 1.0f / sqrtf(a2 / (float)d + 1e-5f); }
+      a1 = wave_sum(a1); a2 = wave_sum(a2);
+      if (lane == 0 && r < R) { const float ms = a1 / (float)d; srow[r][0] = c0 + ms; srow[r][1] = 1.0f / sqrtf(fmaxf(a2 / (float)d - ms * ms, 0.f) + 1e-5f); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float mu = srow[rq][0], rs = srow[rq][1];

@@ -1345,7 +1345,8 @@ int wis_op_dec_self_attn(int device, const float* q, const void* kc, const void*
   WIS_HIP_CHECK(hipStreamSynchronize(ctx_stream(c)));
   return WIS_OK;
 }
-int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void* vt, void* out, int B, int R, int H, int T, int chunks) {
+static int op_dec_cross_attn(int device, const float* q, const float* xres, const float* qcs, const float* qb, const void* kx, const void* vt, void* out,
+                             int B, int R, int H, int T, int chunks) {
   DeviceCtx* c; WIS_RET(get_ctx(device, &c));
   std::lock_guard<std::mutex> op_lock(ctx_op_mutex(c));
   if (!q || !kx || !vt || !out || B < 1 || H < 1 || T < 1) { set_error("wis_op_dec_cross_attn: bad argument"); return WIS_E_ARG; }
@@ -1363,7 +1364,7 @@ int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void
     if (small) { hipMemsetAsync(gran, 0, (size_t)B * H * 6 * 8 * 66 * 8, st); hipMemsetAsync(epoch, 0, ((size_t)B * H + 1) * 4, st); }
     for (int rep = 0; rep < 3 && !rc; ++rep)      // three launches: the epochs of the granule form advance from launch to launch
       rc = launch_dec_cross_attn(st, q, reinterpret_cast<const f16*>(kx), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), part, counters,
-                                 B, R, H, 64 * H, T, cdiv(T, 64) * 64, chunks, nullptr, 0, nullptr, nullptr, nullptr, gran, epoch);
+                                 B, R, H, 64 * H, T, cdiv(T, 64) * 64, chunks, nullptr, 0, xres, qcs, qb, gran, epoch);
     if (small && !rc) hipMemcpyAsync(&flag, epoch, 4, hipMemcpyDeviceToHost, st);
   }
   hipError_t e = hipStreamSynchronize(st);
@@ -1372,6 +1373,14 @@ int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void
   if (flag) { set_error("wis_op_dec_cross_attn: granule hand-off timed out"); return WIS_E_HIP; }
   if (e != hipSuccess) { set_error("wis_op_dec_cross_attn: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;
+}
+int wis_op_dec_cross_attn(int device, const float* q, const void* kx, const void* vt, void* out, int B, int R, int H, int T, int chunks) {
+  return op_dec_cross_attn(device, q, nullptr, nullptr, nullptr, kx, vt, out, B, R, H, T, chunks);
+}
+int wis_op_dec_cross_attn_folded(int device, const float* q_raw, const float* xres, const float* qcs, const float* qb, const void* kx, const void* vt, void* out,
+                                 int B, int R, int H, int T, int chunks) {
+  if (!xres || !qcs || !qb) { set_error("wis_op_dec_cross_attn_folded: bad argument"); return WIS_E_ARG; }
+  return op_dec_cross_attn(device, q_raw, xres, qcs, qb, kx, vt, out, B, R, H, T, chunks);
 }
 
 }  // extern "C"

@@ -95,6 +95,7 @@ SYMBOLS = [
     ("wis_op_gemv", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("wis_op_dec_self_attn", _i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     ("wis_op_dec_cross_attn", _i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    ("wis_op_dec_cross_attn_folded", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
 ]
 
 _lib = None
