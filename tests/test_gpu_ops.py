@@ -58,7 +58,9 @@ def test_logmel_noise_and_batch(golden_dir):
                                          (3000, 512, 5120, 1 | 4), (77, 128, 64, 2 | 4 | 1),
                                          (1500, 1280, 5120, 2 | 4 | 8), (200, 128, 128, 2 | 4 | 8),      # split-K x2 (encoder FFN2)
                                          (1500, 1280, 1280, 2 | 4), (65, 256, 64, 0), (1500, 3840, 1280, 0), (3000, 1280, 320, 1),   # 64-row tiles; QKV / conv1 shapes
-                                         (6321, 2048, 192, 2 | 4), (12000, 1280, 128, 1)])                # 256x256 tiles, 8 waves (batched encoder), ragged M
+                                         (6321, 2048, 192, 2 | 4), (12000, 1280, 128, 1),                 # 256x256 tiles, 8 waves (batched encoder), ragged M
+                                         (1500, 5120, 1280, 1), (1411, 2560, 192, 0), (1500, 3840, 1280, 2 | 4),      # 128x256 8-phase tile (one utterance): FFN1, ragged M / 3 k-tiles, residual epilogue
+                                         (1500, 4096, 128, 1 | 4)])                                       # ... two k-tiles (the prologue alone)
 def test_gemm(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 7 + N)

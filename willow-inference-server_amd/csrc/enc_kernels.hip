@@ -437,6 +437,10 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
     int cb = 0;      // element offset of the buffer holding k-tile t
+    // the lane's bias values: requested in phase 2 of the LAST k-tile (nothing is staged there any more; its closing vmcnt(0) retires them) - a
+    // load inside the store sequence of the epilogue would cost a vmcnt(0) wait, and on gfx9 that one in-order counter also holds
+    // the stores issued before it: the epilogue would run one store round trip per row block
+    f32x4 bq[2][2]; float bt[4];
     for (int t = 0; t < nk; ++t) {
       const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
       const int ob = cb ^ BUF;      // the other buffer
@@ -467,6 +471,15 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
       WIS_MMA16(mlo, nhi, 0, 2);
       __builtin_amdgcn_s_barrier();
       // ---- phase 2
+      if (t + 1 == nk) {      // (the M-lo fragments are dead from here on: registers for the bias values)
+        if (TR) {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) bt[nb] = epi.bias1(n0 + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3));
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) { bq[h][0] = epi.bias4(n0 + wc * 64 + h * 32 + 8 * kq); bq[h][1] = epi.bias4(n0 + wc * 64 + h * 32 + 8 * kq + 4); }
+        }
+      }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -489,6 +502,16 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
     // next tile's prologue first (the k-tile buffers are free), then this tile's stores
     const int mt = m0, ntl = n0, vn = v + (int)gridDim.x;
     const bool more = vn < nwg;
+    // retire the bias loads HERE, on every path (they were requested in the last k-tile and are covered by its vmcnt(0)) - left to the
+    // compiler, each row-guarded store block below would wait for them on its own with vmcnt(0), i.e. for the stores of the block
+    // before it (and for the next tile's DMAs)
+    if (TR) { asm volatile("" :: "v"(bt[0]), "v"(bt[1]), "v"(bt[2]), "v"(bt[3])); }
+    else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(bq[h][i][0]), "v"(bq[h][i][1]), "v"(bq[h][i][2]), "v"(bq[h][i][3]));
+    }
     if (more) { setup(vn); WIS_PROLOGUE(); }
     if (TR) {
       // D[i = row][j = MFMA column]: lane holds rows 4 kq + r of row block mb and MFMA column l15 of block nb = feature 8 (l15 >> 2) + 4 (nb & 1) + (l15 & 3) of half nb >> 1
@@ -497,7 +520,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
         const int m = mt + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + 4 * kq;
         if (m < p.M) {      // (M is a multiple of 4 wherever a transposed epilogue exists: M = utterances x 1500)
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) epi.store_t(m, ntl + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3), acc[mb][nb]);
+          for (int nb = 0; nb < 4; ++nb) epi.fin_t(m, ntl + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3), acc[mb][nb], bt[nb]);
         }
       }
       if (!more) break;
@@ -505,20 +528,201 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
       continue;
     }
     // D[i = MFMA row][j = m]: lane holds m = l15 and MFMA rows 4 kq + r of the blocks 2 h, 2 h + 1 = features 8 kq + 4 (nb & 1) + r of half h
+    if constexpr (Epi::HAS_RES) {      // residual values of TWO row blocks per round (32 registers: the tile's 128 accumulators stay live), then their stores
+#pragma unroll
+      for (int rnd = 0; rnd < 4; ++rnd) {
+        f32x4 rr[2][2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          int m = mt + wr * 128 + (rnd >> 1) * 64 + ((rnd & 1) * 2 + q) * 16 + l15;
+          if (m > p.M - 1) m = p.M - 1;      // clamped, unconditional: the guard is on the stores
+#pragma unroll
+          for (int h = 0; h < 2; ++h) epi.res8(m, ntl + wc * 64 + h * 32 + 8 * kq, rr[q][h][0], rr[q][h][1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(rr[q][h][i][0]), "v"(rr[q][h][i][1]), "v"(rr[q][h][i][2]), "v"(rr[q][h][i][3]));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int mb = rnd * 2 + q, m = mt + wr * 128 + (rnd >> 1) * 64 + ((rnd & 1) * 2 + q) * 16 + l15;
+          if (m < p.M) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) epi.fin2(m, ntl + wc * 64 + h * 32 + 8 * kq, acc[mb][2 * h], acc[mb][2 * h + 1], bq[h][0], bq[h][1], rr[q][h][0], rr[q][h][1]);
+          }
+        }
+      }
+      if (!more) break;
+      v = vn;
+      continue;
+    }
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       const int m = mt + wr * 128 + (mb >> 2) * 64 + (mb & 3) * 16 + l15;
       if (m < p.M) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) epi(m, ntl + wc * 64 + h * 32 + 8 * kq, acc[mb][2 * h], acc[mb][2 * h + 1]);
+        for (int h = 0; h < 2; ++h) epi.fin(m, ntl + wc * 64 + h * 32 + 8 * kq, acc[mb][2 * h], acc[mb][2 * h + 1], bq[h][0], bq[h][1]);
       }
     }
     if (!more) break;
     v = vn;
   }
 #undef WIS_MMA16
-#undef WIS_FRAG
 #undef WIS_PROLOGUE
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same structure on a 128 (M) x 256 (N) tile for ONE utterance (M = 1500: the 256 x 256 tile would leave two thirds of the CUs
+// without work - QKV 90, FFN1 120 tiles - while this one gives 180 / 240).  8 waves as 2 (M) x 4 (N), wave tile 64 x 64: the kernel
+// above without its M-hi half.  A k-tile is THREE half-tiles (g0 = N-lo, g1 = M, g2 = N-hi: 48 KiB) and two phases of 16 MFMAs:
+//   phase 0: reads N-lo (4) + M (8); stages g0 and g1 of k-tile t+2        MFMA M x N-lo
+//   phase 1: reads N-hi (4);         stages g2 of k-tile t+2, vmcnt(6)     MFMA M x N-hi
+// The k-tile is half as long in time as the 256 x 256 one, so the staging runs TWO WHOLE k-tiles ahead through a ring of three
+// buffers (144 KiB): a buffer is restaged one k-tile after its last read (g0 / g1 read in phase 0 of t-1, restaged in phase 0 of t;
+// g2 read in phase 1 of t-1, restaged in phase 1 of t - two phases apart, the rule of the kernel above without its special cases).
+// One counted wait per k-tile: six DMAs of k-tile t+2 may stay in flight, everything older (k-tile t+1) has landed.  Same stagger of
+// the two wave rows, same swizzle, same permuted weight rows / 16-byte stores.  Per k-tile the fragment reads (16 ds_read_b128 per
+// wave = 1024 LDS cycles per CU) equal the MFMA time (32 MFMAs x 16 cycles x 2 waves per SIMD): the tile is at the LDS-bandwidth
+// balance point, which is why the batched encoder keeps the 256 x 256 tile (1536 LDS vs 2048 MFMA cycles).
+// Functors with a transposed part (the V images) run both column sets in ONE launch: workgroups >= tiles_a take `pb` and the swapped
+// MFMA operand order (a wave-uniform branch; with 64 accumulator registers both MFMA clusters fit without spills).
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int tiles_a, int rot_mul, Epi epi) {
+  constexpr int BM_ = 128, BN_ = 256, HALF = 128 * 64, BUF = 3 * HALF, RING = 3 * BUF;
+  __shared__ __attribute__((aligned(1024))) f16 smem[RING];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
+  const bool tr = Epi::HAS_T && (int)blockIdx.x >= tiles_a;
+  const GemmP& p = tr ? pb : pa;
+  const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
+  const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
+  const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
+  int m0, n0, rot;
+  {
+    const int v = (int)blockIdx.x - (tr ? tiles_a : 0);
+    const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    m0 = (wg % nmt) * BM_; n0 = (wg / nmt) * BN_;
+    if (p.n_span) n0 = (n0 / p.n_span) * p.n_period + p.n_phase + n0 % p.n_span;
+    // K ROTATION: this workgroup walks the k-tiles rot, rot + 1, ..., nk - 1, 0, ..., rot - 1.  With one tile per CU every workgroup
+    // would otherwise ask for the same k-slice of a shared operand panel at the same time - each k-tile a cold L2 miss for all of
+    // them, ~2.8 us of latency against two k-tiles of lookahead (measured: 1.4 us per k-tile, the tile no faster than the
+    // register-staged one).  Rotated, the sharers of a panel (12 row tiles per weight block, 2-3 column blocks per activation block
+    // inside an XCD) are spread over K and find most lines already fetched by a neighbour.
+    rot = (int)(((unsigned)wg * (unsigned)rot_mul) % (unsigned)nk);
+  }
+  const f16 *sNl0, *sNl1, *sNh0, *sNh1, *sM0, *sM1;
+  {
+    auto src = [&](int j, const f16** nl, const f16** nh, const f16** ms) {
+      const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
+      const int i16 = rl & 15, nb16 = (rl >> 4) & 1;
+      const int n = n0 + (rl >> 5) * 64 + 8 * (i16 >> 2) + 4 * nb16 + (i16 & 3);      // permuted weight rows: see gemm_8p_kernel
+      *nl = p.W + (int64_t)n * p.K + kbeg + rot * BK + c * 8;
+      *nh = p.W + (int64_t)(n + 32) * p.K + kbeg + rot * BK + c * 8;
+      int m = m0 + rl;
+      if (m > p.M - 1) m = p.M - 1;
+      *ms = p.A + (int64_t)(m / p.a_rpb) * p.a_bs + (int64_t)(m % p.a_rpb) * p.a_rs + kbeg + rot * BK + c * 8;
+    };
+    src(0, &sNl0, &sNh0, &sM0);
+    src(1, &sNl1, &sNh1, &sM1);
+  }
+  // the lane's bias values, requested ahead of everything else: a load between the stores of the epilogue would cost a vmcnt(0) wait,
+  // which on gfx9 also waits for the stores before it
+  // (both forms unconditionally - every index is a valid column: a branch here makes hipcc wait for the loads on the spot)
+  f32x4 bq[2][2]; float bt[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) bt[nb] = epi.bias1(n0 + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { bq[h][0] = epi.bias4(n0 + wc * 64 + h * 32 + 8 * kq); bq[h][1] = epi.bias4(n0 + wc * 64 + h * 32 + 8 * kq + 4); }
+  // the first two k-tiles of the walk (the launcher guarantees nk >= 2); `ks` = K index of the k-tile the pointers stand on, wrapped
+  // after each whole k-tile (wave-uniform)
+  int ks = rot;
+#define WIS_WRAP() do { if (++ks == nk) { ks = 0; const int back_ = nk * BK; sNl0 -= back_; sNl1 -= back_; sNh0 -= back_; sNh1 -= back_; sM0 -= back_; sM1 -= back_; } } while (0)
+  WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sM0, sM1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0); WIS_WRAP();
+  WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sM0, sM1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF); WIS_WRAP();
+  const int fo0 = l15 * 64 + ((kq ^ (l15 >> 1)) << 3);
+  const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;
+  f32x4 acc[4][4];
+  f16x8 nlo[2][2], nhi[2][2], mf[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define WIS_MMA16N(NF, NB0) do { \
+    __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_setprio(1); \
+    if (tr) { \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
+        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) \
+          _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+            acc[mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mf[mb][kb], NF[nb][kb], acc[mb][(NB0) + nb], 0, 0, 0); \
+    } else { \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
+        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) \
+          _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+            acc[mb][(NB0) + nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(NF[nb][kb], mf[mb][kb], acc[mb][(NB0) + nb], 0, 0, 0); \
+    } \
+    __builtin_amdgcn_s_setprio(0); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+  __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6): k-tile 0 (this wave's share) has landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind wave row 0
+  int cb = 0, sb = 2 * BUF;      // buffer of k-tile t; buffer k-tile t+2 is staged into (= the one k-tile t-1 was read from)
+  for (int t = 0; t < nk; ++t) {
+    const int rNb0 = oN0 + cb, rNb1 = rNb0 ^ 32, rMb0 = oM0 + cb, rMb1 = rMb0 ^ 32;
+    // ---- phase 0
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) nlo[nb][kb] = WIS_FRAG(rNb, 0, nb, kb);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mf[mb][kb] = WIS_FRAG(rMb, 1, mb, kb);
+    if (t + 2 < nk) { WIS_STAGE(sNl0, sNl1, 0, sb); WIS_STAGE(sM0, sM1, 1, sb); }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16N(nlo, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
+    if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, sb); WIS_WRAP(); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed; the six DMAs of t+2 fly on
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    WIS_MMA16N(nhi, 2);
+    __builtin_amdgcn_s_barrier();
+    sb = cb; cb = cb + BUF; if (cb == RING) cb = 0;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with wave row 1's last barrier
+  if (tr) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + wr * 64 + mb * 16 + 4 * kq;
+      if (m < p.M) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) epi.fin_t(m, n0 + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3), acc[mb][nb], bt[nb]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + wr * 64 + mb * 16 + l15;
+    if (m < p.M) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) epi.fin(m, n0 + wc * 64 + h * 32 + 8 * kq, acc[mb][2 * h], acc[mb][2 * h + 1], bq[h][0], bq[h][1]);
+    }
+  }
+#undef WIS_MMA16N
+#undef WIS_WRAP
+#undef WIS_FRAG
 #undef WIS_STAGE
 #undef WIS_DMA
 }
@@ -571,6 +775,30 @@ static int launch_gemm_8p(hipStream_t st, const GemmP& p, const Epi& epi) {
   return WIS_OK;
 }
 
+// The 128 x 256 form of the 8-phase kernel: one utterance, wide N.  Returns 1 when the shape is not its case (the caller goes on to
+// the register-staged tiles): N a multiple of 256 (both column sets of a functor with a transposed part), two or more k-tiles, and
+// between 120 tiles and two rounds of the chip (fewer: the 64- / 128-row tiles fill more CUs; more: the 256 x 256 tile's case).
+template <class Epi>
+static int launch_gemm_8pn(hipStream_t st, const GemmP& p, const Epi& epi) {
+  static const bool use = !(getenv("WIS_GEMM_8PN") && atoi(getenv("WIS_GEMM_8PN")) == 0);
+  const int splits = p.klen > 0 ? p.K / p.klen : 1;
+  static const bool use_t = getenv("WIS_GEMM_8PN_T") && atoi(getenv("WIS_GEMM_8PN_T")) != 0;      // functors with a transposed part: measured slower than the ping-pong tile (QKV 33.9 vs 29.8 us)
+  if (Epi::HAS_T && !use_t) return 1;
+  if (!use || p.N % 256 || (p.klen > 0 ? p.klen : p.K) / BK < 2 || p.M < 128) return 1;
+  const int tiles = cdiv(p.M, 128) * (p.N / 256) * splits;
+  if (tiles < 120 || tiles > 512) return 1;
+  GemmP a = p, b = p;
+  int tiles_a = cdiv(p.M, 128) * (p.N / 256);
+  if constexpr (Epi::HAS_T) {
+    epi.split(p.N, &a, &b);
+    if (a.N % 256 || b.N % 256 || a.n_span % 256 || b.n_span % 256) return 1;
+    tiles_a = cdiv(p.M, 128) * (a.N / 256);
+  }
+  static const int rot_mul = getenv("WIS_GEMM_ROT") ? atoi(getenv("WIS_GEMM_ROT")) : 7;      // 0: every workgroup walks K from 0 (A/B switch)
+  hipLaunchKernelGGL((gemm_8pn_kernel<Epi>), dim3(cdiv(p.M, 128) * (p.N / 256), 1, splits), dim3(512), 0, st, a, b, tiles_a, rot_mul, epi);
+  return WIS_OK;
+}
+
 template <class Epi>
 static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   if (p.N % 128 || p.K % BK || p.M <= 0) { set_error("gemm: M=%d N=%d K=%d unsupported (N%%128, K%%64)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
@@ -581,6 +809,10 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   const int nk_ = (p.klen > 0 ? p.klen : p.K) / BK;
   if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) {
     const int rc = launch_gemm_8p(st, p, epi);
+    if (rc <= 0) return rc;
+  }
+  if (bm == 256 && bn == 128) {      // one utterance, wide N: the 128 x 256 8-phase tile where it applies
+    const int rc = launch_gemm_8pn(st, p, epi);
     if (rc <= 0) return rc;
   }
   if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
@@ -600,7 +832,7 @@ __device__ __forceinline__ f32x4 gelu4(f32x4 v) { return f32x4{gelu_erf(v[0]), g
 
 // generic runtime-flag epilogue (wis_op_gemm, FFN, out-proj)
 struct EpiGeneric {
-  static constexpr bool HAS_T = false;
+  static constexpr bool HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   const float* bias; const float* resid; void* C; int N; int flags;  // 1 gelu, 2 resid, 4 out f32
   __device__ void operator()(int m, int n, f32x4 v) const {
@@ -609,6 +841,18 @@ struct EpiGeneric {
     const size_t o = (size_t)m * N + n;
     if (flags & 2) v += ld4(resid + o);
     if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
+  }
+  // the same with the bias of the 8 features already in registers (bias4 / bias1: requested before the k-loop by the 128 x 256 kernel -
+  // a load inside the store sequence costs an s_waitcnt vmcnt(0), which on gfx9 also waits for every store issued before it)
+  __device__ f32x4 bias4(int n) const { return bias ? ld4(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ float bias1(int) const { return 0.f; }
+  __device__ void fin_t(int, int, f32x4, float) const {}
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const {
+    a += ba; b += bb;
+    if (flags & 1) { a = gelu4(a); b = gelu4(b); }
+    const size_t o = (size_t)m * N + n;
+    if (flags & 2) { a += ld4(resid + o); b += ld4(resid + o + 4); }
+    if (flags & 4) { st4(reinterpret_cast<float*>(C) + o, a); st4(reinterpret_cast<float*>(C) + o + 4, b); } else st8h(reinterpret_cast<f16*>(C) + o, a, b);
   }
   // 8 consecutive features of one row (the 8-phase kernel: n % 8 == 0): f16 outputs leave as ONE 16-byte store
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const {
@@ -619,9 +863,27 @@ struct EpiGeneric {
     if (flags & 4) { st4(reinterpret_cast<float*>(C) + o, a); st4(reinterpret_cast<float*>(C) + o + 4, b); } else st8h(reinterpret_cast<f16*>(C) + o, a, b);
   }
 };
+// bias + fp32 residual -> fp32 (out-projection, FFN2) for the 8-phase kernel: HAS_RES = the kernel requests the residual values of TWO
+// row blocks (res8) before it stores any of them (fin2) - four load rounds per tile instead of one load + wait per store
+struct EpiResid {
+  static constexpr bool HAS_T = false, HAS_RES = true;
+  const float* bias; const float* resid; float* C; int N;
+  __device__ void store_t(int, int, f32x4) const {}
+  __device__ void fin_t(int, int, f32x4, float) const {}
+  __device__ float bias1(int) const { return 0.f; }
+  __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
+  __device__ void res8(int m, int n, f32x4& ra, f32x4& rb) const { const size_t o = (size_t)m * N + n; ra = ld4(resid + o); rb = ld4(resid + o + 4); }
+  __device__ void fin2(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb, f32x4 ra, f32x4 rb) const {
+    const size_t o = (size_t)m * N + n;
+    st4(C + o, a + ba + ra); st4(C + o + 4, b + bb + rb);
+  }
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { f32x4 ra, rb; res8(m, n, ra, rb); fin2(m, n, a, b, ba, bb, ra, rb); }
+  __device__ void operator()(int m, int n, f32x4 v) const { const size_t o = (size_t)m * N + n; st4(C + o, v + ld4(bias + n) + ld4(resid + o)); }
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { fin(m, n, a, b, bias4(n), bias4(n + 4)); }
+};
 // conv1: GELU(acc + b) -> f16 time-major padded image [B][T+2][N], row t+1
 struct EpiConv1 {
-  static constexpr bool HAS_T = false;
+  static constexpr bool HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   const float* bias; f16* C; int N; int T;
   __device__ void operator()(int m, int n, f32x4 v) const {
@@ -634,10 +896,18 @@ struct EpiConv1 {
     const int b = m / T, t = m - b * T;
     st8h(C + ((size_t)b * (T + 2) + t + 1) * N + n, a, c);
   }
+  __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
+  __device__ float bias1(int) const { return 0.f; }
+  __device__ void fin_t(int, int, f32x4, float) const {}
+  __device__ void fin(int m, int n, f32x4 a, f32x4 c, f32x4 ba, f32x4 bb) const {
+    a = gelu4(a + ba); c = gelu4(c + bb);
+    const int b = m / T, t = m - b * T;
+    st8h(C + ((size_t)b * (T + 2) + t + 1) * N + n, a, c);
+  }
 };
 // conv2: GELU(acc + b) + pos[t] -> fp32 residual stream [B*T][N]
 struct EpiConv2 {
-  static constexpr bool HAS_T = false;
+  static constexpr bool HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   const float* bias; const float* pos; float* X; int N; int T;
   __device__ void operator()(int m, int n, f32x4 v) const {
@@ -647,12 +917,20 @@ struct EpiConv2 {
     st4(X + (size_t)m * N + n, v);
   }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
+  __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
+  __device__ float bias1(int) const { return 0.f; }
+  __device__ void fin_t(int, int, f32x4, float) const {}
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const {
+    const int t = m % T;
+    a = gelu4(a + ba) + ld4(pos + (size_t)t * N + n); b = gelu4(b + bb) + ld4(pos + (size_t)t * N + n + 4);
+    st4(X + (size_t)m * N + n, a); st4(X + (size_t)m * N + n + 4, b);
+  }
 };
 // fused QKV: [Q*s | K] -> f16 [M][2d]; V -> V^T f16 [B][H][64][Tpad]
 struct EpiQKV {
   // V tiles of the 8-phase kernel run their MFMAs with the operands swapped (D transposed): a lane then holds 4 CONSECUTIVE rows (keys) of
   // one feature, i.e. 8 contiguous bytes of the transposed V image instead of four scattered 2-byte stores
-  static constexpr bool HAS_T = true;
+  static constexpr bool HAS_T = true, HAS_RES = false;
   void split(int N, GemmP* plain, GemmP* tr) const {      // [Q | K] = columns [0, 2d) plain, V = [2d, 3d) transposed
     plain->N = 2 * d; plain->n_span = 2 * d; plain->n_period = 0; plain->n_phase = 0;
     tr->N = N - 2 * d; tr->n_span = N - 2 * d; tr->n_period = 0; tr->n_phase = 2 * d;
@@ -680,6 +958,14 @@ struct EpiQKV {
     // only reached for the Q | K tiles (the 8-phase kernel sends the V tiles through store_t)
     a += ld4(bias + n); b += ld4(bias + n + 4); st8h(qk + (size_t)m * 2 * d + n, a, b);
   }
+  __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
+  __device__ float bias1(int n) const { return bias[n]; }
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { st8h(qk + (size_t)m * 2 * d + n, a + ba, b + bb); }
+  __device__ void fin_t(int m, int n, f32x4 v, float bv) const {
+    const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
+    const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+    st4h(vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+  }
 };
 // cross-attention K/V projection of the encoder memory for ONE decoder layer:
 //   K -> Kx f16 [B][H][8][T][8]    (16-byte dh-groups contiguous along T = the MFMA A-fragment rows of the decode kernel)
@@ -689,7 +975,7 @@ struct EpiQKV {
 // 256-wide tile never straddles layers because 2d is a multiple of 256 for every Whisper size but tiny (768: multiple of 128
 // and of 256).
 struct EpiCrossKV {
-  static constexpr bool HAS_T = true;
+  static constexpr bool HAS_T = true, HAS_RES = false;
   void split(int N, GemmP* plain, GemmP* tr) const {      // per layer: K = columns [0, d) plain, V = [d, 2d) transposed; N = layers x 2d
     plain->N = N / 2; plain->n_span = d; plain->n_period = 2 * d; plain->n_phase = 0;
     tr->N = N / 2; tr->n_span = d; tr->n_period = 2 * d; tr->n_phase = d;
@@ -722,15 +1008,30 @@ struct EpiCrossKV {
     const int b = m / T, t = m - b * T, h = n >> 6, g = (n & 63) >> 3;
     st8h(kx + l * kx_lstride + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8), a, c);
   }
+  __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
+  __device__ float bias1(int n) const { return bias[n]; }
+  __device__ void fin(int m, int n_all, f32x4 a, f32x4 c, f32x4 ba, f32x4 bb) const {
+    const int l = n_all / (2 * d), n = n_all - l * 2 * d;
+    const int b = m / T, t = m - b * T, h = n >> 6, g = (n & 63) >> 3;
+    st8h(kx + l * kx_lstride + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8), a + ba, c + bb);
+  }
+  __device__ void fin_t(int m, int n_all, f32x4 v, float bv) const {
+    const int l = n_all / (2 * d), nn = n_all - l * 2 * d - d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
+    st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+  }
 };
 
 // split-K partial tile: fp32 [blockIdx.z][M][N]
 struct EpiPartial {
-  static constexpr bool HAS_T = false;
+  static constexpr bool HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   float* C; int N; int64_t zstride;
   __device__ void operator()(int m, int n, f32x4 v) const { st4(C + (int64_t)blockIdx.z * zstride + (size_t)m * N + n, v); }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
+  __device__ f32x4 bias4(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ float bias1(int) const { return 0.f; }
+  __device__ void fin_t(int, int, f32x4, float) const {}
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4, f32x4) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
 };
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t zstride, const float* __restrict__ bias,
                                      const float* resid, float* X, int64_t n4, int N) {
@@ -811,7 +1112,8 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
-  if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, p, e);
+  if (gemm_pp_fits(p, splits) && launch_gemm_8pn(st, p, e) <= 0) {}
+  else if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, p, e);
   else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
   if (Y) {
     if (!ln_gamma || !ln_beta || p.N > 2048 || (splits != 2 && splits != 4)) { set_error("splitk: fused LayerNorm needs gamma, beta, N <= 2048 and 2 or 4 splits"); return WIS_E_ARG; }
@@ -826,6 +1128,12 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
 }
 
 int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const float* resid, void* C, int flags) {
+  if (flags == (2 | 4) && bias && resid && p.N % 256 == 0 && p.K % BK == 0 && p.klen == 0 && p.K / BK >= 2) {      // fp32 residual epilogue on the 8-phase tile: its own functor
+    static const bool use_8p = !(getenv("WIS_GEMM_8P") && atoi(getenv("WIS_GEMM_8P")) == 0);
+    int bm, bn; gemm_pick_tile(p, &bm, &bn);
+    static const bool use_res = !(getenv("WIS_GEMM_RESID") && atoi(getenv("WIS_GEMM_RESID")) == 0);      // 0: the generic functor (A/B switch)
+    if (use_res && use_8p && bm == 256 && bn == 256) { launch_8p_part<EpiResid, false>(st, p, EpiResid{bias, resid, reinterpret_cast<float*>(C), p.N}); return WIS_OK; }
+  }
   EpiGeneric e{bias, resid, C, p.N, flags};
   return launch_gemm_t(st, p, e);
 }
