@@ -118,6 +118,78 @@ constexpr int BK = 64, LSTR = 72;  // 64-deep k-tiles; LDS row pitch 72 f16 = 14
 //   QKV   128x128 29.8 | 54.5 | 209    256x128 ping-pong 27.6 | 53.2 | 193    256x256 41.3 | 46.3 | 169
 //   FFN1  128x128 32.4 | 67.0 | 267    256x128 ping-pong 30.3 | 61.3 | 261    256x256 43.2 | 54.8 | 222
 //   out   128x128 20.8 | 22.6 | 65.9    64x128 13.9 | 21.8 | 81.4             256x256 36.9 | 38.1 | 50.3
+// Epilogue of the register-staged tiles (32 x 32 MFMA accumulators: lane holds row m = l31 and features (r & 3) + 8 (r >> 2) + 4 hi of
+// each 32 x 32 block).  Every operand the functor needs from memory - the bias quads, and the residual quads where the functor has
+// them - is requested BEFORE the first store and retired by ONE wait: gfx9 has one in-order counter for loads and stores, so a load
+// between stores (the functor called block by block) makes its wait a wait for every store issued before it - the epilogue then
+// runs one store round trip per row block (measured on the 8-phase kernel, whose epilogue is built the same way).
+#define WIS_PINV4(r) asm volatile("" :: "v"((r)[0]), "v"((r)[1]), "v"((r)[2]), "v"((r)[3]))
+template <class Epi, int NI, int MI>
+__device__ __forceinline__ void epilogue_32(const Epi& epi, const f32x16 (&acc)[NI][MI], int mrow, int ncol, int M) {
+  f32x4 bb[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) bb[ni][r4] = epi.bias4(ncol + ni * 32 + 8 * r4);
+  if (epi.has_res()) {
+    // residual quads: all of the tile's at once where that is <= 64 registers, otherwise one 32-column block per round
+    constexpr int RND = NI * MI <= 4 ? 1 : NI, NPR = NI / RND;
+#pragma unroll
+    for (int rnd = 0; rnd < RND; ++rnd) {
+      f32x4 rr[NPR][MI][4];
+#pragma unroll
+      for (int nj = 0; nj < NPR; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          int m = mrow + mi * 32;
+          if (m > M - 1) m = M - 1;      // clamped, unconditional: the guard is on the stores
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) rr[nj][mi][r4] = epi.res4(m, ncol + (rnd * NPR + nj) * 32 + 8 * r4);
+        }
+#pragma unroll
+      for (int nj = 0; nj < NPR; ++nj) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) WIS_PINV4(bb[rnd * NPR + nj][r4]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) WIS_PINV4(rr[nj][mi][r4]);
+      }
+#pragma unroll
+      for (int nj = 0; nj < NPR; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = mrow + mi * 32, ni = rnd * NPR + nj;
+          if (m < M) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
+              epi.fin4r(m, ncol + ni * 32 + 8 * r4, v, bb[ni][r4], rr[nj][mi][r4]);
+            }
+          }
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) WIS_PINV4(bb[ni][r4]);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = mrow + mi * 32;
+      if (m < M) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
+          epi.fin4(m, ncol + ni * 32 + 8 * r4, v, bb[ni][r4]);
+        }
+      }
+    }
+}
+
 template <class Epi, int BM_, int BN_, int WM_, int WN_>
 __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi epi) {
   constexpr int T = 64 * WM_ * WN_;            // threads
@@ -211,20 +283,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi e
 #undef WIS_GLOAD
 #undef WIS_SSTORE
   // D[i = n][j = m]: lane holds m = l31, n = (r&3) + 8*(r>>2) + 4*hi
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * TM + mi * 32 + l31;
-      if (m < p.M) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int n = n0 + wn * TN + ni * 32 + 8 * r4 + 4 * hi;
-          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
-          epi(m, n, v);
-        }
-      }
-    }
+  epilogue_32<Epi, NI, MI>(epi, acc, m0 + wm * TM + l31, n0 + wn * TN + 4 * hi, p.M);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -313,20 +372,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p, Epi epi) {
 #undef WIS_PLOAD
 #undef WIS_PSTORE
 #undef WIS_PMMA
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + arow0 + mi * 32 + l31;
-      if (m < p.M) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int n = n0 + wn * 64 + ni * 32 + 8 * r4 + 4 * hi;
-          f32x4 v = {acc[ni][mi][4 * r4], acc[ni][mi][4 * r4 + 1], acc[ni][mi][4 * r4 + 2], acc[ni][mi][4 * r4 + 3]};
-          epi(m, n, v);
-        }
-      }
-    }
+  epilogue_32<Epi, 2, 2>(epi, acc, m0 + arow0 + l31, n0 + wn * 64 + 4 * hi, p.M);
 }
 // ---------------------------------------------------------------------------------------------------------------------------
 // 8-phase 256 x 256 workgroup for the batched encoder (>= 150 tiles: two or more utterances), after the guide's plain-HIP template
@@ -842,6 +888,22 @@ struct EpiGeneric {
     if (flags & 2) v += ld4(resid + o);
     if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
   }
+  // register-staged tiles (epilogue_32): bias and residual quads arrive in registers
+  __device__ bool has_res() const { return (flags & 2) != 0; }
+  __device__ f32x4 res4(int m, int n) const { return ld4(resid + (size_t)m * N + n); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const {
+    v += b;
+    if (flags & 1) v = gelu4(v);
+    const size_t o = (size_t)m * N + n;
+    if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
+  }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
+    v += b;
+    if (flags & 1) v = gelu4(v);
+    v += r;
+    const size_t o = (size_t)m * N + n;
+    if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
+  }
   // the same with the bias of the 8 features already in registers (bias4 / bias1: requested before the k-loop by the 128 x 256 kernel -
   // a load inside the store sequence costs an s_waitcnt vmcnt(0), which on gfx9 also waits for every store issued before it)
   __device__ f32x4 bias4(int n) const { return bias ? ld4(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -878,6 +940,10 @@ struct EpiResid {
     st4(C + o, a + ba + ra); st4(C + o + 4, b + bb + rb);
   }
   __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { f32x4 ra, rb; res8(m, n, ra, rb); fin2(m, n, a, b, ba, bb, ra, rb); }
+  __device__ bool has_res() const { return true; }
+  __device__ f32x4 res4(int m, int n) const { return ld4(resid + (size_t)m * N + n); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const { st4(C + (size_t)m * N + n, v + b + res4(m, n)); }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const { st4(C + (size_t)m * N + n, v + b + r); }
   __device__ void operator()(int m, int n, f32x4 v) const { const size_t o = (size_t)m * N + n; st4(C + o, v + ld4(bias + n) + ld4(resid + o)); }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { fin(m, n, a, b, bias4(n), bias4(n + 4)); }
 };
@@ -904,6 +970,14 @@ struct EpiConv1 {
     const int b = m / T, t = m - b * T;
     st8h(C + ((size_t)b * (T + 2) + t + 1) * N + n, a, c);
   }
+  __device__ bool has_res() const { return false; }
+  __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 bq) const {
+    v = gelu4(v + bq);
+    const int b = m / T, t = m - b * T;
+    st4h(C + ((size_t)b * (T + 2) + t + 1) * N + n, v);
+  }
 };
 // conv2: GELU(acc + b) + pos[t] -> fp32 residual stream [B*T][N]
 struct EpiConv2 {
@@ -925,6 +999,11 @@ struct EpiConv2 {
     a = gelu4(a + ba) + ld4(pos + (size_t)t * N + n); b = gelu4(b + bb) + ld4(pos + (size_t)t * N + n + 4);
     st4(X + (size_t)m * N + n, a); st4(X + (size_t)m * N + n + 4, b);
   }
+  // (the positional rows play the residual's part: one quad per (row, column quad))
+  __device__ bool has_res() const { return true; }
+  __device__ f32x4 res4(int m, int n) const { return ld4(pos + (size_t)(m % T) * N + n); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const { fin4r(m, n, v, b, res4(m, n)); }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const { st4(X + (size_t)m * N + n, gelu4(v + b) + r); }
 };
 // fused QKV: [Q*s | K] -> f16 [M][2d]; V -> V^T f16 [B][H][64][Tpad]
 struct EpiQKV {
@@ -961,6 +1040,18 @@ struct EpiQKV {
   __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
   __device__ float bias1(int n) const { return bias[n]; }
   __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { st8h(qk + (size_t)m * 2 * d + n, a + ba, b + bb); }
+  __device__ bool has_res() const { return false; }
+  __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 bq) const {
+    v += bq;
+    if (n < 2 * d) { st4h(qk + (size_t)m * 2 * d + n, v); return; }
+    const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
+    const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+    f16* o = vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
+  }
   __device__ void fin_t(int m, int n, f32x4 v, float bv) const {
     const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
     const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
@@ -1019,6 +1110,24 @@ struct EpiCrossKV {
     const int l = n_all / (2 * d), nn = n_all - l * 2 * d - d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
     st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
   }
+  __device__ bool has_res() const { return false; }
+  __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
+  __device__ void fin4(int m, int n_all, f32x4 v, f32x4 bq) const {
+    v += bq;
+    const int l = n_all / (2 * d), n = n_all - l * 2 * d;
+    f16* kx = this->kx + l * kx_lstride; f16* vt = this->vt + l * vt_lstride;
+    const int b = m / T, t = m - b * T;
+    if (n < d) {
+      const int h = n >> 6, dh = n & 63, g = dh >> 3, j = dh & 7;
+      st4h(kx + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8 + j), v);
+    } else {
+      const int nn = n - d, h = nn >> 6, dh = nn & 63;
+      f16* o = vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[(size_t)j * Tpad] = (f16)v[j];
+    }
+  }
 };
 
 // split-K partial tile: fp32 [blockIdx.z][M][N]
@@ -1032,6 +1141,10 @@ struct EpiPartial {
   __device__ float bias1(int) const { return 0.f; }
   __device__ void fin_t(int, int, f32x4, float) const {}
   __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4, f32x4) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
+  __device__ bool has_res() const { return false; }
+  __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4) const { (*this)(m, n, v); }
 };
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t zstride, const float* __restrict__ bias,
                                      const float* resid, float* X, int64_t n4, int N) {
