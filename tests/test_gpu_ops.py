@@ -171,7 +171,9 @@ def test_enc_attention(lib, B, T, H):
                                          (40, 1280, 5120, 32 | 2), (40, 5120, 1280, 32 | 1), (3, 1004, 384, 32 | 4), (1, 51872, 1280, 32 | 8 | 4),
                                          # 49-96 rows (up to 16 utterances x beam 5): four to six row blocks, six-deep fragment ring
                                          (64, 1280, 1280, 8 | 4), (80, 5120, 1280, 8 | 1), (80, 1280, 5120, 2), (96, 3840, 1280, 8 | 4), (80, 1280, 1280, 32 | 2),
-                                         (72, 768, 384, 8 | 4)])
+                                         (72, 768, 384, 8 | 4),
+                                         # K = 4d over four workgroups per n-tile with the in-launch merge (two launches on one set of tickets where nothing accumulates)
+                                         (40, 1280, 5120, 4), (96, 1280, 5120, 0), (24, 1024, 4096, 1)])
 def test_gemv(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 31 + N + K)

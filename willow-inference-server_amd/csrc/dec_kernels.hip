@@ -590,9 +590,12 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   constexpr int EPN = (MB + 3) / 4;      // row blocks a wave finishes in the epilogue: wave w owns blocks w, w + 4 (up to 96 rows = 6 blocks)
   __shared__ __attribute__((aligned(16))) float red[4 * MB * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockIdx.x;
-  const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps >> 2;
-  const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * ksteps + (size_t)wave * S) * 64 + lane;
-  const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)wave * S * MB * 64 + lane;
+  // K slices (gridDim.y > 1: the K = 4d projection - 80 workgroups would each pull the whole activation image and a 160 KiB weight
+  // panel through one CU's ~55 GB/s; see GemvP::ksplit): slice ksi covers the k-steps [ksi, ksi + 1) * ksteps / KS, a quarter per wave
+  const int KS = gridDim.y, ksi = blockIdx.y;
+  const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps / (4 * KS);
+  const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * ksteps + (size_t)(ksi * 4 + wave) * S) * 64 + lane;
+  const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)(ksi * 4 + wave) * S * MB * 64 + lane;
   WT a[PF]; u32x4 b[PF][MB];
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
@@ -673,15 +676,54 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   for (int mb = 0; mb < MB; ++mb)
     *reinterpret_cast<float4*>(red + ((size_t)(wave * MB + mb) * 64 + lane) * 4) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
+  if (KS > 1) {
+    // publish this slice's sums (write-through, agent scope: the other slices of the n-tile run on other XCDs), take a ticket; the
+    // last arriver re-arms the ticket, drops its stale L1 lines and goes on to add the slices in index order (the order never
+    // depends on who arrived last: bit-reproducible) - the hand-off of the cross-attention's ticket form
+#pragma unroll
+    for (int e = 0; e < EPN; ++e) {
+      if (!ep_act[e]) continue;
+      const int ep_mb = wave + 4 * e;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + ep_mb) * 64 + lane) * 4);
+        s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+      }
+      float* dst = p.kpart + ((((size_t)nt * KS + ksi) * MB + ep_mb) * 64 + lane) * 4;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(s) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(p.kcnt + nt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)(KS - 1);
+      if (last) {
+        __hip_atomic_store(p.kcnt + nt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+  }
 #pragma unroll
   for (int e = 0; e < EPN; ++e) {
     if (!ep_act[e]) continue;                                   // whole waves: a row block belongs to one wave
     const int ep_mb = wave + 4 * e;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KS > 1) {
+      for (int k = 0; k < KS; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(p.kpart + ((((size_t)nt * KS + k) * MB + ep_mb) * 64 + lane) * 4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    } else {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + ep_mb) * 64 + lane) * 4);
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      for (int w = 0; w < 4; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + ep_mb) * 64 + lane) * 4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
     }
     if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
     if (ln) {     // the four lanes of a row (kq = 0..3) hold a quarter of its sums each: ((q0 + q1) + (q2 + q3)) on every lane
@@ -744,8 +786,10 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   if ((p.flags & GV_LN) && (!p.csum || !p.stat_in)) { set_error("gemv_frag: the folded LayerNorm needs column sums and row partials"); return WIS_E_ARG; }
   if ((p.flags & GV_RESID) && (p.N % 16)) { set_error("gemv_frag: residual rows need N %% 16 == 0"); return WIS_E_UNSUPPORTED; }
   const int npad = cdiv(p.N, 16) * 16;
-  dim3 grid(npad / 16), block(256);
-  const bool s10 = p.K == 1280;          // ten k-steps per wave: the whole stream of a wave is requested up front
+  const int ks = p.ksplit > 1 ? p.ksplit : 1;
+  if (ks > 1 && (!p.kpart || !p.kcnt || (p.K / 32) % (4 * ks) || (p.flags & GV_LN))) { set_error("gemv_frag: K split %d unsupported (K=%d)", ks, p.K); return WIS_E_UNSUPPORTED; }
+  dim3 grid(npad / 16, ks), block(256);
+  const bool s10 = p.K / ks == 1280;     // ten k-steps per wave: the whole stream of a wave is requested up front
   // up to three row blocks: the whole wave stream (ten k-steps) or eight k-steps in flight; four to six row blocks (49-96 rows):
   // a six-deep ring, so that weight + activation fragments stay inside the register file ((MB + 1) x 4 VGPRs per k-step)
 #define WIS_GF(MBv, PFA, PFB) do { \

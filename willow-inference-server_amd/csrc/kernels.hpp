@@ -69,6 +69,10 @@ struct GemvP {
   float* stat_out;               // GV_RESID: the same partials of the rows this launch produces, [M][N/16][2]
   f16* y_xf;                     // GV_RESID: f16 fragment image of the produced rows (next projection's input); f16 output: the output itself
   int ymb;                       // 16-row blocks of y_xf (0: f16 output stays row-major [M][N])
+  // K split over workgroups (launch_gemv_frag, ksplit > 1): workgroup (n-tile, k-slice) streams its slice, publishes the 16-column sums
+  // to kpart [N/16][ksplit][xmb][64] float4 and the last-arriving slice of an n-tile (ticket kcnt[N/16], zero-initialised once,
+  // re-armed by the winner) adds the slices in index order and runs the epilogue
+  int ksplit; float* kpart; unsigned* kcnt;
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
 int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // two f16-activation skinny GEMMs in one launch

@@ -150,6 +150,7 @@ struct wis_model {
   size_t kx_lstride = 0, vx_lstride = 0;
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
+  float* gf_part = nullptr; unsigned* gf_cnt = nullptr; int gf_ksplit = 1;      // K split of the batched FFN2 skinny GEMM: slice sums, tickets (GemvP::ksplit)
   unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
   f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
   RowMeta rm; BeamState bs;
@@ -463,6 +464,16 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
   WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bm * H * 4, m->st));
   {
+    // measured (decode ms per utterance batch, 17 steps): 8 utterances 40.7 unsplit / 38.6 two slices / 38.9 four; 12: 46.7 two / 46.9 four;
+    // 16: 60.9 unsplit / 58.7 two / 59.5 four
+    static const int env_ks = getenv("WIS_FRAG_KSPLIT") ? atoi(getenv("WIS_FRAG_KSPLIT")) : 2;      // 1: no split (A/B switch)
+    m->gf_ksplit = env_ks >= 1 && env_ks <= 8 ? env_ks : 2;
+    const size_t nt = (size_t)cdiv(d, 16);
+    WIS_RET(dalloc(m, &m->gf_part, nt * m->gf_ksplit * (MAX_ROWS / 16) * 64 * 4));
+    WIS_RET(dalloc(m, &m->gf_cnt, nt));
+    WIS_HIP_CHECK(hipMemsetAsync(m->gf_cnt, 0, nt * 4, m->st));
+  }
+  {
     const int bh = Bm * H < CA_SPIN_MAX_BH ? Bm * H : CA_SPIN_MAX_BH;
     WIS_RET(dalloc(m, &m->ca_gran, (size_t)bh * 6 * 8 * 66));
     WIS_RET(dalloc(m, &m->ca_epoch, (size_t)bh + 1));
@@ -613,6 +624,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     WIS_RET(launch_gemv_frag(st, g));
     g = base(m->dhxf, w.p_f2, w.s_f2, w.b_f2, d, 4 * d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
+    if (m->gf_ksplit > 1 && (4 * d / 32) % (4 * m->gf_ksplit) == 0) { g.ksplit = m->gf_ksplit; g.kpart = m->gf_part; g.kcnt = m->gf_cnt; }      // K = 4d over `ksplit` workgroups per n-tile
     WIS_RET(launch_gemv_frag(st, g));
   }
   if (want_logits) {
@@ -1317,7 +1329,18 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
       hipMemsetAsync(xfr, 0, (size_t)(K / 32) * MBf * 64 * 8 * 2, st);
       if ((rc = launch_xf_pack(st, x, ln ? 0 : 1, xfr, ln ? stt : nullptr, M, K, MBf))) break;
       g.x = xfr; g.xmb = MBf; g.stat_in = stt;
-      rc = launch_gemv_frag(st, g);
+      float* kp = nullptr; unsigned* kc = nullptr;
+      if (!ln && K >= 4096 && (K / 32) % 16 == 0) {      // the product's rule for the K = 4d projection: four K slices per n-tile, merged in the launch
+        const size_t nt = (size_t)cdiv(N, 16);
+        if (hipMalloc(reinterpret_cast<void**>(&kp), nt * 4 * MBf * 64 * 16) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&kc), nt * 4) != hipSuccess) {
+          hipFree(kp); set_error("wis_op_gemv: out of device memory"); rc = WIS_E_NOMEM; break; }
+        hipMemsetAsync(kc, 0, nt * 4, st);
+        g.ksplit = 4; g.kpart = kp; g.kcnt = kc;
+        if (!(flags & GV_RESID)) rc = launch_gemv_frag(st, g);      // a first launch on the same tickets: they must re-arm themselves
+      }
+      if (!rc) rc = launch_gemv_frag(st, g);
+      hipStreamSynchronize(st);
+      hipFree(kp); hipFree(kc);
       break;
     }
     if (ln && M > 8) {      // the round-1 split path (WIS_NO_FRAG): plain normalisation, then f16 activations against the folded weights
