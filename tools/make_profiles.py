@@ -1,6 +1,6 @@
 """Assemble the committed round-3 artefacts under profiles/ from what tools/gpu_session.sh left under gpurun_out/<tag>/:
 
-    python tools/make_profiles.py --stats r3f --pmc r3e --lab r3c --lab-single r3b --bench r3f
+    python tools/make_profiles.py --stats r3A --pmc r3B --tcc r3s --lab r3c --lab-single r3b --bench r3A
 
   r03_kernel_stats_large_beam5_b{1,8,16}_eager.md   rocprofv3 --kernel-trace --stats (+ per-grid table) of the eager bench
   r03_pmc_decode.json                               HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE) of the decoder kernels at 1 and 8 utterances
@@ -20,13 +20,14 @@ D = 1280
 ALG_B1 = {"gemv_kernel<1, 2, 0, 1, false> 20480": 8 * D * D, "gemv_kernel<1, 1, 10, 5, false> 81920": 8 * D * D, "gemv_kernel<1, 1, 10, 5, false> 61440": 6 * D * D,
           "gemv_kernel<1, 2, 10, 1, false> 20480": 2 * D * D, "gemv_dual_kernel<10, 20> 40960": 6 * D * D, "gemv_kernel<1, 1, 10, 5, false> 829952": 2 * 51872 * D,
           "dec_cross_attn_kernel 30720": 2 * 2 * 1500 * D}
-ALG_B8 = {"gemv_frag_kernel<3, 8, false> 20480": 8 * D * D, "gemv_frag_kernel<3, 10, false> 81920": 8 * D * D, "gemv_frag_kernel<3, 10, false> 61440": 6 * D * D,
+ALG_B8 = {"gemv_frag_kernel<3, 8, false> 40960": 8 * D * D,      # FFN2: two K slices per n-tile (grid.y = 2)
+          "gemv_frag_kernel<3, 10, false> 81920": 8 * D * D, "gemv_frag_kernel<3, 10, false> 61440": 6 * D * D,
           "gemv_frag_kernel<3, 10, false> 20480": 2 * D * D, "gemv_frag_kernel<3, 10, false> 829952": 2 * 51872 * D, "dec_cross_attn_kernel 245760": 8 * 2 * 2 * 1500 * D}
 TEMPLATE_NOTE = ("Template arguments: `gemv_kernel<MB, MODE, SC, RM, W8>` (MODE 1 = LayerNorm-folded projection on raw fp32 rows, MODE 2 = f16 activations; SC = compile-time k-steps per wave, 0 = "
                  "generic ring: FFN2), `gemv_dual_kernel<SCA, SCB>` (out-projection + folded cross-Q in one launch), `gemv_frag_kernel<MB, PF, W8>` (batched rows on fragment images: MB 16-row blocks, "
-                 "PF k-steps in flight), `dec_cross_attn_kernel<TPW, CM, FOLD, SPIN>` (SPIN = granule hand-off of the chunk partials), `gemm_8p_kernel<Epi>` (8-phase 256 x 256 LDS-DMA GEMM, "
-                 "persistent over tiles), `gemm_f16_kernel<Epi, BM, BN, WM, WN>` / `gemm_pp_kernel<Epi>` (register-staged tiles / ping-pong 256 x 128), `enc_attn_kernel<SPLIT>`, "
-                 "`splitk_reduce_ln_kernel<SPLITS>`, `layernorm_kernel<AFFINE>`.  By-grid table: 20480 threads = 80 tiles (d x d or FFN2), 61440 = QKV, 81920 = FFN1, 829952 = vocabulary projection.")
+                 "PF k-steps in flight), `dec_cross_attn_kernel<TPW, CM, FOLD, SPIN>` (SPIN = granule hand-off of the chunk partials), `gemm_8p_kernel<Epi, TR>` (8-phase 256 x 256 LDS-DMA GEMM, "
+                 "persistent over tiles; TR = swapped operands for the V images; EpiResid = bias + fp32 residual), `gemm_8pn_kernel<Epi>` (the same on a 128 x 256 tile: FFN1 of one utterance), `gemm_f16_kernel<Epi, BM, BN, WM, WN>` / `gemm_pp_kernel<Epi>` (register-staged tiles / ping-pong 256 x 128), `enc_attn_kernel<SPLIT>`, "
+                 "`splitk_reduce_ln_kernel<SPLITS>`, `layernorm_kernel<AFFINE>`.  By-grid table: 20480 threads = 80 tiles (d x d; FFN2 at one utterance), 40960 = FFN2 of the batched path (two K slices), 61440 = QKV, 81920 = FFN1, 829952 = vocabulary projection.")
 
 
 def read(path):
@@ -107,7 +108,7 @@ def pmc_decode(tag):
     print("wrote r03_pmc_decode.json", b1, res.get("batch_8", {}).get("skinny_gemm_traffic_over_algorithmic"))
 
 
-def pmc_encoder(tag):
+def pmc_encoder(tag, tcc_tag=None):
     a, b = parse_pmc(f"{G}/{tag}/pmc_sq1_b8.txt"), parse_pmc(f"{G}/{tag}/pmc_sq2_b8.txt")
     if not a:
         return
@@ -130,6 +131,19 @@ def pmc_encoder(tag):
         mfma = g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * wc)
         lines.append(f"| `{short(name)}` ({grid}) | {cs['SQ_WAVE_CYCLES'][0]} | {g('SQ_WAIT_ANY') / wc:.2f} | {g('SQ_WAIT_INST_ANY') / wc:.2f} ({g('SQ_WAIT_INST_LDS') / wc:.2f}) | {g('SQ_ACTIVE_INST_ANY') / wc:.2f} | "
                      f"{mfma:.2f} | {mfma * waves:.2f} | {c2.get('SQ_LDS_BANK_CONFLICT', (0, 0))[1]:.3g} / {c2.get('SQ_LDS_IDX_ACTIVE', (0, 0))[1]:.3g} |")
+    t = parse_pmc(f"{G}/{tcc_tag}/pmc_tcc_b1.txt") if tcc_tag else {}
+    if t:
+        lines += ["", "## L2 (TCC) counters of the encoder kernels at ONE utterance (`pmc tcc \"TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum\" 1`)", "",
+                  "Requests are 128-byte lines.  The one-utterance GEMMs pull ~270 MB through the L2s per launch for ~17 MB of unique operands; a third of the requests miss "
+                  "(every XCD fetches its own copy of the shared panels, and the workgroups of a panel ask for the same k-slice at the same time).  Taken on the intermediate build that ran QKV, FFN1 and the FFN2 slices on the 128 x 256 8-phase tile (the product keeps it for FFN1).", "",
+                  "| kernel (grid threads) | launches | L2 requests | hits | misses | miss share | reads from the fabric (EA) |", "|---|---|---|---|---|---|---|"]
+        for (name, grid), cs in sorted(t.items(), key=lambda kv: -kv[1].get("TCC_REQ_sum", (0, 0))[1] * kv[1].get("TCC_REQ_sum", (0, 0))[0]):
+            if not any(k in name for k in ("gemm_8p", "gemm_f16", "gemm_pp", "enc_attn")):
+                continue
+            g = lambda c: cs.get(c, (0, 0.0))[1]
+            if g("TCC_REQ_sum") <= 0:
+                continue
+            lines.append(f"| `{short(name)}` ({grid}) | {cs['TCC_REQ_sum'][0]} | {g('TCC_REQ_sum'):.3g} | {g('TCC_HIT_sum'):.3g} | {g('TCC_MISS_sum'):.3g} | {g('TCC_MISS_sum') / g('TCC_REQ_sum'):.2f} | {g('TCC_EA0_RDREQ_sum'):.3g} |")
     open(f"{P}/r03_pmc_encoder_sq.md", "w").write("\n".join(lines) + "\n")
     print("wrote r03_pmc_encoder_sq.md")
 
@@ -162,9 +176,9 @@ def bench(tag):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--lab"); ap.add_argument("--lab-single"); ap.add_argument("--bench")
+    ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--lab"); ap.add_argument("--lab-single"); ap.add_argument("--bench"); ap.add_argument("--tcc")
     a = ap.parse_args()
     if a.stats: kernel_stats(a.stats)
-    if a.pmc: pmc_decode(a.pmc); pmc_encoder(a.pmc)
+    if a.pmc: pmc_decode(a.pmc); pmc_encoder(a.pmc, a.tcc)
     if a.lab or a.lab_single: lab(a.lab, a.lab_single)
     if a.bench: bench(a.bench)

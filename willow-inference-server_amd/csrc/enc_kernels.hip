@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
 // Functors with a transposed part (the V images) run both column sets in ONE launch: workgroups >= tiles_a take `pb` and the swapped
 // MFMA operand order (a wave-uniform branch; with 64 accumulator registers both MFMA clusters fit without spills).
 template <class Epi>
-__global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int tiles_a, int rot_mul, Epi epi) {
+__global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int tiles_a, Epi epi) {
   constexpr int BM_ = 128, BN_ = 256, HALF = 128 * 64, BUF = 3 * HALF, RING = 3 * BUF;
   __shared__ __attribute__((aligned(1024))) f16 smem[RING];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -646,19 +646,13 @@ __global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int t
   const int nmt = (p.M + BM_ - 1) / BM_, nwg = nmt * (p.N / BN_);
   const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
   const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
-  int m0, n0, rot;
+  int m0, n0;
   {
     const int v = (int)blockIdx.x - (tr ? tiles_a : 0);
     const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
     m0 = (wg % nmt) * BM_; n0 = (wg / nmt) * BN_;
     if (p.n_span) n0 = (n0 / p.n_span) * p.n_period + p.n_phase + n0 % p.n_span;
-    // K ROTATION: this workgroup walks the k-tiles rot, rot + 1, ..., nk - 1, 0, ..., rot - 1.  With one tile per CU every workgroup
-    // would otherwise ask for the same k-slice of a shared operand panel at the same time - each k-tile a cold L2 miss for all of
-    // them, ~2.8 us of latency against two k-tiles of lookahead (measured: 1.4 us per k-tile, the tile no faster than the
-    // register-staged one).  Rotated, the sharers of a panel (12 row tiles per weight block, 2-3 column blocks per activation block
-    // inside an XCD) are spread over K and find most lines already fetched by a neighbour.
-    rot = (int)(((unsigned)wg * (unsigned)rot_mul) % (unsigned)nk);
   }
   const f16 *sNl0, *sNl1, *sNh0, *sNh1, *sM0, *sM1;
   {
@@ -666,11 +660,11 @@ __global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int t
       const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
       const int i16 = rl & 15, nb16 = (rl >> 4) & 1;
       const int n = n0 + (rl >> 5) * 64 + 8 * (i16 >> 2) + 4 * nb16 + (i16 & 3);      // permuted weight rows: see gemm_8p_kernel
-      *nl = p.W + (int64_t)n * p.K + kbeg + rot * BK + c * 8;
-      *nh = p.W + (int64_t)(n + 32) * p.K + kbeg + rot * BK + c * 8;
+      *nl = p.W + (int64_t)n * p.K + kbeg + c * 8;
+      *nh = p.W + (int64_t)(n + 32) * p.K + kbeg + c * 8;
       int m = m0 + rl;
       if (m > p.M - 1) m = p.M - 1;
-      *ms = p.A + (int64_t)(m / p.a_rpb) * p.a_bs + (int64_t)(m % p.a_rpb) * p.a_rs + kbeg + rot * BK + c * 8;
+      *ms = p.A + (int64_t)(m / p.a_rpb) * p.a_bs + (int64_t)(m % p.a_rpb) * p.a_rs + kbeg + c * 8;
     };
     src(0, &sNl0, &sNh0, &sM0);
     src(1, &sNl1, &sNh1, &sM1);
@@ -683,12 +677,9 @@ __global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int t
   for (int nb = 0; nb < 4; ++nb) bt[nb] = epi.bias1(n0 + wc * 64 + (nb >> 1) * 32 + 8 * (l15 >> 2) + 4 * (nb & 1) + (l15 & 3));
 #pragma unroll
   for (int h = 0; h < 2; ++h) { bq[h][0] = epi.bias4(n0 + wc * 64 + h * 32 + 8 * kq); bq[h][1] = epi.bias4(n0 + wc * 64 + h * 32 + 8 * kq + 4); }
-  // the first two k-tiles of the walk (the launcher guarantees nk >= 2); `ks` = K index of the k-tile the pointers stand on, wrapped
-  // after each whole k-tile (wave-uniform)
-  int ks = rot;
-#define WIS_WRAP() do { if (++ks == nk) { ks = 0; const int back_ = nk * BK; sNl0 -= back_; sNl1 -= back_; sNh0 -= back_; sNh1 -= back_; sM0 -= back_; sM1 -= back_; } } while (0)
-  WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sM0, sM1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0); WIS_WRAP();
-  WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sM0, sM1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF); WIS_WRAP();
+  // k-tiles 0 and 1 (the launcher guarantees nk >= 2)
+  WIS_STAGE(sNl0, sNl1, 0, 0); WIS_STAGE(sM0, sM1, 1, 0); WIS_STAGE(sNh0, sNh1, 2, 0);
+  WIS_STAGE(sNl0, sNl1, 0, BUF); WIS_STAGE(sM0, sM1, 1, BUF); WIS_STAGE(sNh0, sNh1, 2, BUF);
   const int fo0 = l15 * 64 + ((kq ^ (l15 >> 1)) << 3);
   const int oN0 = wc * 32 * 64 + fo0, oM0 = wr * 64 * 64 + fo0;
   f32x4 acc[4][4];
@@ -738,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int t
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) nhi[nb][kb] = WIS_FRAG(rNb, 2, nb, kb);
-    if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, sb); WIS_WRAP(); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed; the six DMAs of t+2 fly on
+    if (t + 2 < nk) { WIS_STAGE(sNh0, sNh1, 2, sb); __builtin_amdgcn_s_waitcnt(0x0F76); }      // k-tile t+1 has landed; the six DMAs of t+2 fly on
     else __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -767,7 +758,6 @@ __global__ __launch_bounds__(512) void gemm_8pn_kernel(GemmP pa, GemmP pb, int t
     }
   }
 #undef WIS_MMA16N
-#undef WIS_WRAP
 #undef WIS_FRAG
 #undef WIS_STAGE
 #undef WIS_DMA
@@ -822,8 +812,12 @@ static int launch_gemm_8p(hipStream_t st, const GemmP& p, const Epi& epi) {
 }
 
 // The 128 x 256 form of the 8-phase kernel: one utterance, wide N.  Returns 1 when the shape is not its case (the caller goes on to
-// the register-staged tiles): N a multiple of 256 (both column sets of a functor with a transposed part), two or more k-tiles, and
-// between 120 tiles and two rounds of the chip (fewer: the 64- / 128-row tiles fill more CUs; more: the 256 x 256 tile's case).
+// the register-staged tiles): N a multiple of 256, two or more k-tiles, and between 120 tiles and two rounds of the chip (fewer: the
+// 64- / 128-row tiles fill more CUs; more: the 256 x 256 tile's case).  Measured against the ping-pong 256 x 128 tile at M = 1500: FFN1
+// 29.2 vs 33.5 us (taken), QKV 33.9 vs 29.8 us (not taken: functors with a transposed part), FFN2's K slices 33.2 vs 32.5 (not taken).
+// Both tiles deliver ~35-55 GB/s of operands per CU, the rate the LDS-DMA / L1 path sustains with two k-tiles in flight against a
+// 35 % L2 miss rate (profiles/r03_pmc_encoder_sq.md): at one utterance the GEMMs are bound by operand ingest per CU, not by the
+// matrix pipe (walking K from a different start per workgroup, so that the sharers of a panel do not miss together, changed nothing).
 template <class Epi>
 static int launch_gemm_8pn(hipStream_t st, const GemmP& p, const Epi& epi) {
   static const bool use = !(getenv("WIS_GEMM_8PN") && atoi(getenv("WIS_GEMM_8PN")) == 0);
@@ -840,8 +834,7 @@ static int launch_gemm_8pn(hipStream_t st, const GemmP& p, const Epi& epi) {
     if (a.N % 256 || b.N % 256 || a.n_span % 256 || b.n_span % 256) return 1;
     tiles_a = cdiv(p.M, 128) * (a.N / 256);
   }
-  static const int rot_mul = getenv("WIS_GEMM_ROT") ? atoi(getenv("WIS_GEMM_ROT")) : 7;      // 0: every workgroup walks K from 0 (A/B switch)
-  hipLaunchKernelGGL((gemm_8pn_kernel<Epi>), dim3(cdiv(p.M, 128) * (p.N / 256), 1, splits), dim3(512), 0, st, a, b, tiles_a, rot_mul, epi);
+  hipLaunchKernelGGL((gemm_8pn_kernel<Epi>), dim3(cdiv(p.M, 128) * (p.N / 256), 1, splits), dim3(512), 0, st, a, b, tiles_a, epi);
   return WIS_OK;
 }
 
@@ -1225,8 +1218,8 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
   p.klen = p.K / splits;
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
-  if (gemm_pp_fits(p, splits) && launch_gemm_8pn(st, p, e) <= 0) {}
-  else if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, p, e);
+  // (the 128 x 256 8-phase tile measured no better here: 33.2 vs 32.5 us for the four K slices of FFN2)
+  if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, p, e);
   else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
   if (Y) {
     if (!ln_gamma || !ln_beta || p.N > 2048 || (splits != 2 && splits != 4)) { set_error("splitk: fused LayerNorm needs gamma, beta, N <= 2048 and 2 or 4 splits"); return WIS_E_ARG; }
