@@ -913,14 +913,13 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   // BEFORE it issues the q / K / V loads above; the first block is unconditional, len >= 1)
   int p0 = 0;
   do {
-    if (p0 > 0) {   // histories beyond 64 positions: next block (not prefetched)
+    if (p0 > 0) {   // histories beyond 64 positions: next block (not prefetched).  Unconditional loads from a clamped position (masked
+                    // below): guarded per position, hipcc serialised the sixteen loads into eight wait-for-the-last-pair round trips
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int p = p0 + 8 * i + pl;
-        if (p < len) {
-          kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)p * d);
-          vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)p * d);
-        }
+        const int p = p0 + 8 * i + pl, pc = p < len ? p : len - 1;
+        kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)pc * d);
+        vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)pc * d);
       }
     }
     float sc[8]; float mx = -INFINITY;
