@@ -414,9 +414,10 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
   const int kbeg = p.klen > 0 ? (int)blockIdx.z * p.klen : 0;
   const int nk = (p.klen > 0 ? p.klen : p.K) / BK;
   // PERSISTENT over output tiles: the grid is min(tiles, CUs) workgroups and workgroup g computes the tiles g, g + grid, ...  The
-  // stores of a tile (128 KiB per workgroup; with one tile per workgroup every CU of a round wrote at the same time and the chip
-  // sat on its HBM write bandwidth: 20 % of the GEMM at 8 utterances, tools/gemm_lab.hip "8p-nostore") are issued and left to drain
-  // while the matrix cores are already on the next tile, whose first seven half-tiles were requested BEFORE those stores.
+  // stores of a tile (128 KiB per workgroup) are issued back to back and left to drain while the matrix cores are already on the
+  // next tile, whose first seven half-tiles were requested BEFORE those stores.  (That only holds since the epilogue carries no load
+  // between its stores - see the bias / residual handling below: with `load, vmcnt(0), store` per row block every wait also covered
+  // the stores before it and the next tile's DMAs, and the loop overlapped nothing.)
   // staging sources: wave w stages local rows (2 w + j) * 8 + (lane >> 3), j = 0, 1, of every half-tile; each pointer is used once
   // per k-tile and advances by one k-tile per use
   const f16 *sNl0, *sNl1, *sNh0, *sNh1, *sMl0, *sMl1, *sMh0, *sMh1;
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
       const int rl = (wave * 2 + j) * 8 + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7);
       // which weight row feeds MFMA row i of 16-row block nb of a wave's 32-row half: 8 (i >> 2) + 4 nb + (i & 3), so that the lane
       // holding MFMA rows 4 kq .. 4 kq + 3 of BOTH blocks of a half owns the 8 consecutive features 8 kq .. 8 kq + 7 - its two
-      // accumulator quads leave as one 16-byte store (the epilogue is store-issue-bound: half the instructions for the f16 outputs)
+      // accumulator quads leave as one 16-byte store (half the store instructions for the f16 outputs)
       const int i16 = rl & 15, nb16 = (rl >> 4) & 1;
       const int n = n0 + (rl >> 5) * 64 + 8 * (i16 >> 2) + 4 * nb16 + (i16 & 3);
       *nl = p.W + (int64_t)n * p.K + kbeg + c * 8;
