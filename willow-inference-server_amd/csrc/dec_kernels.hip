@@ -923,10 +923,13 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   if (ks > 1 && (!p.kpart || !p.kcnt || (p.K / 32) % (4 * ks) || (p.flags & GV_LN))) { set_error("gemv_frag: K split %d unsupported (K=%d)", ks, p.K); return WIS_E_UNSUPPORTED; }
   // two n-tiles per workgroup where there are more n-tiles than CUs (LayerNorm-folded projections: FFN1, vocabulary).  OFF by
-  // default (WIS_FRAG_NB=2 turns it on): measured -2.8 % / -3.5 % of the decode time at 8 / 16 utterances, but at 80 rows x 51872
-  // columns one or two of the 1621 workgroups of a launch come out with features 12 and 14 of their tiles off by 0.1-1.5 in row
-  // blocks 2 and 3 (not reproducible launch to launch; 33-64 and 96 rows, and 80 rows at 5120-25600 columns, were clean) - not
-  // understood yet, so the product keeps one n-tile per workgroup
+  // default (WIS_FRAG_NB=2 turns it on): measured -2.8 % / -3.5 % of the decode time at 8 / 16 utterances, but the five-row-block
+  // instantiation (168 VGPRs, 40 KiB of LDS: THREE workgroups per CU) fails sporadically at 80 rows x 51872 columns - one or two
+  // of a launch's 1621 workgroups come out with features 12 and 14 of their tiles off by one wave's partial sum in row blocks 2
+  // and 3.  Narrowed down on the hardware: clean with two workgroups per CU (LDS padded to 64 KiB, or amdgpu_waves_per_eu(1, 2),
+  // or a six-deep ring = more registers), unchanged by waits / nops around the LDS hand-off or behind the MFMA clusters; the
+  // other instantiations (24 / 32 / 48 KiB, three or two workgroups per CU) never failed.  Cause not understood, so the product
+  // keeps one n-tile per workgroup.
   static const int env_nb = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 1;
   if (env_nb == 2 && (p.flags & GV_LN) && !(p.flags & GV_RESID) && ks == 1 && (npad / 16) % 2 == 0 && npad / 16 > 256) {
     dim3 g2(npad / 32), blk(256);
