@@ -227,13 +227,13 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   // c = x[r][0]: var = E[(x-c)^2] - E[x-c]^2) are reduced AFTER the MFMA loop and meet the accumulators in the epilogue.
   constexpr bool fast = MODE == 1;
   constexpr int RMAX = fast ? RM : 1;        // RM in {3, 5, 8}: smallest that holds M (rows >= M are clamped duplicates)
-  float4 xv[RMAX][2];
+  f32x4 xv[RMAX][2];      // (vector type, not HIP's float4 struct: hipcc split each struct load into an overlapping dwordx2 + dwordx3 pair)
   float cshift[RMAX];
   unsigned long long* pf = (nt == 0 && tid == 0) ? p.prof : nullptr;
   if (tid == 0) tl_begin(p.prof);
   stamp(pf, 0);
   if (fast) {
-    const float4* x4 = reinterpret_cast<const float4*>(p.x);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k4 = tid + 256 * j;
@@ -309,9 +309,9 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
       for (int j = 0; j < 2; ++j) {
         const int k4 = tid + 256 * j;
         if (k4 < k4n) {
-          const f16x4 o = {(f16)xv[r][j].x, (f16)xv[r][j].y, (f16)xv[r][j].z, (f16)xv[r][j].w};
+          const f16x4 o = {(f16)xv[r][j][0], (f16)xv[r][j][1], (f16)xv[r][j][2], (f16)xv[r][j][3]};
           *reinterpret_cast<f16x4*>(xs + (size_t)rr * xstr + k4 * 4) = o;
-          const float a = xv[r][j].x - cshift[r], b = xv[r][j].y - cshift[r], c = xv[r][j].z - cshift[r], e = xv[r][j].w - cshift[r];
+          const float a = xv[r][j][0] - cshift[r], b = xv[r][j][1] - cshift[r], c = xv[r][j][2] - cshift[r], e = xv[r][j][3] - cshift[r];
           sa[r] += (a + b) + (c + e); sb[r] += (a * a + b * b) + (c * c + e * e);
         }
       }
