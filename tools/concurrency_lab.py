@@ -1,6 +1,6 @@
 """Tuning aid: utterances per second with 1..R device batches in flight on one GPU (bench.py's concurrent_batches alone, so that
 launch-side switches can be compared without the whole bench): python tools/concurrency_lab.py [B] [R] [iters]
-Environment switches read by the library at load: WIS_STREAM_PRIO, WIS_GEMM_PERSIST, WIS_CA_SPIN, ..."""
+Environment switches read by the library at load: WIS_GEMM_PERSIST, WIS_CA_SPIN, WIS_FRAG_KSPLIT, ..."""
 import ctypes as C
 import json
 import os
