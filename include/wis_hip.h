@@ -169,9 +169,21 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B,
                      const int32_t* dec_in, int T, float* logits);
 /* the same logits computed R (1..16) positions of every utterance per decoder pass: a pass then has B*R rows, i.e. with
  * B*R > 8 it runs the batched-row route of the decode step (the one 8 utterances x beam 5 take, main.py:685-693 with
- * concurrent requests) instead of the <= 8-row route; B*R <= 48 */
+ * concurrent requests) instead of the <= 8-row route; B*R <= 96 (MAX_ROWS) */
 int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, int B,
                           const int32_t* dec_in, int T, int R, float* logits);
+
+/* rows a11-a13 on caller-supplied logits: the SAMPLING kernels wis_generate runs after every decoder pass (logits processors,
+ * log-softmax statistics, candidate selection, CTranslate2's beam bookkeeping - dec_kernels.hip logit_stats_kernel /
+ * beam_step_kernel) driven by `logits` f32 [n_steps][B*beam][n_vocab] (host) instead of the decoder's output: at step s live beam j of
+ * utterance b reads row s*B*beam + b*beam + j (step 0: row b*beam for every beam, like the merged prefill + first step).  Integer
+ * bookkeeping only, so the result is compared EXACTLY with the oracle's search over the same table (tests/test_gpu_search.py):
+ * an EOT arriving at any step, hypotheses of unequal length, refill from the secondary candidates, patience / early exit,
+ * utterances of one device batch finishing at different steps.  opts->max_new_tokens (0 => n_steps) <= n_steps <= 256.
+ * out_ids [B][max_new], out_len [B], out_score [B] or NULL, out_finish_step [B] or NULL (step index at which the utterance ended),
+ * out_parent [n_steps][B*beam] or NULL (KV slot every live beam continues from after each step: what kv_reorder_kernel applies). */
+int wis_debug_search(wis_model_t* m, const float* logits, int n_steps, int B, const wis_gen_opts_t* opts,
+                     int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* out_finish_step, int32_t* out_parent);
 
 /* ---- timing taps: wall/device ms of the stages of the LAST wis_generate on this handle */
 typedef struct {

@@ -162,102 +162,138 @@ class WhisperRef:
         return lg
 
     # ---- search: CTranslate2 BeamSearch::search (beam_size 1 degenerates to GreedySearch) ------
+    @staticmethod
+    def search(step_fn, k, V, eot, max_new, length_penalty=1.0, patience=1.0):
+        """The bookkeeping of CTranslate2 4.1.0 `BeamSearch::search` (src/decoding.cc, restated from recall - SURVEY App. C) over an
+        arbitrary model: step_fn(step, last_tokens[k], origin[k] or None) -> processed logits [k, V] (float tensor; `origin` = the
+        beam slot each live beam descends from after the previous step, None at step 0).
+
+        2k candidates per step over the flattened beam x vocab log-probs + cumulative score (ties: lower flat id first).  A candidate
+        among the first k that is EOT (or any on the last step) is a finished hypothesis - EOT not included, RAW cumulative score
+        stored - and its slot continues from the next non-EOT candidate beyond the first k (`secondary_candidates_offset`; none left:
+        the slot keeps the EOT candidate).  The utterance ends when round(k * patience) hypotheses exist (allow_early_exit - only for
+        patience 1 and length_penalty 0 - additionally requires the top candidate to be finished), or on the last step.  Hypotheses are
+        ranked by score / len**length_penalty (C++ float semantics: a zero-length hypothesis scores -inf).
+        -> dict(ids, score, hyps [(raw score, tokens)] in registration order, steps, finish_step, trace, trace_full, origins [per
+        continued step: the slot every live beam descends from])
+        trace = per-step DECISION margin: as sets, the step's outcome is {EOT candidates of rank < k} (finished) and the first k
+        non-EOT candidates (live) - so what can change it is an EOT candidate crossing the rank k-1 / k boundary or the k-th / (k+1)-th
+        non-EOT candidate swapping (a swap inside either set only permutes beam slots); greedy: top-1 / top-2; plus the gap between
+        the two best finished hypotheses.  trace_full = the stricter all-adjacent-gaps variant over the top-(2k+1) list."""
+        ncand = 2 * k
+        max_cand = max(1, int(round(k * patience)))
+        allow_early_exit = (patience == 1 and length_penalty == 0)
+        seqs = [[] for _ in range(k)]
+        cum = [0.0] + [float("-inf")] * (k - 1)           # GPU path: beams tiled up front, only the first one live
+        last, origin = None, None
+        hyps, trace, trace_full, origins = [], [], [], []
+        finish_step = None
+        for step in range(max_new):
+            logits = step_fn(step, last, origin).float()
+            logp = torch.log_softmax(logits, dim=-1)
+            flat = (logp + torch.tensor(cum, dtype=torch.float32)[:, None]).reshape(-1)
+            vals, order = torch.sort(flat, descending=True, stable=True)      # ties by lower flat index
+            cand_score = vals[:ncand].tolist()
+            cand_flat = order[:ncand].tolist()
+            cand_word = [f % V for f in cand_flat]
+            cand_org = [f // V for f in cand_flat]
+            is_last = step + 1 >= max_new
+            # ---- margins
+            head = [v for v in vals[:ncand + 1].tolist() if v > float("-inf")] if k > 1 else vals[:2].tolist()
+            gaps = [a - b for a, b in zip(head[:-1], head[1:])]
+            full = min(gaps) if gaps else float("inf")
+            if k == 1:
+                dec = full
+            elif is_last:
+                dec = gaps[k - 1] if len(gaps) >= k else float("inf")       # which k candidates become hypotheses
+            else:
+                dec = float("inf")
+                ext = vals[:ncand + 1].tolist()
+                extw = [f % V for f in order[:ncand + 1].tolist()]
+                for r in range(ncand):
+                    if extw[r] == eot and ext[r] > float("-inf"):
+                        dec = min(dec, ext[r] - ext[k]) if r < k else min(dec, ext[k - 1] - ext[r])
+                non = [ext[r] for r in range(ncand + 1) if extw[r] != eot]
+                if len(non) > k and non[k] > float("-inf"):
+                    dec = min(dec, non[k - 1] - non[k])
+            trace.append(dec)
+            trace_full.append(full)
+            # ---- bookkeeping
+            nxt, second, top_finished = [], k, False
+            for kk in range(k):
+                choice = kk
+                eos = cand_word[kk] == eot
+                if eos or is_last:
+                    if kk == 0:
+                        top_finished = True
+                    hyps.append((cand_score[kk], seqs[cand_org[kk]] + ([] if eos else [cand_word[kk]])))
+                    for j in range(second, ncand):
+                        if cand_word[j] != eot:
+                            choice, second = j, j + 1
+                            break
+                nxt.append(choice)
+            finished = is_last or ((top_finished and len(hyps) >= max_cand) if allow_early_exit else len(hyps) >= max_cand)
+            if finished:
+                finish_step = step
+                break
+            seqs = [seqs[cand_org[c]] + [cand_word[c]] for c in nxt]
+            cum = [cand_score[c] for c in nxt]
+            last = [cand_word[c] for c in nxt]
+            origin = [cand_org[c] for c in nxt]
+            origins.append(origin)
+
+        def norm(h):
+            s, toks = h
+            if length_penalty == 0:
+                return s
+            den = float(len(toks)) ** length_penalty
+            return s / den if den != 0 else (float("-inf") if s < 0 else float("nan"))
+        best, bsc = 0, float("-inf")
+        for i, h in enumerate(hyps):          # first of equal scores wins; nothing beats -inf (engine: `s > best`)
+            if norm(h) > bsc:
+                best, bsc = i, norm(h)
+        others = [norm(h) for i, h in enumerate(hyps) if i != best]
+        if others:                            # the final ranking of the finished hypotheses is a decision too
+            trace.append(bsc - max(others))
+            trace_full.append(trace[-1])
+        return dict(ids=hyps[best][1], score=bsc, hyps=hyps, steps=len(trace_full) - (1 if others else 0), finish_step=finish_step,
+                    trace=trace, trace_full=trace_full, origins=origins)
+
     @torch.no_grad()
     def generate(self, mel, prompt, beam_size=5, max_new_tokens=0, length_penalty=1.0, patience=1.0, suppress_ids=(),
                  suppress_begin=(220, EOT), suppress_blank=True, fixed_new=0, memory=None, return_trace=False):
-        """One utterance: mel [80,3000] (or memory [1500,d]), prompt list[int] -> (ids, score, trace).
+        """One utterance: mel [80,3000] (or memory [1500,d]), prompt list[int] -> (ids, score[, trace]).
 
-        The prompt minus its last token primes the decoder; the last prompt token is the first decoder input
-        (CT2 models/whisper.cc).  2*beam candidates per step over the flattened beam x vocab log-probs + cumulative
-        score (ties: lower flat id first); a candidate in the top `beam` that is EOT (or on the last step) is a
-        finished hypothesis (EOT not included, raw cumulative score stored) and its slot is refilled from the next
-        non-EOT candidate beyond the first `beam`; the utterance ends when `round(beam*patience)` hypotheses exist
-        (allow_early_exit additionally requires the top candidate to be finished and is only active for patience 1,
-        length_penalty 0), or on the last step; hypotheses are ranked by score / len**length_penalty.
-        trace = per-step DECISION margin (see the comment at its computation: the k / k+1 survival boundary, every adjacent gap
-        of the top-(2k+1) list on steps that finish a hypothesis; greedy: top-1 / top-2), plus the gap between the two best
-        finished hypotheses.  The margin rule of SURVEY §8c is applied to min(trace): if it exceeds the engine's score error,
-        every decision of the search is forced and the ids must be identical.  `self.last_trace_full` keeps the stricter
-        all-adjacent-gaps variant of the same run."""
+        The prompt minus its last token primes the decoder; the last prompt token is the first decoder input (CT2
+        models/whisper.cc); the search itself is `search` above.  The margin rule of SURVEY §8c is applied to min(trace): if it
+        exceeds the engine's score error, every decision of the search is forced and the ids must be identical.
+        `self.last_trace_full` keeps the stricter all-adjacent-gaps variant, `self.last_search` the whole search record."""
         if memory is None:
             memory = self.encode(np.asarray(mel, np.float32)[None])[0]
         memory = torch.as_tensor(np.asarray(memory, np.float32))
         P = len(prompt)
         max_new = max_new_tokens if max_new_tokens > 0 else min(self.ctx // 2, self.ctx - P)
         k = beam_size
-        ncand = 2 * k
-        max_cand = max(1, int(round(k * patience)))
-        allow_early_exit = (patience == 1 and length_penalty == 0)
-        V = self.V
-        seqs = [list(prompt) for _ in range(k)]           # full decoder inputs per live beam
-        cum = [0.0] + [float("-inf")] * (k - 1)           # GPU path: beams tiled up front
-        hyps = []                                         # (raw_score, tokens)
-        trace, trace_full = [], []
         ckv = self.cross_kv(memory)
-        cache = [None] * self.L
+        state = {"cache": [None] * self.L}
         if P > 1:                                         # prime the self-attention cache with prompt[:-1]
-            self.decoder_step(np.asarray([prompt[:-1]]), 0, cache, ckv)
-            cache = [(kk.expand(k, -1, -1).contiguous(), vv.expand(k, -1, -1).contiguous()) for kk, vv in cache]
-        last = [prompt[-1]] * k
-        for step in range(max_new):
-            logits = self.decoder_step(np.asarray(last)[:, None], P - 1 + step, cache, ckv).float()
-            logits = self.apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank, fixed_new, self.eot)
-            logp = torch.log_softmax(logits, dim=-1)
-            flat = (logp + torch.tensor(cum, dtype=torch.float32)[:, None]).reshape(-1)
-            # top-ncand, ties by lower flat index: stable sort on (-value)
-            vals, order = torch.sort(flat, descending=True, stable=True)
-            cand_score = vals[:ncand].tolist()
-            cand_flat = order[:ncand].tolist()
-            # margins of this step (finite candidates only; greedy: the top-1 / top-2 gap):
-            #   full = smallest gap between ADJACENT entries of the sorted list from top-1 / top-2 down to the (2k)-th / (2k+1)-th
-            #          boundary that decides membership of the candidate set;
-            #   dec  = smallest gap that can change a DECISION: the k-th / (k+1)-th boundary (which beams survive) - a swap of two
-            #          neighbours inside the top k only permutes the beam slots - unless a hypothesis finishes on this step (an EOT
-            #          among the top k, or the last step), where replacement candidates and hypothesis scores make every gap count.
-            head = [v for v in vals[:ncand + 1].tolist() if v > float("-inf")] if k > 1 else vals[:2].tolist()
-            gaps = [a - b for a, b in zip(head[:-1], head[1:])]
-            full = min(gaps) if gaps else float("inf")
-            finishing = (step + 1 >= max_new) or any((f % V) == self.eot for f in cand_flat[:k])
-            dec = full if (k == 1 or finishing or len(gaps) < k) else gaps[k - 1]
-            trace.append(dec)
-            trace_full.append(full)
-            cand_word = [f % V for f in cand_flat]
-            cand_org = [f // V for f in cand_flat]
-            is_last = step + 1 >= max_new
-            nxt, second, top_finished = [], k, False
-            for kk in range(k):
-                choice = kk
-                eos = cand_word[kk] == self.eot
-                if eos or is_last:
-                    if kk == 0:
-                        top_finished = True
-                    gen = seqs[cand_org[kk]][P:] + ([] if eos else [cand_word[kk]])
-                    hyps.append((cand_score[kk], gen))
-                    for j in range(second, ncand):
-                        if cand_word[j] != self.eot:
-                            choice, second = j, j + 1
-                            break
-                nxt.append(choice)
-            finished = is_last or ((top_finished and len(hyps) >= max_cand) if allow_early_exit else len(hyps) >= max_cand)
-            if finished:
-                break
-            seqs = [seqs[cand_org[c]] + [cand_word[c]] for c in nxt]
-            cum = [cand_score[c] for c in nxt]
-            last = [cand_word[c] for c in nxt]
-            origin = torch.tensor([cand_org[c] for c in nxt])
-            cache = [(kk[origin], vv[origin]) for kk, vv in cache]     # CT2 gathers the self-attention state by beam origin
+            self.decoder_step(np.asarray([prompt[:-1]]), 0, state["cache"], ckv)
+            state["cache"] = [(kk.expand(k, -1, -1).contiguous(), vv.expand(k, -1, -1).contiguous()) for kk, vv in state["cache"]]
 
-        def norm(h):
-            s, toks = h
-            return s / (len(toks) ** length_penalty) if length_penalty != 0 else s
-        best = max(range(len(hyps)), key=lambda i: (norm(hyps[i]), -i))
-        out = (hyps[best][1], norm(hyps[best]))
-        others = [norm(h) for i, h in enumerate(hyps) if i != best]
-        if others:                      # the final ranking of the finished hypotheses is a decision too
-            trace.append(norm(hyps[best]) - max(others))
-            trace_full.append(trace[-1])
-        self.last_trace_full = trace_full
-        return out + (trace,) if return_trace else out
+        def step_fn(step, last, origin):
+            if origin is not None:                        # CT2 gathers the self-attention state by beam origin
+                idx = torch.tensor(origin)
+                state["cache"] = [(kk[idx], vv[idx]) for kk, vv in state["cache"]]
+            toks = [prompt[-1]] * k if last is None else last
+            logits = self.decoder_step(np.asarray(toks)[:, None], P - 1 + step, state["cache"], ckv).float()
+            return self.apply_processors(logits, step, suppress_ids, suppress_begin, suppress_blank, fixed_new, self.eot)
+
+        r = self.search(step_fn, k, self.V, self.eot, max_new, length_penalty, patience)
+        self.last_trace_full = r["trace_full"]
+        self.last_hyps = r["hyps"]
+        self.last_search = r
+        out = (r["ids"], r["score"])
+        return out + (r["trace"],) if return_trace else out
 
     @torch.no_grad()
     def detect_language(self, mel, lang_ids):

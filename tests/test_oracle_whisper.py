@@ -144,3 +144,82 @@ def test_logits_processors():
     assert torch.isfinite(out[:, [220, EOT]]).all()
     out = WhisperRef.apply_processors(lg, 3, [], [220], True, 3)
     assert torch.isfinite(out[:, EOT]).all() and torch.isinf(out[:, 0]).all()
+
+
+def _table_fn(table):
+    """step_fn over a fixed table [steps][k][V] of PROBABILITIES: live beam j reads row j of the step (whatever its history)."""
+    def fn(step, last, origin):
+        return torch.log(torch.tensor(table[step], dtype=torch.float32))
+    return fn
+
+
+def test_search_eot_mid_search_hand_computed():
+    """An EOT that arrives while the search is running (what every real utterance does: reference main.py:687-693 passes no
+    max_length), worked out by hand.  k = 2, V = 5, EOT = 4.
+      step 0 (only beam 0 live): p = [.5 .3 .1 .06 .04]        -> live [0] (.5), [1] (.3)
+      step 1: beam 0: [.1 .1 .1 .1 .6], beam 1: [.7 .1 .1 .05 .05]
+              candidates: (b0, EOT) .30 | (b1, 0) .21 | (b0, 0) .05 | (b0, 1) .05 (exact tie: lower flat id first)
+              -> hypothesis A = [0], raw score ln .30; its slot continues from the secondary candidate (b0, 0): [0, 0] (.05);
+                 slot 1 = [1, 0] (.21); one hypothesis < 2: go on
+      step 2: slot 0: [.25 .25 .25 .15 .10], slot 1: [.05 .05 .1 .1 .7]
+              candidates: (s1, EOT) .147 | (s1, 2) .021 | (s1, 3) .021 | (s0, 0) .0125
+              -> hypothesis B = [1, 0], raw score ln .147; two hypotheses: finished at step 2
+      length_penalty 1: A = ln .30 / 1 = -1.204, B = ln .147 / 2 = -0.9587 -> B;  length_penalty 0: A (-1.204 > -1.917)."""
+    table = [
+        [[.5, .3, .1, .06, .04], [.2, .2, .2, .2, .2]],
+        [[.1, .1, .1, .1, .6], [.7, .1, .1, .05, .05]],
+        [[.25, .25, .25, .15, .10], [.05, .05, .1, .1, .7]],
+        [[.2, .2, .2, .2, .2], [.2, .2, .2, .2, .2]],
+    ]
+    r = WhisperRef.search(_table_fn(table), 2, 5, 4, max_new=4)
+    assert r["ids"] == [1, 0] and abs(r["score"] - np.log(.147) / 2) < 1e-6
+    assert [h[1] for h in r["hyps"]] == [[0], [1, 0]]                      # unequal lengths, registration order
+    assert abs(r["hyps"][0][0] - np.log(.30)) < 1e-6 and abs(r["hyps"][1][0] - np.log(.147)) < 1e-6      # RAW cumulative scores
+    assert r["finish_step"] == 2
+    assert r["origins"] == [[0, 0], [0, 1]]                                # slot 0 of step 1 was refilled from beam 0's next candidate
+    r0 = WhisperRef.search(_table_fn(table), 2, 5, 4, max_new=4, length_penalty=0.0)
+    assert r0["ids"] == [0] and abs(r0["score"] - np.log(.30)) < 1e-6 and r0["finish_step"] == 2
+    # patience 2 -> four hypotheses wanted: the run goes to the last step, where every one of the k candidates is registered with
+    # its last token (no EOT): slot 0 = [1, 0, 3], slot 1 = [1, 0, 2] after step 2 (the refill takes (s1, 3), slot 1 keeps (s1, 2))
+    r2 = WhisperRef.search(_table_fn(table), 2, 5, 4, max_new=4, patience=2.0)
+    assert r2["finish_step"] == 3 and len(r2["hyps"]) == 4
+    assert [h[1] for h in r2["hyps"][:2]] == [[0], [1, 0]] and sorted(len(h[1]) for h in r2["hyps"][2:]) == [4, 4]
+    assert r2["origins"][2] == [1, 1]
+    # greedy: argmax chain until EOT; EOT is not part of the result
+    g = WhisperRef.search(_table_fn([[[.5, .3, .1, .06, .04]], [[.1, .1, .1, .1, .6]]]), 1, 5, 4, max_new=5)
+    assert g["ids"] == [0] and abs(g["score"] - (np.log(.5) + np.log(.6))) < 1e-6 and g["finish_step"] == 1
+    # an EOT as the very first token: the hypothesis is empty; C++ float semantics rank it at score / 0 = -inf (CT2 divides
+    # by the length; WIS never sees this because suppress_blank masks EOT at the first step)
+    e = WhisperRef.search(_table_fn([[[.1, .1, .1, .1, .6]]]), 1, 5, 4, max_new=5)
+    assert e["ids"] == [] and e["score"] == float("-inf")
+
+
+def test_generate_ends_on_eot_by_itself(setup):
+    """The model-level form: weights whose EOT logit rises with the text position (tests/eot_ramp.py), no fixed length, no
+    max-length stop - greedy must equal the arg-max chain up to the first EOT and beam search must return hypotheses that
+    ended at different steps."""
+    from eot_ramp import with_eot_ramp
+    d, L, H, V, w, ref, mel = setup
+    wr = with_eot_ramp(w, start=3, slope=0.6, eot=2)
+    r = WhisperRef(wr, d, L, H, n_vocab=V, eot=2, sot=1)
+    prompt = [1, 5, 9, 11]
+    kw = dict(suppress_ids=[3, 4], suppress_begin=[7, 2])
+    mem = r.encode(mel[:1])
+    ids, score = r.generate(None, prompt, beam_size=1, memory=mem[0].numpy(), **kw)
+    seq, lp = list(prompt), 0.0
+    for step in range(60):
+        lg = r.decode_logits(np.array([seq]), mem)[0, -1].clone()
+        lg[[3, 4]] = float("-inf")
+        if step == 0:
+            lg[[7, 2]] = float("-inf")
+        tok = int(lg.argmax())
+        lp += float(torch.log_softmax(lg, -1)[tok])
+        if tok == 2:
+            break
+        seq.append(tok)
+    assert 1 <= len(ids) < 50 and ids == seq[len(prompt):] and 2 not in ids
+    assert abs(score - lp / len(ids)) < 1e-4
+    ids5, score5, trace = r.generate(None, prompt, beam_size=5, memory=mem[0].numpy(), return_trace=True, **kw)
+    s = r.last_search
+    assert s["finish_step"] < 60 and len(s["hyps"]) >= 5 and 2 not in ids5
+    assert len({len(h[1]) for h in s["hyps"]}) >= 2                       # hypotheses of unequal length were ranked

@@ -38,6 +38,7 @@ size_t enc_attention_part_floats(int B, int T, int H);
 constexpr int MAX_ROWS = 96;      // decoder rows per pass: B*beam (decode) or B*P (merged prefill + first step): 16 utterances x beam 5 + slack; wis_hip/ctranslate2.py MAX_DECODER_ROWS
 constexpr int MAX_R = 8;          // rows per utterance (beam or prompt prefix length)
 constexpr int MAX_CAND = 2 * MAX_R;
+constexpr int MAX_HYP = 3 * MAX_R;      // finished hypotheses an utterance can hold (model.hip make_sample_cfg)
 
 // per-row decode metadata (device arrays, length MAX_ROWS)
 struct RowMeta {

@@ -482,7 +482,7 @@ int alloc_buffers(wis_model* m) {
   }
   WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
   WIS_RET(dalloc(m, &m->rm.slot, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.lslot, MAX_ROWS));
-  const int max_new = 256, max_hyp = 2 * MAX_R;
+  const int max_new = 256, max_hyp = MAX_HYP;
   WIS_RET(dalloc(m, &m->bs.step_u, Bm)); WIS_RET(dalloc(m, &m->bs.done, Bm)); WIS_RET(dalloc(m, &m->bs.n_hyp, Bm));
   WIS_RET(dalloc(m, &m->bs.cum, slots));
   WIS_RET(dalloc(m, &m->bs.alive, (size_t)slots * max_new));
@@ -705,6 +705,39 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   return WIS_OK;
 }
 
+// search state of a device batch: beams tiled up front with scores [0, -inf, ...] (CT2 GPU path), counters cleared
+static int init_beam_state(wis_model* m, int B, int beam) {
+  hipStream_t st = m->st;
+  const int Mrows = B * beam;
+  std::vector<float> cum(Mrows);
+  for (int r = 0; r < Mrows; ++r) cum[r] = (r % beam == 0) ? 0.f : -INFINITY;
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->bs.step_u, 0, (size_t)B * 4, st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->bs.done, 0, (size_t)B * 4, st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->bs.n_hyp, 0, (size_t)B * 4, st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->bs.all_done, 0, 16, st));
+  WIS_HIP_CHECK(hipMemsetAsync(m->bs.out_len, 0, (size_t)B * 4, st));
+  WIS_HIP_CHECK(hipStreamSynchronize(st));   // the host vector goes out of scope
+  return WIS_OK;
+}
+// decoding options -> what the sampling kernels take (CTranslate2 4.1.0 BeamSearch defaults where WIS passes none, main.py:687-693)
+static SampleCfg make_sample_cfg(const wis_model* m, const wis_gen_opts_t* o, int beam, int max_new, float* patience_out) {
+  const wis_config_t& c = m->cfg;
+  SampleCfg sc; memset(&sc, 0, sizeof(sc));
+  sc.n_vocab = c.n_vocab; sc.n_vocab_pad = m->n_vocab_pad; sc.eot = c.eot; sc.beam = beam; sc.n_cand = 2 * beam; sc.max_new = max_new;
+  sc.fixed_new = o->fixed_new_tokens; sc.suppress_blank = o->suppress_blank; sc.greedy = beam == 1;
+  sc.length_penalty = o->length_penalty; sc.max_hyp = MAX_HYP;
+  const float patience = o->patience > 0.f ? o->patience : 1.f;
+  // hypotheses an utterance can hold: the search ends once max_candidates exist and one step adds at most `beam`, so
+  // max_candidates + beam - 1 slots never overflow; a patience beyond that is clamped (MAX_HYP = 3 MAX_R: patience <= 2 at any beam)
+  sc.max_candidates = (int)lroundf((float)beam * patience); if (sc.max_candidates < 1) sc.max_candidates = 1;
+  if (sc.max_candidates > sc.max_hyp - beam + 1) sc.max_candidates = sc.max_hyp - beam + 1;
+  // CT2: allow_early_exit = patience == 1 && length_penalty == 0 && coverage_penalty == 0
+  sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
+  *patience_out = patience;
+  return sc;
+}
+
 int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot) {
   const size_t n = tok.size();
   int* h = m->h_pin + 1024;
@@ -872,26 +905,9 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
 
   // ---- decode state
   const int Mrows = B * beam;
-  {
-    std::vector<float> cum(Mrows);
-    for (int r = 0; r < Mrows; ++r) cum[r] = (r % beam == 0) ? 0.f : -INFINITY;   // CT2 GPU path: beams tiled up front, scores [0, -inf, ...]
-    WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, st));
-    WIS_HIP_CHECK(hipMemsetAsync(m->bs.step_u, 0, (size_t)B * 4, st));
-    WIS_HIP_CHECK(hipMemsetAsync(m->bs.done, 0, (size_t)B * 4, st));
-    WIS_HIP_CHECK(hipMemsetAsync(m->bs.n_hyp, 0, (size_t)B * 4, st));
-    WIS_HIP_CHECK(hipMemsetAsync(m->bs.all_done, 0, 16, st));
-    WIS_HIP_CHECK(hipMemsetAsync(m->bs.out_len, 0, (size_t)B * 4, st));
-    WIS_HIP_CHECK(hipStreamSynchronize(st));   // host vectors go out of scope
-  }
-  SampleCfg sc; memset(&sc, 0, sizeof(sc));
-  sc.n_vocab = c.n_vocab; sc.n_vocab_pad = m->n_vocab_pad; sc.eot = c.eot; sc.beam = beam; sc.n_cand = 2 * beam; sc.max_new = max_new;
-  sc.fixed_new = o->fixed_new_tokens; sc.suppress_blank = o->suppress_blank; sc.greedy = beam == 1;
-  sc.length_penalty = o->length_penalty; sc.max_hyp = 2 * MAX_R;
-  const float patience = o->patience > 0.f ? o->patience : 1.f;
-  sc.max_candidates = (int)lroundf((float)beam * patience); if (sc.max_candidates < 1) sc.max_candidates = 1;
-  if (sc.max_candidates > sc.max_hyp - beam) sc.max_candidates = sc.max_hyp - beam > 0 ? sc.max_hyp - beam : 1;
-  // CT2: allow_early_exit = patience == 1 && length_penalty == 0 && coverage_penalty == 0
-  sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
+  WIS_RET(init_beam_state(m, B, beam));
+  float patience;
+  const SampleCfg sc = make_sample_cfg(m, o, beam, max_new, &patience);
   const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
 
   // ---- prefill + FIRST decode step in one pass: all P prompt tokens of an utterance are rows (b, i) at positions i in the
@@ -981,6 +997,52 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   hipEventElapsedTime(&ms, m->ev[4], m->ev[5]); m->timing.decode_ms = ms;
   m->timing.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   m->timing.decode_steps = steps;
+  return WIS_OK;
+}
+
+int wis_debug_search(wis_model_t* m, const float* logits, int n_steps, int B, const wis_gen_opts_t* o,
+                     int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* out_finish_step, int32_t* out_parent) {
+  if (!m || !logits || !o || !out_ids || !out_len || n_steps < 1 || n_steps > 256) { set_error("wis_debug_search: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_debug_search")
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  const wis_config_t& c = m->cfg;
+  const int beam = o->beam_size < 1 ? 1 : o->beam_size;
+  WIS_RET(check_batch(m, B, beam));
+  const int max_new = o->max_new_tokens > 0 ? std::min(o->max_new_tokens, 256) : n_steps;
+  if (max_new > n_steps) { set_error("wis_debug_search: %d steps of logits for max_new_tokens %d", n_steps, max_new); return WIS_E_ARG; }
+  hipStream_t st = m->st;
+  const int Mrows = B * beam, V = c.n_vocab, P = 1;
+  WIS_RET(init_beam_state(m, B, beam));
+  float patience;
+  const SampleCfg sc = make_sample_cfg(m, o, beam, max_new, &patience);
+  const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
+  std::vector<int> done(B, 0), fin(B, -1), par(Mrows);
+  for (int s = 0; s < max_new; ++s) {
+    WIS_HIP_CHECK(hipMemcpy2DAsync(m->logits, (size_t)m->n_vocab_pad * 4, logits + (size_t)s * Mrows * V, (size_t)V * 4, (size_t)V * 4, Mrows, hipMemcpyHostToDevice, st));
+    // step 0 samples every beam of an utterance from ONE row (wis_generate: the last prompt row; here row b*beam), later steps row b*beam + j
+    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, beam, s == 0 ? 0 : 1, 0));
+    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, c.n_text_ctx, sc));
+    WIS_HIP_CHECK(hipMemcpyAsync(done.data(), m->bs.done, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipMemcpyAsync(par.data(), m->bs.parent, (size_t)Mrows * 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipStreamSynchronize(st));
+    bool all = true;
+    for (int b = 0; b < B; ++b) { if (done[b] && fin[b] < 0) fin[b] = s; all = all && done[b]; }
+    if (out_parent) for (int r = 0; r < Mrows; ++r) out_parent[(size_t)s * Mrows + r] = par[r];
+    if (all) break;
+  }
+  for (int b = 0; b < B; ++b) if (fin[b] < 0) { set_error("wis_debug_search: utterance %d did not finish within %d steps", b, max_new); return WIS_E_STATE; }
+  std::vector<int32_t> ids((size_t)B * 256);
+  std::vector<float> sc_h(B);
+  WIS_HIP_CHECK(hipMemcpyAsync(ids.data(), m->bs.out_ids, (size_t)B * 256 * 4, hipMemcpyDeviceToHost, st));
+  WIS_HIP_CHECK(hipMemcpyAsync(out_len, m->bs.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  WIS_HIP_CHECK(hipMemcpyAsync(sc_h.data(), m->bs.out_score, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  WIS_HIP_CHECK(hipStreamSynchronize(st));
+  for (int b = 0; b < B; ++b) {
+    if (out_len[b] > max_new) out_len[b] = max_new;
+    for (int t = 0; t < max_new; ++t) out_ids[(size_t)b * max_new + t] = t < out_len[b] ? ids[(size_t)b * max_new + t] : 0;
+    if (out_score) out_score[b] = sc_h[b];
+    if (out_finish_step) out_finish_step[b] = fin[b];
+  }
   return WIS_OK;
 }
 
