@@ -115,7 +115,7 @@ def test_greedy_ends_on_eot(which, request, mel):
         assert s["finish_step"] < 100 and len(r.sequences_ids[0]) < 100       # ended on EOT, far from max_new = 224
         exact += same; lens.add(len(r.sequences_ids[0]))
     print(f"{which} greedy, natural EOT: {exact} of 4 identical, lengths {sorted(lens)}")
-    assert exact >= 3 and len(lens) >= 2
+    assert exact >= 3 and len(lens) >= 2          # observed on MI355X: 4 of 4
 
 
 @pytest.mark.parametrize("beam,lp,patience", [(5, 1.0, 1.0), (3, 1.0, 1.0), (5, 0.0, 1.0), (5, 1.0, 2.0), (2, 0.0, 2.0), (8, 1.0, 1.0)])
@@ -131,7 +131,7 @@ def test_beam_search_ends_on_eot(tiny, mel, beam, lp, patience):
         exact += same
         unequal += len({len(h[1]) for h in s["hyps"]}) > 1
     print(f"tiny beam {beam} lp {lp} patience {patience}, natural EOT: {exact} of 4 identical; searches that ranked hypotheses of unequal length: {unequal}")
-    assert unequal >= 1 and exact >= 2
+    assert unequal >= 1 and exact >= 3          # observed on MI355X: 4 of 4 in every configuration
 
 
 def test_beam5_base_ends_on_eot(base, mel):
@@ -145,7 +145,7 @@ def test_beam5_base_ends_on_eot(base, mel):
         assert s["finish_step"] < 100
         exact += same
     print(f"base beam 5, natural EOT: {exact} of 3 identical")
-    assert exact >= 1
+    assert exact >= 2          # observed: 3 of 3
 
 
 def test_short_max_length_with_eot_candidates(tiny, mel):
@@ -184,7 +184,7 @@ def test_ragged_termination_in_a_device_batch(tiny, mel, B, beam):
     print(f"{B} x beam {beam}: oracle finish steps {finish}, engine ran {steps} steps, {exact} of {B} identical")
     assert len(set(finish)) >= (3 if B > 3 else 2)
     assert max(finish) - 1 <= steps <= max(finish) + 1 + 6          # stopped at the first host poll (every 4 steps) after the last utterance ended
-    assert exact >= B // 2
+    assert exact >= B - 1          # observed on MI355X: every utterance identical at 3 / 40 / 80 / 96 rows
     # an utterance decoded alone gives the same answer as inside the batch (or an oracle-rescored near-tie, checked above)
     one = model.generate(ct2.StorageView.from_array(np.ascontiguousarray(mel[None])), [prompts[B - 1]], beam_size=beam)[0]
     if one.sequences_ids != res[B - 1].sequences_ids:

@@ -191,7 +191,37 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
             if margin > 0.02:
                 assert got == ids
             exact += got == ids
-        assert exact >= 1
+        assert exact >= 7          # observed on MI355X: 8 of 8 (a near-tie may flip one)
+    if size == "large":
+        # ---- decoding that ends ON EOT at this size (reference main.py:687-693: no max_length, no fixed length): the same weights with
+        # an EOT ramp on the decoder positions (tests/eot_ramp.py; the encoder and its memory are unchanged), nothing masked or
+        # forced.  One utterance at beam 5 (the <= 8-row route) and a device batch of 8 whose prompts differ, so that the utterances
+        # end at different steps while their rows stay in the 40-row passes (the fragment-image route); bars as tests/test_gpu_eot.py
+        import copy
+        from eot_ramp import with_eot_ramp
+        from test_gpu_eot import check_utterance
+        wr = with_eot_ramp(w, start=3, slope=1.2)
+        model_r = ct2.Whisper("unused", weights=wr, arch=a, max_batch=8, max_beam=5)
+        ref_r = copy.copy(ref)
+        ref_r.w = dict(ref.w)
+        ref_r.w["decoder/position_encodings/encodings"] = torch.from_numpy(np.asarray(wr["decoder/position_encodings/encodings"], np.float32))
+        memory = mem[0].numpy()
+        feats1 = ct2.StorageView.from_array(np.ascontiguousarray(mels[:1]))
+        r1 = model_r.generate(feats1, [PROMPT], beam_size=5)[0]
+        same1, s1 = check_utterance(ref_r, memory, PROMPT, r1.sequences_ids[0], r1.scores[0], 5, tag="large, natural EOT")
+        assert s1["finish_step"] < 60 and len({len(h[1]) for h in s1["hyps"]}) > 1
+        prompts4 = [[50258, 50259, 50359, 40763], [50258, 50280, 50359, 12603], [50258, 50287, 50359, 9886], [50258, 50266, 50359, 5196]]
+        order8 = [0, 1, 2, 3, 1, 0, 3, 2]
+        batch = ct2.StorageView.from_array(np.ascontiguousarray(np.repeat(mels[:1], 8, axis=0)))
+        r8 = model_r.generate(batch, [prompts4[i] for i in order8], beam_size=5)
+        exact, finish = int(same1), {}
+        for i, r in enumerate(r8):
+            same, s = check_utterance(ref_r, memory, prompts4[order8[i]], r.sequences_ids[0], r.scores[0], 5, tag=f"large 8 x beam 5, natural EOT, utterance {i}")
+            exact += same; finish[order8[i]] = s["finish_step"]
+        print(f"large, natural EOT: {exact} of 9 identical to the oracle; finish steps of the four prompts {finish}; engine ran {model_r.last_timing()['decode_steps']} steps")
+        assert len(set(finish.values())) >= 3 and exact >= 7
+        assert r8[0].sequences_ids == r8[5].sequences_ids and r8[1].sequences_ids == r8[4].sequences_ids       # same prompt, same answer, whatever the slot
+        model_r.close()
     if size == "medium":
         # ---- int8_float16 (reference GPU default, main.py:242) at this size: the oracle on the de-quantised decoder weights, both
         # row routes of the decode step (<= 8 rows and the batched fragment images)

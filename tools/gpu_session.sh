@@ -9,9 +9,11 @@
 #                   environment assignments for that run and become part of the output name
 #   benchfull       the default bench.py line (what the driver runs)
 #   prof<N>         rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
+#   frag2 [iters]   tools/bin/frag2_lab in its three flag variants (as the library / -fno-slp-vectorize / accumulators in AGPRs): the two-n-tile
+#                   skinny GEMM against the shipped kernel, bit for bit, with LDS dump + hardware ids of a failing workgroup -> frag2_*.txt
 #   pmc <tag> "<COUNTER ...>" [batch]   one rocprofv3 --pmc pass of the eager bench (default 8 utterances) -> pmc_<tag>_b<batch>.txt (per kernel and grid: launches, mean per launch)
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${WIS_TAG:-r3}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
+TAG=${WIS_TAG:-r4}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
 R=$GRAFT_REPO_ROOT
 run_bench() {   # $1 = batch, rest = env assignments
   local B=$1; shift
@@ -52,6 +54,9 @@ while [ $# -gt 0 ]; do
       [ "$B" = 1 ] && python tools/spread.py "$DB" 32 > "$O/spread_b1.txt" 2>&1
       find "$O/prof_b$B" -name "*.db" -delete
       head -30 "$O/kernel_stats_b$B.txt" ;;
+    frag2)
+      IT=100; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then IT=$1; shift; fi
+      for v in frag2_lab frag2_lab_noslp frag2_lab_agpr; do [ -x tools/bin/$v ] && { timeout 120 tools/bin/$v "$IT" > "$O/$v.txt" 2>&1; echo "== $v"; grep -c "differing words" "$O/$v.txt"; grep "^variant\|^shipped\|reference launch" "$O/$v.txt"; }; done ;;
     pmc)      # pmc <tag> "<COUNTER ...>" [batch]: ONE rocprofv3 --pmc pass (counters only with --kernel-trace, as gpurun requires) of the eager bench
       PT=$1; CNT=$2; shift 2; PB=8; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then PB=$1; shift; fi
       ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc_$PT" -o p --output-format csv -- python "$R/bench.py" --steps 2 --warmup 1 --batch "$PB" --no-cpu-baseline --no-extras --no-roofline > "$O/pmc_$PT.log" 2>&1 )

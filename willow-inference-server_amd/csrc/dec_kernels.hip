@@ -19,6 +19,7 @@
 //  * suppress masks, log-softmax statistics and the top-2*beam candidates are computed in one
 //    pass over the logits (16 chunks per row), the beam bookkeeping runs on device (one wave per
 //    utterance) so the host never sees logits and a whole step replays as one HIP graph.
+#include <string.h>
 #include <atomic>
 #include <mutex>
 #include "common.hpp"
@@ -585,16 +586,17 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 //   y = rs * (W'x - mu * c) + b'.
 // Residual epilogues (GV_RESID) write the fp32 rows in place, their f16 fragment image for the next projection and the partials.
 template <int MB, int PF, bool W8>
-__global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
+__device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, const int KS, const int ksi) {
   typedef typename WFrag<W8>::T WT;
   constexpr int EPN = (MB + 3) / 4;      // row blocks a wave finishes in the epilogue: wave w owns blocks w, w + 4 (up to 96 rows = 6 blocks)
   __shared__ __attribute__((aligned(16))) float red[4 * MB * 64 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockIdx.x;
-  // K slices (gridDim.y > 1: the K = 4d projection - 80 workgroups would each pull the whole activation image and a 160 KiB weight
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // K slices (KS > 1: the K = 4d projection - 80 workgroups would each pull the whole activation image and a 160 KiB weight
   // panel through one CU's ~55 GB/s; see GemvP::ksplit): slice ksi covers the k-steps [ksi, ksi + 1) * ksteps / KS, a quarter per wave
-  const int KS = gridDim.y, ksi = blockIdx.y;
   const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps / (4 * KS);
-  const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * ksteps + (size_t)(ksi * 4 + wave) * S) * 64 + lane;
+  // (wks / wk0: the matrix is a k-step window of a wider packed image - the two halves of the folded cross-Q matrix [W'q | W'q Wo])
+  const int wks = p.wks ? p.wks : ksteps;
+  const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * wks + p.wk0 + (size_t)(ksi * 4 + wave) * S) * 64 + lane;
   const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)(ksi * 4 + wave) * S * MB * 64 + lane;
   WT a[PF]; u32x4 b[PF][MB];
 #pragma unroll
@@ -781,6 +783,24 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
   }
 }
 
+template <int MB, int PF, bool W8>
+__global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
+  gemv_frag_body<MB, PF, W8>(p, blockIdx.x, gridDim.y, blockIdx.y);
+}
+// Up to three skinny GEMMs of one row count in ONE launch (f16 weights, no K split): workgroups [0, n0) run problem 0, the next n1
+// problem 1, the rest problem 2 - a dependent stage less per decoder layer at 9-96 rows (model.hip dec_forward_frag): the self-attention
+// output projection together with the two halves of the cross-attention query folded THROUGH it (q_raw = W'q x0 + (W'q Wo) a + W'q bo:
+// one half reads the layer input's fragment image, the other the attention output's; the cross-attention kernel adds the halves and
+// applies the LayerNorm statistics of the rows the out-projection produces in this same launch).
+struct GemvP3 { GemvP p[3]; int n0, n1; };
+template <int MB, int PF>
+__global__ __launch_bounds__(256) void gemv_frag3_kernel(GemvP3 ps) {
+  const int b = blockIdx.x;
+  const int sel = b < ps.n0 ? 0 : (b < ps.n0 + ps.n1 ? 1 : 2);
+  const int nt = sel == 0 ? b : (sel == 1 ? b - ps.n0 : b - ps.n0 - ps.n1);
+  gemv_frag_body<MB, PF, false>(ps.p[sel], nt, 1, 0);
+}
+
 // The same skinny GEMM with TWO n-tiles (32 output columns) per workgroup, for the LayerNorm-folded projections that have more
 // n-tiles than the chip has CUs (FFN1: 320, vocabulary: 3242): a workgroup's ingest is its weight panel PLUS the whole activation
 // image (41 + 123 KB at 8 utterances), a CU takes in ~55 GB/s, and with 320 one-tile workgroups 64 CUs get two of them - the
@@ -913,6 +933,34 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(GemvP p) {
       }
     }
   }
+}
+
+int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n) {
+  if (n < 2 || n > 3) { set_error("gemv_frag3: %d problems", n); return WIS_E_ARG; }
+  GemvP3 ps; memset(&ps, 0, sizeof(ps));
+  int nts[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const GemvP& g = p[i];
+    if (g.M != p[0].M || g.xmb != p[0].xmb || g.K != p[0].K || g.M < 1 || g.M > MAX_ROWS || g.K % 128 || g.N % 16 || g.xmb != cdiv(g.M, 16) || g.wscale || g.ksplit > 1 ||
+        (g.flags & (GV_LN | GV_QKV))) { set_error("gemv_frag3: problem %d unsupported (M=%d N=%d K=%d flags=%d)", i, g.M, g.N, g.K, g.flags); return WIS_E_UNSUPPORTED; }
+    ps.p[i] = g; nts[i] = g.N / 16;
+  }
+  if (n == 2) ps.p[2] = ps.p[1];
+  ps.n0 = nts[0]; ps.n1 = nts[1];
+  dim3 grid(nts[0] + nts[1] + nts[2]), block(256);
+  const bool s10 = p[0].K == 1280;
+#define WIS_GF3(MBv, PFA, PFB) do { if (s10) hipLaunchKernelGGL((gemv_frag3_kernel<MBv, PFA>), grid, block, 0, st, ps); else hipLaunchKernelGGL((gemv_frag3_kernel<MBv, PFB>), grid, block, 0, st, ps); } while (0)
+  switch (p[0].xmb) {
+    case 1: WIS_GF3(1, 10, 8); break;
+    case 2: WIS_GF3(2, 10, 8); break;
+    case 3: WIS_GF3(3, 10, 8); break;
+    case 4: WIS_GF3(4, 6, 6); break;
+    case 5: WIS_GF3(5, 6, 6); break;
+    case 6: WIS_GF3(6, 6, 6); break;
+    default: set_error("gemv_frag3: %d row blocks unsupported", p[0].xmb); return WIS_E_UNSUPPORTED;
+  }
+#undef WIS_GF3
+  return WIS_OK;
 }
 
 int launch_gemv_frag(hipStream_t st, const GemvP& p) {
@@ -1180,12 +1228,16 @@ __device__ __forceinline__ void st_gran(gran_t* p, unsigned tag, float v) {
 __device__ __forceinline__ gran_t ld_gran(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr unsigned CA_SPIN_LIMIT = 1u << 17;      // sweeps before the combiner gives up (~0.1 s)
 
-template <int TPW, int CM, bool FOLD, bool SPIN>
+// FOLD: 0 = q is the finished query; 1 = folded query, statistics reduced from the rows themselves (xres = x1 fp32 [B*R][d]: the one-utterance
+// step); 2 = folded query of the BATCHED step: q_raw arrives as two halves (q + q2: W'q x0 + W'q bo and (W'q Wo) a, model.hip
+// dec_forward_frag) and the statistics come from the per-16-column (sum, M2) partials the out-projection's residual epilogue left
+// (xres = [B*R][d/16][2]; merged like gemv_frag_kernel merges them) - 80 pairs per row instead of 1280 floats.
+template <int TPW, int CM, int FOLD, bool SPIN>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              f16* __restrict__ out, float* part, unsigned* counters,
                                                              int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb,
                                                              const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb,
-                                                             gran_t* gran, unsigned* epoch) {
+                                                             gran_t* gran, unsigned* epoch, const float* __restrict__ q2) {
   __shared__ float ssc[16][257];
   __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
   __shared__ float smax[16][16];
@@ -1211,10 +1263,22 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // to the rows the out-projection has produced SINCE (xres = x1, fp32 [B*R][d]).  Every workgroup reduces its utterance's R
   // rows itself (R x d floats from L2, requested together with K and V) and finishes q = rs (q_raw - mu c) + b'.
   // wave w reduces rows w and w + 4 of the utterance (R <= 8): 5 float4 per lane and row cover d <= 1280
-  constexpr int NXS = FOLD ? 5 : 1;
+  constexpr int NXS = FOLD == 1 ? 5 : 1;
   float4 xs4[2][NXS]; float4 cs0, cs1, cs2, cs3, bq0, bq1, bq2, bq3;
-  const int d4 = d >> 2;
-  if (FOLD) {
+  float4 qc0, qc1, qc2, qc3; float2 pt[2][2];
+  const int d4 = d >> 2, ntile = d >> 4;
+  if (FOLD == 2) {
+    const float* qp2 = q2 + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
+    qc0 = *reinterpret_cast<const float4*>(qp2); qc1 = *reinterpret_cast<const float4*>(qp2 + 4); qc2 = *reinterpret_cast<const float4*>(qp2 + 32); qc3 = *reinterpret_cast<const float4*>(qp2 + 36);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {      // wave w merges the partials of rows w and w + 4: lane = tile (and tile + 64; d <= 2048)
+      const int r = wave + 4 * j;
+      const float2* sp = reinterpret_cast<const float2*>(xres) + (size_t)(b * R + (r < R ? r : R - 1)) * ntile;
+      pt[j][0] = sp[lane < ntile ? lane : ntile - 1];
+      pt[j][1] = sp[lane + 64 < ntile ? lane + 64 : ntile - 1];
+    }
+  }
+  if (FOLD == 1) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = wave + 4 * j;
@@ -1222,6 +1286,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 #pragma unroll
       for (int i = 0; i < NXS; ++i) { const int c4 = lane + 64 * i; xs4[j][i] = xr[c4 < d4 ? c4 : d4 - 1]; }      // unconditional (clamped; masked in the sums): no exec-masked branch between the loads
     }
+  }
+  if (FOLD) {
     const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
     cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
     bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
@@ -1237,8 +1303,13 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   constexpr int NSTEP = 2 * TPW;                      // 32-key P.V steps per chunk; V^T is zero padded up to Tpad >= chunks * CL
   const f16* vb = vt + ((size_t)(b * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
   u32x4 vf[NSTEP];
+  // (batched fold: the V fragments are requested BEHIND the query prologue - its column sums, biases, second q half and partials
+  // are dead by then, so the kernel stays near the 88 registers of the plain form (five workgroups per CU: the 960 workgroups of an
+  // 8-utterance batch in one round) instead of 153 (three per CU); V is not needed before the softmax)
+  if (FOLD != 2) {
 #pragma unroll
-  for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
+    for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
+  }
   stamp(pf, 1);
 
   float4 qa0 = qa0_, qa1 = qa1_, qb0 = qb0_, qb1 = qb1_;
@@ -1252,6 +1323,19 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     for (int j = 0; j < 2; ++j) {
       const int r = wave + 4 * j;
       float a1 = 0.f, a2 = 0.f;
+      if (FOLD == 2) {
+        // Chan merge of the (sum, M2 about the tile mean) pairs about c0 = the first tile's mean (gemv_frag_kernel's one-pass form):
+        //   mu = c0 + mean_t (m_t - c0),   var = (sum_t (M2_t + 16 (m_t - c0)^2)) / d - (mu - c0)^2
+        const float c0 = readlane_f(pt[j][0].x, 0) * 0.0625f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bool in = lane + 64 * i < ntile;
+          const float dm = in ? pt[j][i].x * 0.0625f - c0 : 0.f;
+          a1 += dm; a2 += in ? pt[j][i].y + 16.0f * dm * dm : 0.f;
+        }
+        a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0 && r < R) { const float invd = 1.0f / (float)d, dmu = a1 * 16.0f * invd; srow[r][0] = c0 + dmu; srow[r][1] = 1.0f / sqrtf(fmaxf(a2 * invd - dmu * dmu, 0.f) + 1e-5f); }
+      } else {
       // ONE pass, shifted by the row's first element: no E[x^2] - mu^2 cancellation for rows with a large common offset, and both
       // wave reductions issue together (a second pass over the registers about the exact mean measured +2.3 us per launch)
       const float c0 = readlane_f(xs4[j][0].x, 0);
@@ -1264,13 +1348,23 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       }
       a1 = wave_sum(a1); a2 = wave_sum(a2);
       if (lane == 0 && r < R) { const float ms = a1 / (float)d; srow[r][0] = c0 + ms; srow[r][1] = 1.0f / sqrtf(fmaxf(a2 / (float)d - ms * ms, 0.f) + 1e-5f); }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float mu = srow[rq][0], rs = srow[rq][1];
+    if (FOLD == 2) {      // the two halves of q_raw
+      qa0 = make_float4(qa0.x + qc0.x, qa0.y + qc0.y, qa0.z + qc0.z, qa0.w + qc0.w); qa1 = make_float4(qa1.x + qc1.x, qa1.y + qc1.y, qa1.z + qc1.z, qa1.w + qc1.w);
+      qb0 = make_float4(qb0.x + qc2.x, qb0.y + qc2.y, qb0.z + qc2.z, qb0.w + qc2.w); qb1 = make_float4(qb1.x + qc3.x, qb1.y + qc3.y, qb1.z + qc3.z, qb1.w + qc3.w);
+    }
     qa0 = make_float4(rs * (qa0.x - mu * cs0.x) + bq0.x, rs * (qa0.y - mu * cs0.y) + bq0.y, rs * (qa0.z - mu * cs0.z) + bq0.z, rs * (qa0.w - mu * cs0.w) + bq0.w);
     qa1 = make_float4(rs * (qa1.x - mu * cs1.x) + bq1.x, rs * (qa1.y - mu * cs1.y) + bq1.y, rs * (qa1.z - mu * cs1.z) + bq1.z, rs * (qa1.w - mu * cs1.w) + bq1.w);
     qb0 = make_float4(rs * (qb0.x - mu * cs2.x) + bq2.x, rs * (qb0.y - mu * cs2.y) + bq2.y, rs * (qb0.z - mu * cs2.z) + bq2.z, rs * (qb0.w - mu * cs2.w) + bq2.w);
     qb1 = make_float4(rs * (qb1.x - mu * cs3.x) + bq3.x, rs * (qb1.y - mu * cs3.y) + bq3.y, rs * (qb1.z - mu * cs3.z) + bq3.z, rs * (qb1.w - mu * cs3.w) + bq3.w);
+  }
+  if (FOLD == 2) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
   }
   f16x8 qf0, qf1;
   qf0[0] = (f16)qa0.x; qf0[1] = (f16)qa0.y; qf0[2] = (f16)qa0.z; qf0[3] = (f16)qa0.w; qf0[4] = (f16)qa1.x; qf0[5] = (f16)qa1.y; qf0[6] = (f16)qa1.z; qf0[7] = (f16)qa1.w;
@@ -1473,8 +1567,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
-                          const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch) {
-  if (xres && (!qcs || !qb || R > 8 || d > 1280)) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280"); return WIS_E_ARG; }
+                          const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch, const float* q2, int xres_is_stat) {
+  if (xres && (!qcs || !qb || R > 8 || d > (xres_is_stat ? 2048 : 1280))) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280 (2048 from partials)"); return WIS_E_ARG; }
+  if (xres_is_stat && (!xres || !q2)) { set_error("dec_cross_attn: the batched fold needs the row partials and the second half of q_raw"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
@@ -1483,10 +1578,13 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
   // granule hand-off: small grids only (fewer spinning combiners than CUs), the default 256-key chunking, <= 8 rows per utterance
   const bool spin = env_spin && gran && epoch && B * H <= CA_SPIN_MAX_BH && CL == 256 && used >= 2 && used <= 6 && R <= 8;
 #define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, \
-                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb, gran, epoch)
-  if (spin) { if (xres) WIS_CA(4, 6, true, true); else WIS_CA(4, 6, false, true); }
-  else if (xres) { if (CL <= 128) WIS_CA(2, 16, true, false); else if (used <= 6) WIS_CA(4, 6, true, false); else WIS_CA(4, 16, true, false); }
-  else { if (CL <= 128) WIS_CA(2, 16, false, false); else if (used <= 6) WIS_CA(4, 6, false, false); else WIS_CA(4, 16, false, false); }
+                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb, gran, epoch, q2)
+  if (xres_is_stat) {
+    if (spin) WIS_CA(4, 6, 2, true); else if (CL <= 128) WIS_CA(2, 16, 2, false); else if (used <= 6) WIS_CA(4, 6, 2, false); else WIS_CA(4, 16, 2, false);
+  }
+  else if (spin) { if (xres) WIS_CA(4, 6, 1, true); else WIS_CA(4, 6, 0, true); }
+  else if (xres) { if (CL <= 128) WIS_CA(2, 16, 1, false); else if (used <= 6) WIS_CA(4, 6, 1, false); else WIS_CA(4, 16, 1, false); }
+  else { if (CL <= 128) WIS_CA(2, 16, 0, false); else if (used <= 6) WIS_CA(4, 6, 0, false); else WIS_CA(4, 16, 0, false); }
 #undef WIS_CA
   return WIS_OK;
 }

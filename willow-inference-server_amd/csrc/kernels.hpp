@@ -74,6 +74,9 @@ struct GemvP {
   // to kpart [N/16][ksplit][xmb][64] float4 and the last-arriving slice of an n-tile (ticket kcnt[N/16], zero-initialised once,
   // re-armed by the winner) adds the slices in index order and runs the epilogue
   int ksplit; float* kpart; unsigned* kcnt;
+  // the weight matrix as a k-step window of a wider packed image (launch_gemv_frag / launch_gemv_frag3): wks = k-steps per n-tile of
+  // the image (0: K / 32, the matrix is the whole image), wk0 = first k-step of the window
+  int wks, wk0;
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
 int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // two f16-activation skinny GEMMs in one launch
@@ -82,6 +85,8 @@ int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // t
 // the pre-LN LayerNorm needs no launch of its own: every residual epilogue leaves per-16-column partial sums of the rows it
 // produced, the folded projection that follows (W o gamma, b + W.beta, column sums) turns them into mean / rstd in its epilogue.
 int launch_gemv_frag(hipStream_t st, const GemvP& p);
+// n (2 or 3) such GEMMs of one row count in one launch (f16 weights, no K split, same K / 128 for all): see gemv_frag3_kernel
+int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n);
 // activation fragment image: element (row m, column k) of an [M][K] matrix, MB = ceil(M / 16) row blocks:
 //   [k / 32][m / 16][lane = (m % 16) + 16 * ((k / 8) % 4)][k % 8]      (one 1 KiB wave load per (k-step, row block))
 __host__ __device__ static inline size_t xf_index(int m, int k, int MB) {
@@ -111,7 +116,8 @@ constexpr int CA_SPIN_MAX_BH = 192;      // spinning combiners per launch: fewer
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0,
                           const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr,   // folded query: see the kernel
-                          unsigned long long* gran = nullptr, unsigned* epoch = nullptr);
+                          unsigned long long* gran = nullptr, unsigned* epoch = nullptr,
+                          const float* q2 = nullptr, int xres_is_stat = 0);   // batched fold: q = q + q2; xres = row partials [B*R][d/16][2] instead of the rows
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {

@@ -150,6 +150,7 @@ struct wis_model {
   size_t kx_lstride = 0, vx_lstride = 0;
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
+  float* dq2 = nullptr;         // batched fold: second half of the cross-attention q_raw (dec_forward_frag)
   float* gf_part = nullptr; unsigned* gf_cnt = nullptr; int gf_ksplit = 1;      // K split of the batched FFN2 skinny GEMM: slice sums, tickets (GemvP::ksplit)
   unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
   f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
@@ -448,6 +449,7 @@ int alloc_buffers(wis_model* m) {
   }
   WIS_RET(dalloc(m, &m->dx, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dq, (size_t)MAX_ROWS * d));
+  WIS_RET(dalloc(m, &m->dq2, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dao, (size_t)MAX_ROWS * d));
   WIS_RET(dalloc(m, &m->dh, (size_t)MAX_ROWS * 4 * d));
   WIS_RET(dalloc(m, &m->dln, (size_t)MAX_ROWS * d));
@@ -597,6 +599,10 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx, MB = cdiv(M, 16);
   WIS_RET(launch_dec_embed_xf(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, m->dxf, m->dstat, M, d, MB));
+  // cross-Q folded through the self-attention out-projection (f16 weights; <= 8 rows per utterance: the cross-attention kernel's
+  // statistics prologue); WIS_NO_FRAG_FOLD=1 keeps the two-launch form (A/B switch)
+  static const bool no_frag_fold = getenv("WIS_NO_FRAG_FOLD") != nullptr;
+  const bool fold = m->cq_fold && !no_frag_fold && R <= 8;
   auto base = [&](const void* x, const f16* Wp, const float* wscale, const float* bias, int N, int K, int flags) {
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = x; g.Wp = Wp; g.wscale = wscale; g.bias = bias; g.M = M; g.N = N; g.K = K; g.flags = flags; g.xmb = MB; g.rows = 16;
@@ -608,6 +614,24 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     g.csum = w.c_qkv; g.stat_in = m->dstat; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     WIS_RET(launch_gemv_frag(st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB));
+    if (fold) {
+      // ONE launch, three d x d problems on 3 d / 16 workgroups: x1 = x0 + Wo a + bo (residual rows + their LayerNorm partials; nobody
+      // reads x1's fragment image any more, so none is written and x0's image stays valid for the other two), q_A = W'q x0 + W'q bo
+      // from the layer input's image, q_B = (W'q Wo) a from the attention output's - the two k-step halves of the packed [W'q | W'q Wo]
+      // matrix of the one-utterance step (load_weights: p_cqo).  The cross-attention kernel adds the halves and finishes
+      // q = rs (q_A + q_B - mu c) + b' with mu / rs merged from x1's partials: the LayerNorm-folded cross-Q projection as a launch of
+      // its own (6.4 us per layer at 8 utterances) is gone.
+      GemvP g3[3];
+      g3[0] = base(m->daoxf, w.p_out, nullptr, w.b_out, d, d, GV_RESID);
+      g3[0].y = m->dx; g3[0].ymb = MB; g3[0].stat_out = m->dstat;
+      g3[1] = base(m->dxf, w.p_cqo, nullptr, w.b_cqo, d, d, GV_OUT_F32);
+      g3[1].y = m->dq; g3[1].wks = 2 * d / 32; g3[1].wk0 = 0;
+      g3[2] = base(m->daoxf, w.p_cqo, nullptr, nullptr, d, d, GV_OUT_F32);
+      g3[2].y = m->dq2; g3[2].wks = 2 * d / 32; g3[2].wk0 = d / 32;
+      WIS_RET(launch_gemv_frag3(st, g3, 3));
+      WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, m->dstat, w.c_cq, w.b_cq,
+                                    m->ca_gran, m->ca_epoch, m->dq2, 1));
+    } else {
     g = base(m->daoxf, w.p_out, w.s_out, w.b_out, d, d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
     WIS_RET(launch_gemv_frag(st, g));
@@ -616,6 +640,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     WIS_RET(launch_gemv_frag(st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, nullptr, nullptr, nullptr,
                                   m->ca_gran, m->ca_epoch));
+    }
     g = base(m->daoxf, w.p_cout, w.s_cout, w.b_cout, d, d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
     WIS_RET(launch_gemv_frag(st, g));
