@@ -185,6 +185,12 @@ int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, in
 int wis_debug_search(wis_model_t* m, const float* logits, int n_steps, int B, const wis_gen_opts_t* opts,
                      int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* out_finish_step, int32_t* out_parent);
 
+/* the decoder cross-attention's granule hand-off (small grids; dec_kernels.hip SPIN): retries = calls on this handle that were run
+ * again in the ticket form because a combiner's bounded spin ran out (a request never fails for it; expected 0 - the granule form is
+ * only taken while B * heads * live handles on the GPU <= 192), spin_disabled = the handle has switched to the ticket form for good.
+ * raise_flag != 0 raises the give-up flag by hand, so that the NEXT compute call exercises the repeat path (tests). */
+int wis_debug_handoff(wis_model_t* m, int raise_flag, int* retries, int* spin_disabled);
+
 /* ---- timing taps: wall/device ms of the stages of the LAST wis_generate on this handle */
 typedef struct {
   float logmel_ms, encoder_ms, crosskv_ms, prefill_ms, decode_ms, total_ms;

@@ -1440,10 +1440,12 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   }
   if (SPIN) {
     const unsigned tag = ep_now + 1u;
-    gran_t* gbase = gran + ((size_t)(b * H + h) * C) * R * 66;
+    // slot of (utterance-head, chunk c, row r): fixed strides (6 chunks x 8 rows) - the same words for every R / C / batch size, so a tag
+    // in a slot was always written under THIS (utterance, head)'s epoch and can never alias another one's (advisor, round 3)
+    gran_t* gbase = gran + (size_t)(b * H + h) * 6 * 8 * 66;
     if (c != C - 1) {      // producer: one granule per value, no drain, no ticket
       if (l15 < R) {
-        gran_t* gp = gbase + ((size_t)c * R + l15) * 66;
+        gran_t* gp = gbase + ((size_t)c * 8 + l15) * 66;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) st_gran(gp + dh0 + r4, tag, oacc[r4]);
         if (wave == 0 && kq == 0) { st_gran(gp + 64, tag, smx[l15]); st_gran(gp + 65, tag, ssum[l15]); }
@@ -1469,7 +1471,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 #pragma unroll
         for (int cc = 0; cc < CM - 1; ++cc) {
           if (cc < C - 1) {
-            const gran_t* gp = gbase + ((size_t)cc * R + r) * 66;
+            const gran_t* gp = gbase + ((size_t)cc * 8 + r) * 66;
             const gran_t g0 = ld_gran(gp + 64), g1 = ld_gran(gp + 65), g2 = ld_gran(gp + 2 * dp), g3 = ld_gran(gp + 2 * dp + 1);
             ok = ok & ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag) & ((unsigned)(g2 >> 32) == tag) & ((unsigned)(g3 >> 32) == tag);
             ml[cc] = make_float2(__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1));

@@ -112,7 +112,7 @@ struct DecLayerW {
 };
 
 struct GraphKey {
-  int B, beam, P, max_new, fixed_new, suppress_blank, suppress_default, early_exit; float lp, patience;
+  int B, beam, P, max_new, fixed_new, suppress_blank, suppress_default, early_exit, spin; float lp, patience;
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -153,6 +153,9 @@ struct wis_model {
   float* dq2 = nullptr;         // batched fold: second half of the cross-attention q_raw (dec_forward_frag)
   float* gf_part = nullptr; unsigned* gf_cnt = nullptr; int gf_ksplit = 1;      // K split of the batched FFN2 skinny GEMM: slice sums, tickets (GemvP::ksplit)
   unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
+  bool spin_off = false;        // sticky: a combiner's bounded spin ran out once on this handle - it keeps to the ticket hand-off from then on
+  int handoff_retries = 0;      // calls repeated because a combiner's spin ran out (wis_debug_handoff: expected to stay 0)
+  bool spin_now = true;         // this call's decision (spin_allowed): dec_forward passes the granule buffers only when set
   f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
@@ -172,6 +175,7 @@ struct wis_model {
   bool prof_on; bool prof_all;
   size_t enc_part_cap = 0;      // (utterance, head, query tile) triples the split-key encoder attention buffers were sized for
   std::atomic_flag busy = ATOMIC_FLAG_INIT;   // one compute call at a time per handle (BusyGuard)
+  bool counted = false;         // this handle is in the per-device census (g_live_handles)
 };
 
 namespace {
@@ -590,6 +594,34 @@ static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
   return launch_gemv(st, g);
 }
 
+// ---- granule hand-off of the cross-attention: when it may be used -------------------------------
+// Its progress argument ("at most B*H <= CA_SPIN_MAX_BH combiners spin, fewer than the chip's CUs, so a producer always finds a slot") is
+// about ONE decode chain.  Several handles on a GPU (wis_model_clone replicas, other models) run their chains concurrently, so the
+// budget is divided by the number of live handles on the device: with the server's four replicas per GPU a batch of 8 utterances
+// (160 combiners) takes the ticket form, one utterance per replica (20 combiners each) keeps the granules.  Whatever happens, a
+// spin that runs out never fails a request: the flag is read at every host poll, the handle switches to the ticket form for good and
+// the call is run again (wis_generate / wis_detect_language / the logits taps).
+static std::atomic<int> g_live_handles[64];
+static bool spin_allowed(const wis_model* m, int B) {
+  static const bool env_share = getenv("WIS_CA_SPIN_SHARED") != nullptr;      // test switch: ignore the census (exercises the shared-GPU hazard on purpose)
+  if (m->spin_off) return false;
+  const int live = std::max(1, g_live_handles[m->device & 63].load(std::memory_order_relaxed));
+  return env_share || B * m->cfg.n_heads * live <= CA_SPIN_MAX_BH;
+}
+// reads and clears the give-up flag (word 0 of the epoch block); true = a combiner gave up: results of the pass are garbage
+static int spin_gave_up(wis_model* m, bool* gave_up) {
+  int* h = m->h_pin + 2;
+  WIS_HIP_CHECK(hipMemcpyAsync(h, m->ca_epoch, 4, hipMemcpyDeviceToHost, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  *gave_up = *h != 0;
+  if (*gave_up) {
+    WIS_HIP_CHECK(hipMemsetAsync(m->ca_epoch, 0, 4, m->st));
+    m->spin_off = true; ++m->handoff_retries;
+    fprintf(stderr, "[wis_hip] device %d: decoder cross-attention granule hand-off timed out; this handle uses the ticket hand-off from now on, the call is repeated\n", m->device);
+  }
+  return WIS_OK;
+}
+
 // ---- one decoder forward over the current row metadata ---------------------------------
 // sstride / rmul: logical-slot mapping of the rows (decode rows: beam, 1; prefill rows: beam, 0; single rows: 1, 0)
 // Batched rows (8 < M <= 48): every activation a projection reads lives in HBM as an MFMA fragment image, LayerNorm statistics
@@ -630,7 +662,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
       g3[2].y = m->dq2; g3[2].wks = 2 * d / 32; g3[2].wk0 = d / 32;
       WIS_RET(launch_gemv_frag3(st, g3, 3));
       WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, m->dstat, w.c_cq, w.b_cq,
-                                    m->ca_gran, m->ca_epoch, m->dq2, 1));
+                                    m->spin_now ? m->ca_gran : nullptr, m->ca_epoch, m->dq2, 1));
     } else {
     g = base(m->daoxf, w.p_out, w.s_out, w.b_out, d, d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
@@ -639,7 +671,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     g.csum = w.c_cq; g.stat_in = m->dstat; g.y = m->dq;
     WIS_RET(launch_gemv_frag(st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, nullptr, nullptr, nullptr,
-                                  m->ca_gran, m->ca_epoch));
+                                  m->spin_now ? m->ca_gran : nullptr, m->ca_epoch));
     }
     g = base(m->daoxf, w.p_cout, w.s_cout, w.b_cout, d, d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
@@ -692,7 +724,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
       gb.x = m->dxh; gb.x2 = m->dao; gb.xsplit = d; gb.Wp = w.p_cqo; gb.bias = w.b_cqo; gb.y = m->dq; gb.M = M; gb.N = d; gb.K = 2 * d; gb.flags = GV_OUT_F32;
       WIS_RET(launch_gemv_dual(st, ga, gb));
       WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
-                                    m->dx, w.c_cq, w.b_cq, m->ca_gran, m->ca_epoch));
+                                    m->dx, w.c_cq, w.b_cq, m->spin_now ? m->ca_gran : nullptr, m->ca_epoch));
     } else {
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_out; g.wscale = w.s_out; g.bias = w.b_out; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 32 : nullptr;
@@ -704,7 +736,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0, nullptr, nullptr, nullptr,
-                                  m->ca_gran, m->ca_epoch));
+                                  m->spin_now ? m->ca_gran : nullptr, m->ca_epoch));
     }
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
@@ -859,12 +891,14 @@ int wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_by
   } while (0);
   if (d_arena) hipFree(d_arena);
   if (rc) { wis_model_destroy(m); return rc; }
+  g_live_handles[device & 63].fetch_add(1, std::memory_order_relaxed); m->counted = true;
   *out = m;
   return WIS_OK;
 }
 
 void wis_model_destroy(wis_model_t* m) {
   if (!m) return;
+  if (m->counted) g_live_handles[m->device & 63].fetch_sub(1, std::memory_order_relaxed);
   hipSetDevice(m->device);
   if (m->st) hipStreamSynchronize(m->st);
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
@@ -899,15 +933,18 @@ int wis_model_clone(wis_model_t* parent, wis_model_t** out) {
     if (hipStreamSynchronize(m->st) != hipSuccess) { set_error("clone init failed"); rc = WIS_E_HIP; break; }
   } while (0);
   if (rc) { wis_model_destroy(m); return rc; }
+  g_live_handles[m->device & 63].fetch_add(1, std::memory_order_relaxed); m->counted = true;
   *out = m;
   return WIS_OK;
 }
 
-int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
-                 const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score) {
-  if (!m || !input || !prompt || !o || !out_ids || !out_len) { set_error("wis_generate: bad argument"); return WIS_E_ARG; }
-  WIS_ENTER(m, "wis_generate")
+}  // extern "C" (reopened below: the generate driver is a static helper)
+
+static int generate_impl(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
+                 const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score, bool* retry) {
+  *retry = false;
   WIS_HIP_CHECK(hipSetDevice(m->device));
+  m->spin_now = spin_allowed(m, B);
   const wis_config_t& c = m->cfg;
   const int beam = o->beam_size < 1 ? 1 : o->beam_size;
   WIS_RET(check_batch(m, B, beam));
@@ -960,7 +997,7 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   if (m->use_graph) {
     GraphKey key; memset(&key, 0, sizeof(key));
     key.B = B; key.beam = beam; key.P = P; key.max_new = max_new; key.fixed_new = sc.fixed_new; key.suppress_blank = sc.suppress_blank;
-    key.suppress_default = o->suppress_default; key.early_exit = sc.allow_early_exit; key.lp = sc.length_penalty; key.patience = patience;
+    key.suppress_default = o->suppress_default; key.early_exit = sc.allow_early_exit; key.lp = sc.length_penalty; key.patience = patience; key.spin = m->spin_now;
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) gexec = it->second;
     else {
@@ -994,11 +1031,18 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     WIS_HIP_CHECK(hipMemcpyAsync(h_done, m->bs.all_done, 4, hipMemcpyDeviceToHost, st));
     WIS_HIP_CHECK(hipMemcpyAsync(h_done + 1, m->ca_epoch, 4, hipMemcpyDeviceToHost, st));      // (word 0 of the epoch block: the hand-off's give-up flag)
     WIS_HIP_CHECK(hipStreamSynchronize(st));
-    if (*h_done >= B || steps >= limit) break;
+    if (*h_done >= B || steps >= limit || h_done[1]) break;      // (h_done[1]: a hand-off gave up - no point decoding on)
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
-  // the granule hand-off's give-up flag (a combiner's bounded spin ran out: never expected; results would be garbage)
-  if (h_done[1]) { hipMemsetAsync(m->ca_epoch, 0, 4, st); set_error("decoder cross-attention hand-off timed out (granule sweep exhausted)"); return WIS_E_HIP; }
+  // the granule hand-off's give-up flag (a combiner's bounded spin ran out: another handle's chain held the CUs its producers needed).
+  // Not an error for the caller: the handle keeps to the ticket hand-off from now on and the call is run again (wis_generate).
+  if (h_done[1]) {
+    WIS_HIP_CHECK(hipMemsetAsync(m->ca_epoch, 0, 4, st));
+    WIS_HIP_CHECK(hipStreamSynchronize(st));
+    m->spin_off = true; *retry = true; ++m->handoff_retries;
+    fprintf(stderr, "[wis_hip] device %d: decoder cross-attention granule hand-off timed out; this handle uses the ticket hand-off from now on, the call is repeated\n", m->device);
+    return WIS_OK;
+  }
   if (*h_done < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, *h_done, B); return WIS_E_STATE; }
   // results
   std::vector<int32_t> ids((size_t)B * 256);
@@ -1022,6 +1066,21 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
   hipEventElapsedTime(&ms, m->ev[4], m->ev[5]); m->timing.decode_ms = ms;
   m->timing.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   m->timing.decode_steps = steps;
+  return WIS_OK;
+}
+
+extern "C" {
+
+int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
+                 const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score) {
+  if (!m || !input || !prompt || !o || !out_ids || !out_len) { set_error("wis_generate: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_generate")
+  bool retry = false;
+  WIS_RET(generate_impl(m, input, B, prompt, P, o, out_ids, out_len, out_score, &retry));
+  if (retry) {      // once: the second run takes the ticket hand-off (spin_off is set), which cannot time out
+    WIS_RET(generate_impl(m, input, B, prompt, P, o, out_ids, out_len, out_score, &retry));
+    if (retry) { set_error("wis_generate: hand-off flag raised without the granule path"); return WIS_E_STATE; }
+  }
   return WIS_OK;
 }
 
@@ -1071,6 +1130,20 @@ int wis_debug_search(wis_model_t* m, const float* logits, int n_steps, int B, co
   return WIS_OK;
 }
 
+int wis_debug_handoff(wis_model_t* m, int raise_flag, int* retries, int* spin_disabled) {
+  if (!m) { set_error("wis_debug_handoff: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_debug_handoff")
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  if (raise_flag) {      // what a combiner does when its bounded spin runs out
+    const unsigned one = 1u;
+    WIS_HIP_CHECK(hipMemcpyAsync(m->ca_epoch, &one, 4, hipMemcpyHostToDevice, m->st));
+    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  }
+  if (retries) *retries = m->handoff_retries;
+  if (spin_disabled) *spin_disabled = m->spin_off ? 1 : 0;
+  return WIS_OK;
+}
+
 int wis_last_timing(const wis_model_t* m, wis_timing_t* t) {
   if (!m || !t) { set_error("wis_last_timing: bad argument"); return WIS_E_ARG; }
   *t = m->timing; return WIS_OK;
@@ -1094,11 +1167,16 @@ int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int 
   WIS_RET(run_encoder(m, B));
   WIS_RET(run_cross_kv(m, B));
   std::vector<int> tok(B, m->cfg.sot);
-  WIS_RET(single_row_setup(m, B, tok, 0));
-  WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
-  WIS_RET(launch_lang_probs(m->st, m->logits, m->n_vocab_pad, m->d_lang_ids, m->cfg.n_lang, m->d_probs, B));
-  WIS_HIP_CHECK(hipMemcpyAsync(lang_probs, m->d_probs, (size_t)B * m->cfg.n_lang * 4, hipMemcpyDeviceToHost, m->st));
-  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    m->spin_now = spin_allowed(m, B);
+    WIS_RET(single_row_setup(m, B, tok, 0));
+    WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
+    WIS_RET(launch_lang_probs(m->st, m->logits, m->n_vocab_pad, m->d_lang_ids, m->cfg.n_lang, m->d_probs, B));
+    WIS_HIP_CHECK(hipMemcpyAsync(lang_probs, m->d_probs, (size_t)B * m->cfg.n_lang * 4, hipMemcpyDeviceToHost, m->st));
+    bool gave_up = false;
+    WIS_RET(spin_gave_up(m, &gave_up));      // (synchronises the stream)
+    if (!gave_up) break;
+  }
   return WIS_OK;
 }
 
@@ -1128,11 +1206,16 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, 
   for (int t = 0; t < T; ++t) {
     std::vector<int> tok(B);
     for (int b = 0; b < B; ++b) tok[b] = dec_in[b * T + t];
-    WIS_RET(single_row_setup(m, B, tok, t));
-    WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
-    for (int b = 0; b < B; ++b)
-      WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t) * V, m->logits + (size_t)b * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
-    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+    for (int attempt = 0; attempt < 2; ++attempt) {      // (a pass whose granule hand-off gave up is repeated in the ticket form)
+      m->spin_now = spin_allowed(m, B);
+      WIS_RET(single_row_setup(m, B, tok, t));
+      WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
+      for (int b = 0; b < B; ++b)
+        WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t) * V, m->logits + (size_t)b * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
+      bool gave_up = false;
+      WIS_RET(spin_gave_up(m, &gave_up));
+      if (!gave_up) break;
+    }
   }
   return WIS_OK;
 }
@@ -1156,11 +1239,16 @@ int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, in
     std::vector<int> tok(M), pos(M), slot(M), ls(M);
     for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i) { const int r = b * rows + i; tok[r] = dec_in[b * T + t0 + i]; pos[r] = t0 + i; slot[r] = b; ls[r] = b; }
     for (int r = 0; r < M; ++r) if (tok[r] < 0 || tok[r] >= V) { set_error("wis_debug_logits_rows: token %d out of range", tok[r]); return WIS_E_ARG; }
-    WIS_RET(upload_rows(m, tok, pos, slot, ls));
-    WIS_RET(dec_forward(m, M, rows, B, true, 1, 0));
-    for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i)
-      WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t0 + i) * V, m->logits + (size_t)(b * rows + i) * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
-    WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+    for (int attempt = 0; attempt < 2; ++attempt) {      // (a pass whose granule hand-off gave up is repeated in the ticket form)
+      m->spin_now = spin_allowed(m, B);
+      WIS_RET(upload_rows(m, tok, pos, slot, ls));
+      WIS_RET(dec_forward(m, M, rows, B, true, 1, 0));
+      for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i)
+        WIS_HIP_CHECK(hipMemcpyAsync(logits + ((size_t)b * T + t0 + i) * V, m->logits + (size_t)(b * rows + i) * m->n_vocab_pad, (size_t)V * 4, hipMemcpyDeviceToHost, m->st));
+      bool gave_up = false;
+      WIS_RET(spin_gave_up(m, &gave_up));
+      if (!gave_up) break;
+    }
   }
   return WIS_OK;
 }

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("wis_debug_logits", _i, [_vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _fp]),
     ("wis_debug_logits_rows", _i, [_vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _fp]),
     ("wis_debug_search", _i, [_vp, _vp, _i, _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("wis_debug_handoff", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("wis_last_timing", _i, [_vp, C.POINTER(Timing)]),
     ("wis_debug_phase_cycles", _i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
     ("wis_debug_timeline", _i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_uint64), _i]),

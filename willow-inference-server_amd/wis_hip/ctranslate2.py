@@ -367,12 +367,16 @@ class Whisper:
         raise ValueError(f"no replica on device {device}")
 
     def generate_from_device(self, device, mel_device_ptr, prompt, *, beam_size=5, max_length=448, length_penalty=1, patience=1,
-                             suppress_blank=True, fixed_new_tokens=0):
+                             suppress_blank=True, fixed_new_tokens=0, replica=None):
         """One utterance whose log-mel features ALREADY live in HBM on `device` (f32 [80][3000] at `mel_device_ptr`, e.g. an
         audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Goes through the micro-batcher
         with that device's replica as its affinity: concurrent windows of several streaming sessions on the same GPU coalesce
         into one device batch like REST requests do."""
-        r = self.replica_on(device)
+        # `replica`: the replica the caller holds (a streaming session pins itself to the least-loaded one, acquire_replica - its windows
+        # run THERE, so the sessions of a GPU spread over its replicas and the load accounting is charged where the work is done)
+        r = replica if replica is not None else self.replica_on(device)
+        if r.device != device:
+            raise ValueError(f"replica lives on device {r.device}, the features on {device}")
         P = len(prompt)
         max_new = min(max_length // 2, max_length - P)
         if not 1 <= int(beam_size) <= self.max_beam:
@@ -404,6 +408,18 @@ class Whisper:
                         out.append([(f"<|{LANGUAGE_CODES[i]}|>", float(row[i])) for i in order])
         finally:
             self._release(r)
+        return out
+
+    def handoff_state(self, raise_flag_on=None):
+        """[(retries, spin_disabled)] per replica (wis_debug_handoff): calls that were repeated in the ticket form because the
+        cross-attention's granule hand-off timed out - a request never fails for it.  raise_flag_on = replica index: raise the
+        give-up flag there by hand (tests of the repeat path)."""
+        out = []
+        for i, r in enumerate(self._replicas):
+            n, off = C.c_int(0), C.c_int(0)
+            with r.lock:
+                _lib.check(_lib.load().wis_debug_handoff(r.handle, int(raise_flag_on == i), C.byref(n), C.byref(off)))
+            out.append((n.value, bool(off.value)))
         return out
 
     def last_timing(self, replica=0):

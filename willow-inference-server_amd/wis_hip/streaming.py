@@ -157,7 +157,7 @@ class StreamingSession:
             try:
                 stream.finish(to_host=False)
                 r = self._whisper.generate_from_device(stream.device, stream.device_ptr, self._prompt(language), beam_size=beam,
-                                                       fixed_new_tokens=self.fixed_new_tokens)
+                                                       fixed_new_tokens=self.fixed_new_tokens, replica=self._replica)
                 self.front_windows += 1
                 return r.sequences_ids[0]
             finally:
