@@ -38,8 +38,8 @@ def log(*a):
 
 def cpu_baseline(size, weights, pcm, beam, fixed_new, audio_ms):
     """PyTorch-fp32 oracle (kind "port": CTranslate2 4.1.0's int8 CPU path is not installable offline) timed on the host
-    cores on a bounded sample of the same workload: log-mel + encoder of the window + 2 of the S+1 beam-search steps,
-    the remaining steps extrapolated at the measured per-step cost."""
+    cores on the SAME workload, measured end to end (no extrapolation): log-mel + encoder of the window + the cross-K/V
+    projection, the prompt prefill and all S + 1 beam-search steps of the utterance (about 15 s of CPU work for large-v2)."""
     import torch
     from oracle import audio_ref
     from oracle.whisper_ref import WhisperRef
@@ -61,14 +61,25 @@ def cpu_baseline(size, weights, pcm, beam, fixed_new, audio_ms):
     torch.set_num_threads(enc_t)
     a = W.arch(size)
     ref = WhisperRef(weights, a["d_model"], a["n_layers"], a["n_heads"])
+    # log-mel: the reference's own wis/audio.py when its tree is present (the build container), else the oracle's numpy restatement
+    # of it (the GPU box has no /root/reference)
+    mel_fn, mel_src = (lambda x: audio_ref.log_mel_spectrogram(audio_ref.pad_or_trim(x))), "oracle/audio_ref.py (numpy restatement of wis/audio.py)"
+    if os.path.exists("/root/reference/wis/audio.py"):
+        try:
+            sys.path.insert(0, "/root/reference")
+            from wis.audio import log_mel_spectrogram as ref_mel, pad_or_trim as ref_pad
+            ref_mel(ref_pad(pcm))          # first call builds the window / filter tensors
+            mel_fn, mel_src = (lambda x: ref_mel(ref_pad(x)).numpy()), "the reference's wis/audio.py (torch CPU)"
+        except Exception as e:      # noqa: BLE001
+            log(f"reference wis/audio.py not usable ({e}); timing the oracle's log-mel")
     t0 = time.perf_counter()
-    mel = audio_ref.log_mel_spectrogram(audio_ref.pad_or_trim(pcm))
+    mel = np.asarray(mel_fn(pcm), np.float32)
     t1 = time.perf_counter()
     mem = ref.encode(mel[None])[0]
     t2e = time.perf_counter()
     kw = dict(beam_size=beam, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN, memory=mem)
     # the decode steps are hundreds of small matmuls: with every host thread on each of them torch spends its time in
-    # thread hand-offs, so the step is timed at the best of a few thread counts (the encoder keeps all `cores` threads)
+    # thread hand-offs, so the thread count is the best of a few on ONE step (the encoder keeps its own best count)
     best_t, best = cores, None
     for t in sorted({min(cores, 8), min(cores, 16), min(cores, 32), cores}):
         torch.set_num_threads(t)
@@ -79,18 +90,14 @@ def cpu_baseline(size, weights, pcm, beam, fixed_new, audio_ms):
             best, best_t = tb - ta, t
     torch.set_num_threads(best_t)
     t2 = time.perf_counter()
-    ref.generate(None, PROMPT, max_new_tokens=1, **kw)
+    ids, _ = ref.generate(None, PROMPT, fixed_new=fixed_new, **kw)          # cross-K/V + prefill + every one of the S + 1 steps
     t3 = time.perf_counter()
-    ref.generate(None, PROMPT, max_new_tokens=3, **kw)
-    t4 = time.perf_counter()
-    per_step = max(((t4 - t3) - (t3 - t2)) / 2.0, 1e-6)
-    fixed = max((t3 - t2) - per_step, 0.0)                 # cross-K/V projection + prompt prefill
-    enc_s = t2e - t0
-    est = enc_s + fixed + per_step * (fixed_new + 1)
-    return {"value": round(audio_ms / 1000.0 / est, 4), "unit": "x realtime", "cores": max(enc_t, best_t), "kind": "port",
-            "sample": (f"torch-fp32 oracle (KV-cached): log-mel {1e3 * (t1 - t0):.0f} ms + encoder {1e3 * (t2e - t1):.0f} ms on {enc_t} host threads (best of 16/32/64/{cores} on a probe GEMM) + "
-                       f"cross-KV/prefill {1e3 * fixed:.0f} ms measured; beam-{beam} decode step measured over 3 steps at {1e3 * per_step:.0f} ms/step on {best_t} threads (best of 8/16/32/{cores}) and "
-                       f"extrapolated to {fixed_new + 1} steps (est. {est:.2f} s per utterance). Stand-in for the CT2 int8 CPU path (not installable offline); "
+    enc_s, dec_s = t2e - t0, t3 - t2
+    total = enc_s + dec_s
+    return {"value": round(audio_ms / 1000.0 / total, 4), "unit": "x realtime", "cores": max(enc_t, best_t), "kind": "port",
+            "sample": (f"torch-fp32 oracle (KV-cached), the whole utterance measured: log-mel {1e3 * (t1 - t0):.0f} ms [{mel_src}] + encoder {1e3 * (t2e - t1):.0f} ms on {enc_t} host "
+                       f"threads (best of 16/32/64/{cores} on a probe GEMM) + cross-KV, prefill and all {fixed_new + 1} beam-{beam} steps {1e3 * dec_s:.0f} ms on {best_t} threads "
+                       f"(best of 8/16/32/{cores} on one step), {len(ids)} tokens = {total:.2f} s per utterance. Stand-in for the CT2 int8 CPU path (not installable offline); "
                        f"published CT2-int8 CPU figure: large beam1 3.84 s clip 3344 ms on Threadripper 5955WX (README.md:103)")}
 
 
@@ -444,7 +451,7 @@ def main():
         per_launch_us = 1e3 * ms.value / (passes * nl.value)
         achieved = nb.value / nl.value / (per_launch_us * 1e-6) / 1e9
         traffic = None
-        for name in ("r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
+        for name in ("r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -457,6 +464,9 @@ def main():
         step_ms = timing["decode_ms"] / steps_dec
         roofline = {"bound": "hbm", "kernel": "gemv_kernel (decoder skinny GEMM, weight streaming)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    # companion of `frac` (round-3 review item 8): the WHOLE decode step (weights + cross K/V + self KV over the measured step
+                    # time, attention / sampling / boundaries included) against the same peak - the dominant kernel's tap above flatters it
+                    "frac_decode_step": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "bytes_per_launch": round(nb.value / nl.value), "avg_launch_us": round(per_launch_us, 3),
                     "launches_per_decode_step": nl.value,
                     "how": "wis_bench_weight_stream: one launch of the skinny GEMM per decoder weight matrix (6 per layer + the vocabulary projection = one decode step's weight stream, 1.6 GB), "
@@ -507,7 +517,7 @@ def main():
                                           "frac_of_hbm_peak": round(sb / (tm["decode_ms"] / sd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                     if Bc == 8:
                         try:      # HBM traffic of the step's two byte-heavy kernels from the --pmc passes (profiles/r03_pmc_decode.json)
-                            b8 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_decode.json")))["batch_8"]
+                            b8 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_decode.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_decode.json")) else "r03_pmc_decode.json")))["batch_8"]
                             row["decode_step"]["traffic_over_algorithmic"] = {"skinny_gemm (gemv_frag_kernel)": b8["skinny_gemm_traffic_over_algorithmic"],
                                                                               "cross_attention": b8["per_kernel"]["dec_cross_attn_kernel 245760"]["traffic_over_algorithmic"]}
                         except Exception:
@@ -581,6 +591,11 @@ def main():
             "reference_published": "RTX 4090: 140 ms / 27x; H100: 294 ms / 12x (README.md:71,73; CT2 int8_float16, real weights, other hardware)",
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        # the span BASELINE.md section 3 defines for infer_ms (PCM in HOST memory -> ids on host) next to `value` (PCM resident in HBM, as the
+        # round contract fixes it): same call with WIS_IN_PCM_HOST, p50 of 20
+        bm = extra.get("boundary_ms_p50", {}).get("pcm_in_host_memory")
+        if bm:
+            out["value_pcm_in_host_memory"] = {"x_realtime": round(world * B * audio_ms / bm, 2), "p50_ms": bm}
         out.update(extra)
         print(json.dumps(out), flush=True)
     lib.wis_model_destroy(handle)

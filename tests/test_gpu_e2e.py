@@ -127,12 +127,12 @@ def _check_generate(model, ref, mel, beam, fixed_new, max_new=0):
 
 def test_generate_greedy_fixed(tiny, mels):
     model, ref, w, a = tiny
-    assert _check_generate(model, ref, mels, 1, 8) >= 1
+    assert _check_generate(model, ref, mels, 1, 8) == 2          # observed on MI355X: both identical (margins 0.14 / 0.19 force them)
 
 
 def test_generate_beam5_fixed(tiny, mels):
     model, ref, w, a = tiny
-    assert _check_generate(model, ref, mels, 5, 8) >= 1
+    assert _check_generate(model, ref, mels, 5, 8) >= 1          # observed on MI355X: 2 of 2; the oracle's decision margins here are 0.005 / 0.0009, so one may flip
 
 
 def _oracle_rescore(ref, memory, ids, fixed_new, suppress_blank=True):
@@ -361,8 +361,8 @@ def test_int8_float16_compute_type(mels, lib):
     _lib.check(lib.wis_debug_logits(_handle(f16_model), _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, B, dec_in.ctypes.data_as(C.POINTER(C.c_int32)), T,
                                     out16.ctypes.data_as(C.POINTER(C.c_float))))
     assert _relerr(out16, exp) > 3 * e
-    assert _check_generate(model, ref, mels, 1, 8) >= 1
-    assert _check_generate(model, ref, mels, 5, 8) >= 1
+    assert _check_generate(model, ref, mels, 1, 8) == 2          # observed on MI355X: both identical (margins 0.14 / 0.19 force them)
+    assert _check_generate(model, ref, mels, 5, 8) >= 1          # observed on MI355X: 2 of 2; the oracle's decision margins here are 0.005 / 0.0009, so one may flip
     with pytest.raises(ValueError):
         ct2.Whisper("unused", weights=w, arch=a, compute_type="bfloat16")
 

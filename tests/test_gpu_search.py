@@ -126,8 +126,8 @@ def test_hand_computed_case_on_the_engine(engine):
 def test_single_utterance_search_is_exact(engine, beam):
     rng = np.random.default_rng(100 + beam)
     stats = dict(checked=0, skipped=0, finish=[], lens=[], eot_hyps=0)
-    for case in range(6):
-        steps = int(rng.integers(10, 22))
+    for case in range(8 if beam == 1 else 4):
+        steps = int(rng.integers(10, 20))
         table = _random_table(rng, steps, 1, beam)
         for opts in (dict(), dict(length_penalty=0.0), dict(patience=2.0), dict(length_penalty=0.0, patience=2.0)):
             if beam == 1 and opts:
@@ -136,7 +136,7 @@ def test_single_utterance_search_is_exact(engine, beam):
     print(f"beam {beam}: {stats['checked']} searches identical to the oracle ({stats['skipped']} skipped as fp32 near-ties); finish steps "
           f"{sorted(set(stats['finish']))}; hypotheses that ended on EOT mid-search: {stats['eot_hyps']}; unequal-length sets: "
           f"{sum(1 for l in stats['lens'] if len(l) > 1)}")
-    assert stats["checked"] >= 5 and stats["skipped"] <= max(1, stats["checked"] // 5)
+    assert stats["checked"] >= 4 and stats["skipped"] <= max(1, stats["checked"] // 5)
     assert stats["eot_hyps"] >= 3 and len(set(stats["finish"])) >= 3
     if beam > 1:
         assert any(len(l) > 1 for l in stats["lens"])         # hypotheses of different lengths were ranked
