@@ -11,6 +11,9 @@
 #   prof<N>         rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
 #   frag2 [iters]   tools/bin/frag2_lab in its three flag variants (as the library / -fno-slp-vectorize / accumulators in AGPRs): the two-n-tile
 #                   skinny GEMM against the shipped kernel, bit for bit, with LDS dump + hardware ids of a failing workgroup -> frag2_*.txt
+#   engine          tools/bin/engine_lab: the persistent decode-layer skeleton against the graph-replayed launch chain (40 / 20 / 8 k-steps of
+#                   weights per CU and stage) -> engine_lab.txt
+#   dbgfrag2        tools/debug_frag2.py with WIS_FRAG_NB=2 (the round-3 reproducer of the two-tile kernel's wrong tiles) -> dbgfrag2.txt
 #   pmc <tag> "<COUNTER ...>" [batch]   one rocprofv3 --pmc pass of the eager bench (default 8 utterances) -> pmc_<tag>_b<batch>.txt (per kernel and grid: launches, mean per launch)
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${WIS_TAG:-r4}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
@@ -57,6 +60,12 @@ while [ $# -gt 0 ]; do
     frag2)
       IT=100; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then IT=$1; shift; fi
       for v in frag2_lab frag2_lab_noslp frag2_lab_agpr; do [ -x tools/bin/$v ] && { timeout 120 tools/bin/$v "$IT" > "$O/$v.txt" 2>&1; echo "== $v"; grep -c "differing words" "$O/$v.txt"; grep "^variant\|^shipped\|reference launch" "$O/$v.txt"; }; done ;;
+    engine)
+      : > "$O/engine_lab.txt"
+      for ks in 40 20 8; do timeout 90 tools/bin/engine_lab 56 $ks 20 >> "$O/engine_lab.txt" 2>&1; echo "rc=$?" >> "$O/engine_lab.txt"; done
+      cat "$O/engine_lab.txt" ;;
+    dbgfrag2)
+      WIS_FRAG_NB=2 timeout 300 python tools/debug_frag2.py > "$O/dbgfrag2.txt" 2>&1; echo "rc=$?" >> "$O/dbgfrag2.txt"; cat "$O/dbgfrag2.txt" | head -40 ;;
     pmc)      # pmc <tag> "<COUNTER ...>" [batch]: ONE rocprofv3 --pmc pass (counters only with --kernel-trace, as gpurun requires) of the eager bench
       PT=$1; CNT=$2; shift 2; PB=8; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then PB=$1; shift; fi
       ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc_$PT" -o p --output-format csv -- python "$R/bench.py" --steps 2 --warmup 1 --batch "$PB" --no-cpu-baseline --no-extras --no-roofline > "$O/pmc_$PT.log" 2>&1 )
