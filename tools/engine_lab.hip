@@ -19,6 +19,19 @@
 //   chain   : the same stage as a kernel of 256 workgroups (weights prefetched into registers, rows read from the previous kernel's
 //             output), S launches captured into a HIP graph - what the product's decode step is.
 // Both are checked against a plain reference of the chain.  Every spin is bounded (error flag, no hang).
+//
+// MEASURED on MI355X (round 4, gpurun_out/r4b, r4c; 56 stages = eight 7-stage layers, weights beyond the Infinity Cache):
+//     k-steps per CU and stage (MB per stage) | launch chain, us per stage | engine, us per stage | engine / chain
+//       40 (10.5 MB)                          |  5.16                      |  6.01                |  1.16
+//       20 ( 5.2 MB)                          |  4.28                      |  5.50                |  1.29
+//        8 ( 2.1 MB)                          |  3.79                      |  5.38                |  1.42
+//   The engine hides most of the weight stream (40 vs 8 k-steps: +0.6 us against the chain's +1.4 us) but its all-to-all edge - last
+//   publish -> write-through store visible -> one 30 KiB sweep per CU -> barrier - costs 5.4 us where the chain pays 3.8 us for a
+//   kernel boundary plus its first dependent loads.  A Whisper large-v2 decode stage streams 3.3-13.1 MB (0.5-2 us of HBM time): too
+//   little for the prefetch credit to buy back the edge.  A second form (rows double-buffered, no closing barrier, consumers start
+//   sweeping right after the reduction barrier) was SLOWER (7.8 / 7.2 / 7.1 us per stage): sweeps that start before the producers
+//   have published only add failed 30 KiB passes in front of the one that succeeds (the guide's polling-cost row).
+//   -> the product's decode step stays a graph-replayed launch chain.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/engine_lab tools/engine_lab.hip
 // run:   tools/bin/engine_lab [stages=56] [ksteps=40] [reps=20]
 #include <hip/hip_runtime.h>
