@@ -265,6 +265,53 @@ int main(int argc, char** argv) {
     }
     printf("variant f2dbg (3 workgroups/CU): %u of %d launches differ\n", bad_launches, iters);
   }
+  // ---- the two-tile kernel with FOUR launches in flight (tools/frag_stress.hip found: clean alone, wrong tiles as soon as launches overlap):
+  // the debug copy on four streams, each with its own output and LDS-dump buffers, against the idle-GPU reference
+  {
+    hipStream_t ss[4]; float* ys[4]; float* ds[4]; unsigned* hw[4];
+    for (int i = 0; i < 4; ++i) { CK(hipStreamCreate(&ss[i])); CK(hipMalloc(&ys[i], ny * 4)); CK(hipMalloc(&ds[i], ndump * 4)); CK(hipMalloc(&hw[i], (size_t)(N / 32) * 4 * 2 * 4)); }
+    std::vector<unsigned> hhw((size_t)(N / 32) * 8);
+    int shown = 0; unsigned bad = 0;
+    for (int it = 0; it < iters && shown < 6; ++it) {
+      for (int i = 0; i < 4; ++i) { GemvP gi = g; gi.y = ys[i]; hipLaunchKernelGGL((frag2_dbg<5, 4>), dim3(N / 32), dim3(256), 0, ss[i], gi, ds[i], hw[i]); }
+      for (int i = 0; i < 4; ++i) CK(hipStreamSynchronize(ss[i]));
+      for (int i = 0; i < 4 && shown < 6; ++i) {
+        const unsigned c = check("f2dbg x4 streams", ys[i], yref, ny, it, false);
+        if (!c) continue;
+        ++bad; ++shown;
+        const unsigned nshow = c < 4096 ? c : 4096;
+        CK(hipMemcpy(hrec.data(), recs, nshow * sizeof(Rec), hipMemcpyDeviceToHost));
+        std::vector<Rec> out_recs(hrec.begin(), hrec.begin() + nshow);
+        printf("  [x4] round %d stream %d: %u output words differ\n", it, i, c);
+        CK(hipMemcpy(hhw.data(), hw[i], hhw.size() * 4, hipMemcpyDeviceToHost));
+        unsigned last_wg = ~0u; int nwg = 0;
+        for (auto& r : out_recs) {
+          const unsigned row = r.idx / N, col = r.idx % N, wg = col / 32;
+          float gv, ev; memcpy(&gv, &r.got, 4); memcpy(&ev, &r.exp, 4);
+          if (wg != last_wg) {
+            if (++nwg > 6) break;
+            last_wg = wg;
+            printf("    workgroup %u:", wg);
+            for (int w = 0; w < 4; ++w) { const unsigned h = hhw[((size_t)wg * 4 + w) * 2]; printf(" [w%d slot %u simd %u cu %u sh %u se %u xcc %u]", w, h & 15, (h >> 4) & 3, (h >> 8) & 15, (h >> 12) & 1, (h >> 13) & 7, hhw[((size_t)wg * 4 + w) * 2 + 1] & 15); }
+            printf("\n");
+          }
+          printf("      row %u (block %u, row-in-block %u) col %u (tile %u of the workgroup, feature %u): got %.5f exp %.5f diff %.5f\n", row, row / 16, row % 16, col, (col / 16) & 1, col % 16, gv, ev, gv - ev);
+        }
+        const unsigned cl = check("LDS image", ds[i], dump_ref, ndump, it, false);
+        printf("    LDS exchange buffer of that launch: %u words differ from the reference image\n", cl);
+        if (cl) {
+          const unsigned ns2 = cl < 4096 ? cl : 4096;
+          CK(hipMemcpy(hrec.data(), recs, ns2 * sizeof(Rec), hipMemcpyDeviceToHost));
+          for (unsigned k = 0; k < ns2 && k < 40; ++k) {
+            const unsigned per = 4 * MB * 2 * 64 * 4, wg = hrec[k].idx / per, o = hrec[k].idx % per, slot = o / 256, ln = (o % 256) / 4, comp = o % 4;
+            float gv, ev; memcpy(&gv, &hrec[k].got, 4); memcpy(&ev, &hrec[k].exp, 4);
+            printf("      workgroup %u: writer wave %u row block %u tile %u lane %u comp %u: LDS %.6f reference %.6f\n", wg, slot / (MB * 2), (slot / 2) % MB, slot & 1, ln, comp, gv, ev);
+          }
+        }
+      }
+    }
+    printf("variant f2dbg, 4 streams in flight: %u differing launches shown\n", bad);
+  }
   // ---- the shipped kernel under load: four streams, every launch against the idle-GPU reference
   {
     hipStream_t ss[4]; float* ys[4];

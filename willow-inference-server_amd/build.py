@@ -28,6 +28,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
              "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
 C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
+# Per-source flags.  dec_kernels.hip is built WITHOUT SLP vectorisation: hipcc's SLP pass turns the skinny GEMMs' epilogue arithmetic
+# (adjacent scalar f32 adds / multiplies on float4 values) into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 /
+# v_pk_fma_f32), and the two-n-tile skinny GEMM's 3-waves-per-SIMD instantiation (168 VGPRs) returned WRONG low halves of those
+# packed results in lanes 48-63 on some MI355X chips of the pool (round 3's "features 12 and 14" corruption: 10 808 of 96 000
+# launches wrong on a failing chip with SLP, 0 of 240 000 without, same registers, same occupancy, same chip - tools/frag_stress.hip,
+# tools/frag2_lab.hip).  Scalar f32 code is also what the guide recommends beside MFMAs (packed f32 is "an
+# anti-lever" there); measured cost: none at 1 and 8 utterances (22.54 vs 22.55 ms and 36.50 vs 36.50 ms of decode).
+SOURCE_FLAGS = {"dec_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def _digest(paths):
@@ -35,7 +43,7 @@ def _digest(paths):
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(HIP_FLAGS + C_FLAGS).encode())
+    h.update(" ".join(HIP_FLAGS + C_FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(SOURCE_FLAGS.items())]).encode())
     return h.hexdigest()
 
 
@@ -69,7 +77,7 @@ def build(force=False, verbose=True, variant=None, extra_flags=()):
             if src.endswith(".c"):
                 _run(["gcc"] + C_FLAGS + ["-c", path, "-o", obj])
             else:
-                _run([HIPCC] + hip_flags + ["-c", path, "-o", obj])
+                _run([HIPCC] + hip_flags + SOURCE_FLAGS.get(src, []) + ["-c", path, "-o", obj])
             with open(stamp, "w") as f:
                 f.write(dig)
         objs.append(obj)
@@ -82,7 +90,7 @@ def build(force=False, verbose=True, variant=None, extra_flags=()):
 
 
 if __name__ == "__main__":
-    # python build.py [--force] [--variant NAME -DFLAG ...]
+    # python build.py [--force] [--variant NAME -DFLAG -fflag ...]
     argv = sys.argv[1:]
     var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
-    print(build(force="--force" in argv, variant=var, extra_flags=[a for a in argv if a.startswith("-D") or a.startswith("-m")]))
+    print(build(force="--force" in argv, variant=var, extra_flags=[a for a in argv if a.startswith("-") and a not in ("--force", "--variant")]))

@@ -970,15 +970,18 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   const int npad = cdiv(p.N, 16) * 16;
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   if (ks > 1 && (!p.kpart || !p.kcnt || (p.K / 32) % (4 * ks) || (p.flags & GV_LN))) { set_error("gemv_frag: K split %d unsupported (K=%d)", ks, p.K); return WIS_E_UNSUPPORTED; }
-  // two n-tiles per workgroup where there are more n-tiles than CUs (LayerNorm-folded projections: FFN1, vocabulary).  OFF by
-  // default (WIS_FRAG_NB=2 turns it on): measured -2.8 % / -3.5 % of the decode time at 8 / 16 utterances, but the five-row-block
-  // instantiation (168 VGPRs, 40 KiB of LDS: THREE workgroups per CU) fails sporadically at 80 rows x 51872 columns - one or two
-  // of a launch's 1621 workgroups come out with features 12 and 14 of their tiles off by one wave's partial sum in row blocks 2
-  // and 3.  Narrowed down on the hardware: clean with two workgroups per CU (LDS padded to 64 KiB, or amdgpu_waves_per_eu(1, 2),
-  // or a six-deep ring = more registers), unchanged by waits / nops around the LDS hand-off or behind the MFMA clusters; the
-  // other instantiations (24 / 32 / 48 KiB, three or two workgroups per CU) never failed.  Cause not understood, so the product
-  // keeps one n-tile per workgroup.
-  static const int env_nb = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 1;
+  // two n-tiles per workgroup where there are more n-tiles than CUs (LayerNorm-folded projections: FFN1, vocabulary): -1.7 ... -3.5 % of
+  // the decode time at 8 / 16 utterances.  ON since round 4 (WIS_FRAG_NB=1 keeps one tile per workgroup: A/B switch).  Round 3 kept it
+  // off for a sporadic corruption of its five-row-block instantiation (168 VGPRs: three waves per SIMD) - features 12 and 14 of a tile
+  // wrong for a whole row block.  Cause, narrowed down in round 4 (tools/frag2_lab.hip, tools/frag_stress.hip): hipcc's SLP pass had
+  // turned the epilogue's f32 arithmetic into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32); on SOME chips of the pool the
+  // LOW halves of those packed results (float4 components x and z = features 12 and 14 of the 4-feature group a lane owns) come
+  // out wrong in lanes 48-63 when three such waves share a SIMD - 14-22 of every 40 launches on a failing chip, 10 808 of 96 000
+  // with four launches in flight, none on other chips; the same source built with -fno-slp-vectorize (scalar v_add / v_fma: same 168
+  // registers, same occupancy) is clean on the failing chip (0 of 240 000 launches), as is any form with two waves per SIMD.  This
+  // file is therefore compiled without SLP vectorisation (build.py SOURCE_FLAGS), and tests/test_gpu_stress.py bit-compares 10^4
+  // launches of every shipped instantiation on four streams with the idle-GPU launch.
+  static const int env_nb = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 2;
   if (env_nb == 2 && (p.flags & GV_LN) && !(p.flags & GV_RESID) && ks == 1 && (npad / 16) % 2 == 0 && npad / 16 > 256) {
     dim3 g2(npad / 32), blk(256);
 #define WIS_GF2(MBv, PFv) do { if (p.wscale) hipLaunchKernelGGL((gemv_frag2_kernel<MBv, PFv, true>), g2, blk, 0, st, p); \
