@@ -3,11 +3,11 @@
 // K = 5120 / 2 x f16 and 8-bit weights - at Whisper large-v2's real shapes and epilogues
 //     QKV (3840 x 1280, LayerNorm-folded, q / K-cache / V-cache scatter), out-projection (1280 x 1280, residual rows + fragment image
 //     + LayerNorm partials), cross-Q (1280 x 1280, LayerNorm-folded, fp32), FFN1 (5120 x 1280, GELU, f16 fragment image), FFN2
-//     (1280 x 5120, residual, K split over four two-tile workgroups with the in-launch ticket merge), vocabulary (51872 x 1280),
+//     (1280 x 5120, residual, K split over two workgroups per n-tile with the in-launch ticket merge), vocabulary (51872 x 1280),
 //     and the three-problem launch of the folded cross-Q (out-projection + two halves of q_raw),
 // launched back to back on FOUR streams at once (what four replicas of a GPU do: workgroups of different launches share CUs), every
-// single launch compared WORD FOR WORD on the device with the result of the same launch done alone on the idle GPU.  The wide
-// projections take the two-n-tile kernels (the product default since round 4); WIS_FRAG_NB=1 stresses the one-tile forms instead.
+// single launch compared WORD FOR WORD on the device with the result of the same launch done alone on the idle GPU.  With
+// WIS_FRAG_NB=2 in the environment the two-n-tile kernel (off by default) is stressed the same way on its two shapes.
 // Prints one line per (row blocks, shape, weight type) and a final "TOTAL ... mismatching launches"; exit code 1 on any mismatch.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -I include -I willow-inference-server_amd/csrc \
 //        -o tools/bin/frag_stress tools/frag_stress.hip          run: tools/bin/frag_stress [launches per stream = 2500]
@@ -48,7 +48,7 @@ __global__ void compare_words(const unsigned* a, const unsigned* ref, size_t n, 
 struct Arena { char* base; size_t bytes; float* y; f16* yxf; float* stat; float* q; float* q2; f16* kc; f16* vc; float* kpart; unsigned* kcnt; };
 static Arena make_arena() {
   const size_t ny = (size_t)MAX_ROWS * 51872 * 4, nxf = (size_t)160 * 6 * 1024, nst = (size_t)MAX_ROWS * 80 * 8, nq = (size_t)MAX_ROWS * 1280 * 4, nkv = (size_t)MAX_ROWS * 4 * 1280 * 2,
-               nkp = (size_t)80 * 4 * 6 * 1024, nkc = 80 * 4;
+               nkp = (size_t)80 * 2 * 6 * 1024, nkc = 80 * 4;
   Arena a; a.bytes = ny + nxf + nst + 2 * nq + 2 * nkv + nkp + nkc;
   CK(hipMalloc(&a.base, a.bytes)); CK(hipMemset(a.base, 0, a.bytes));
   char* p = a.base;
@@ -59,7 +59,7 @@ static Arena make_arena() {
 
 int main(int argc, char** argv) {
   const int per_stream = argc > 1 ? atoi(argv[1]) : 2500;
-  const bool nb2 = false;      // (round-4 diagnosis runs restricted the shapes to the two-tile kernel's; kept for reference)
+  const bool nb2 = getenv("WIS_FRAG_NB") && atoi(getenv("WIS_FRAG_NB")) == 2;
   const int d = 1280, NS = 4;
   hipStream_t ss[NS]; for (int i = 0; i < NS; ++i) CK(hipStreamCreate(&ss[i]));
   // shared, read-only operands: random packed weights (any bytes are a valid fragment image), activation images, partials, vectors
@@ -79,8 +79,8 @@ int main(int argc, char** argv) {
   std::vector<unsigned> hslots(nslots);
 
   struct Shape { const char* name; int N, K, flags, ksplit, kind; };      // kind 0 = one problem, 1 = the three-problem fold launch
-  Shape shapes[] = {{"QKV 3840x1280 LN+scatter", 3 * d, d, GV_LN | GV_QKV, 1, 0}, {"out 1280x1280 resid", d, d, GV_RESID, 1, 0}, {"cross-Q 1280x1280 LN f32", d, d, GV_LN | GV_OUT_F32, 1, 0},
-                          {"FFN1 5120x1280 LN+GELU image", 4 * d, d, GV_LN | GV_GELU, 1, 0}, {"FFN2 1280x5120 resid K-split", d, 4 * d, GV_RESID, gemv_frag_nb() == 2 ? 4 : 2, 0},      // the product's rule (model.hip alloc_buffers): four slices on two-tile workgroups, else two
+  const Shape shapes[] = {{"QKV 3840x1280 LN+scatter", 3 * d, d, GV_LN | GV_QKV, 1, 0}, {"out 1280x1280 resid", d, d, GV_RESID, 1, 0}, {"cross-Q 1280x1280 LN f32", d, d, GV_LN | GV_OUT_F32, 1, 0},
+                          {"FFN1 5120x1280 LN+GELU image", 4 * d, d, GV_LN | GV_GELU, 1, 0}, {"FFN2 1280x5120 resid ksplit2", d, 4 * d, GV_RESID, 2, 0},
                           {"vocab 51872x1280 LN f32", 51872, d, GV_LN | GV_OUT_F32, 1, 0}, {"fold3 out+qA+qB 1280x1280", d, d, 0, 1, 1}};
   auto fill_g = [&](const Shape& s, const Arena& a, int M, bool w8, GemvP* g3) {
     const int MB = (M + 15) / 16;

@@ -935,159 +935,6 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(GemvP p) {
   }
 }
 
-// Two n-tiles per workgroup for the RESIDUAL projection with the deep K (FFN2: K = 4d, 80 n-tiles) and the K split over gridDim.y
-// workgroups per tile pair: 40 x 4 = 160 workgroups that each pull 80 KiB of weights + a quarter of the activation image (120 KiB at 40
-// rows) instead of 80 x 2 that pull 80 KiB + HALF the image (240 KiB) - a CU takes in ~55 GB/s, so the launch's time is its
-// per-workgroup ingest (round-3 review item 3: fewer pulls of the activation image).  Slice sums are published write-through and merged
-// by the last-arriving slice IN INDEX ORDER (gemv_frag_body's ticket hand-off: bit-reproducible whoever arrives last); the epilogue
-// is the residual one: fp32 rows in place, f16 fragment image, per-16-column (sum, M2) partials.
-template <int MB, int PF, bool W8>
-__global__ __launch_bounds__(256) void gemv_frag2r_kernel(GemvP p) {
-  typedef typename WFrag<W8>::T WT;
-  constexpr int EPN = (MB + 3) / 4;
-  __shared__ __attribute__((aligned(16))) float red[4 * MB * 2 * 64 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt0 = 2 * blockIdx.x;
-  const int KS = gridDim.y, ksi = blockIdx.y;
-  const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps / (4 * KS);
-  const WT* wq0 = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt0 * ksteps + (size_t)(ksi * 4 + wave) * S) * 64 + lane;
-  const WT* wq1 = wq0 + (size_t)ksteps * 64;
-  const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)(ksi * 4 + wave) * S * MB * 64 + lane;
-  WT a0[PF], a1[PF]; u32x4 b[PF][MB];
-#pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    if (u < S) {
-      a0[u] = __builtin_nontemporal_load(wq0 + (size_t)u * 64);
-      a1[u] = __builtin_nontemporal_load(wq1 + (size_t)u * 64);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(u * MB + mb) * 64];
-    }
-  }
-  f32x4 acc[MB][2];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) { acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int base = 0; base < S; base += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      if (base + u < S) {
-        const f16x8 av0 = WFrag<W8>::cvt(a0[u]), av1 = WFrag<W8>::cvt(a1[u]);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const f16x8 xb = *reinterpret_cast<const f16x8*>(&b[u][mb]);
-          acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, xb, acc[mb][0], 0, 0, 0);
-          acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, xb, acc[mb][1], 0, 0, 0);
-        }
-        const int nx = base + u + PF;
-        if (nx < S) {
-          a0[u] = __builtin_nontemporal_load(wq0 + (size_t)nx * 64);
-          a1[u] = __builtin_nontemporal_load(wq1 + (size_t)nx * 64);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(nx * MB + mb) * 64];
-        }
-      }
-    }
-  }
-  const int l15 = lane & 15, kq = lane >> 4;
-  float4 ep_bias[2], ep_sc[2]; int ep_n[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    ep_n[nb] = 16 * (nt0 + nb) + 4 * kq;
-    ep_bias[nb] = make_float4(0.f, 0.f, 0.f, 0.f); ep_sc[nb] = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (p.bias) ep_bias[nb] = *reinterpret_cast<const float4*>(p.bias + ep_n[nb]);
-    if (W8) ep_sc[nb] = *reinterpret_cast<const float4*>(p.wscale + ep_n[nb]);
-  }
-  bool ep_act[EPN], ep_ok[EPN]; int ep_m[EPN]; float4 ep_res[EPN][2];
-#pragma unroll
-  for (int e = 0; e < EPN; ++e) {
-    const int mb = wave + 4 * e;
-    ep_act[e] = mb < MB; ep_m[e] = mb * 16 + l15; ep_ok[e] = ep_act[e] && ep_m[e] < M;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      ep_res[e][nb] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ep_ok[e]) ep_res[e][nb] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m[e] * p.N + ep_n[nb]);
-    }
-  }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-      *reinterpret_cast<float4*>(red + ((size_t)((wave * MB + mb) * 2 + nb) * 64 + lane) * 4) = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
-  __syncthreads();
-  if (KS > 1) {
-#pragma unroll
-    for (int e = 0; e < EPN; ++e) {
-      if (!ep_act[e]) continue;
-      const int ep_mb = wave + 4 * e;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)((w * MB + ep_mb) * 2 + nb) * 64 + lane) * 4);
-          s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
-        }
-        float* dst = p.kpart + ((((size_t)(nt0 + nb) * KS + ksi) * MB + ep_mb) * 64 + lane) * 4;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(s) : "memory");
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ int s_last;
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned prev = __hip_atomic_fetch_add(p.kcnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = prev == (unsigned)(KS - 1);
-      if (last) {
-        __hip_atomic_store(p.kcnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-  }
-#pragma unroll
-  for (int e = 0; e < EPN; ++e) {
-    if (!ep_act[e]) continue;                                   // whole waves: a row block belongs to one wave
-    const int ep_mb = wave + 4 * e, m = ep_m[e];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KS > 1) {
-        for (int k = 0; k < KS; ++k) {
-          const float4 t = *reinterpret_cast<const float4*>(p.kpart + ((((size_t)(nt0 + nb) * KS + k) * MB + ep_mb) * 64 + lane) * 4);
-          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-      } else {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)((w * MB + ep_mb) * 2 + nb) * 64 + lane) * 4);
-          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-      }
-      if (W8) { s.x *= ep_sc[nb].x; s.y *= ep_sc[nb].y; s.z *= ep_sc[nb].z; s.w *= ep_sc[nb].w; }
-      s.x += ep_bias[nb].x; s.y += ep_bias[nb].y; s.z += ep_bias[nb].z; s.w += ep_bias[nb].w;
-      const int n = ep_n[nb];
-      const float4 r = make_float4(ep_res[e][nb].x + s.x, ep_res[e][nb].y + s.y, ep_res[e][nb].z + s.z, ep_res[e][nb].w + s.w);
-      float t1 = 0.f, t2 = 0.f;
-      if (ep_ok[e]) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n) = r;
-        if (p.y_xf) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y_xf + xf_index(m, n, p.ymb)) = h; }
-        t1 = (r.x + r.y) + (r.z + r.w);
-      }
-      if (p.stat_out) {      // (all four kq lanes take part in the shuffles)
-        t1 += __shfl_xor(t1, 16);
-        t1 += __shfl_xor(t1, 32);
-        if (ep_ok[e]) { const float ml = t1 * 0.0625f, a_ = r.x - ml, b_ = r.y - ml, c_ = r.z - ml, e_ = r.w - ml; t2 = (a_ * a_ + b_ * b_) + (c_ * c_ + e_ * e_); }
-        t2 += __shfl_xor(t2, 16);
-        t2 += __shfl_xor(t2, 32);
-        if (kq == 0 && m < M) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt0 + nb) * 2) = make_float2(t1, t2);
-      }
-    }
-  }
-}
-
-// 2 (default): two n-tiles per workgroup where that pays (FFN1, vocabulary, FFN2 with four K slices); WIS_FRAG_NB=1: one tile (A/B switch)
-int gemv_frag_nb() { static const int v = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 2; return v == 1 ? 1 : 2; }
-
 int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n) {
   if (n < 2 || n > 3) { set_error("gemv_frag3: %d problems", n); return WIS_E_ARG; }
   GemvP3 ps; memset(&ps, 0, sizeof(ps));
@@ -1134,24 +981,7 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   // registers, same occupancy) is clean on the failing chip (0 of 240 000 launches), as is any form with two waves per SIMD.  This
   // file is therefore compiled without SLP vectorisation (build.py SOURCE_FLAGS), and tests/test_gpu_stress.py bit-compares 10^4
   // launches of every shipped instantiation on four streams with the idle-GPU launch.
-  static const int env_nb = gemv_frag_nb();
-  // the residual projection with the deep K (FFN2) on two-tile workgroups with four K slices (gemv_frag2r_kernel)
-  if (env_nb == 2 && (p.flags & GV_RESID) && !(p.flags & GV_LN) && ks == 4 && (npad / 16) % 2 == 0 && p.N == npad && (p.K / 32) % 16 == 0) {
-    dim3 g2(npad / 32, ks), blk(256);
-#define WIS_GF2R(MBv, PFv) do { if (p.wscale) hipLaunchKernelGGL((gemv_frag2r_kernel<MBv, PFv, true>), g2, blk, 0, st, p); \
-                                else hipLaunchKernelGGL((gemv_frag2r_kernel<MBv, PFv, false>), g2, blk, 0, st, p); } while (0)
-    switch (p.xmb) {
-      case 1: WIS_GF2R(1, 6); break;
-      case 2: WIS_GF2R(2, 6); break;
-      case 3: WIS_GF2R(3, 6); break;
-      case 4: WIS_GF2R(4, 4); break;
-      case 5: WIS_GF2R(5, 4); break;
-      case 6: WIS_GF2R(6, 4); break;
-      default: set_error("gemv_frag: %d row blocks unsupported", p.xmb); return WIS_E_UNSUPPORTED;
-    }
-#undef WIS_GF2R
-    return WIS_OK;
-  }
+  static const int env_nb = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 2;
   if (env_nb == 2 && (p.flags & GV_LN) && !(p.flags & GV_RESID) && ks == 1 && (npad / 16) % 2 == 0 && npad / 16 > 256) {
     dim3 g2(npad / 32), blk(256);
 #define WIS_GF2(MBv, PFv) do { if (p.wscale) hipLaunchKernelGGL((gemv_frag2_kernel<MBv, PFv, true>), g2, blk, 0, st, p); \
@@ -1467,20 +1297,18 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   }
   const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
   u32x4 kf[TPW][2];
-  // (batched fold, FOLD == 2: the K and V fragments are requested BEHIND the query prologue.  A batch has hundreds of workgroups in
-  // flight per launch, so the kernel is throughput-bound: what counts is how many workgroups a CU holds, and the prologue's operands
-  // - second q half, column sums, biases, partials: 64 registers - would otherwise be live next to the 64 registers of K / V fragments)
-  if (FOLD != 2) {
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      int key = klo + 16 * (wave + 4 * i) + l15; if (key > T - 1) key = T - 1;      // clamped; masked below
+  for (int i = 0; i < TPW; ++i) {
+    int key = klo + 16 * (wave + 4 * i) + l15; if (key > T - 1) key = T - 1;      // clamped; masked below
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
-    }
+    for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
   }
   constexpr int NSTEP = 2 * TPW;                      // 32-key P.V steps per chunk; V^T is zero padded up to Tpad >= chunks * CL
   const f16* vb = vt + ((size_t)(b * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
   u32x4 vf[NSTEP];
+  // (batched fold: the V fragments are requested BEHIND the query prologue - its column sums, biases, second q half and partials
+  // are dead by then, so the kernel stays near the 88 registers of the plain form (five workgroups per CU: the 960 workgroups of an
+  // 8-utterance batch in one round) instead of 153 (three per CU); V is not needed before the softmax)
   if (FOLD != 2) {
 #pragma unroll
     for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
@@ -1536,21 +1364,14 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     qb0 = make_float4(rs * (qb0.x - mu * cs2.x) + bq2.x, rs * (qb0.y - mu * cs2.y) + bq2.y, rs * (qb0.z - mu * cs2.z) + bq2.z, rs * (qb0.w - mu * cs2.w) + bq2.w);
     qb1 = make_float4(rs * (qb1.x - mu * cs3.x) + bq3.x, rs * (qb1.y - mu * cs3.y) + bq3.y, rs * (qb1.z - mu * cs3.z) + bq3.z, rs * (qb1.w - mu * cs3.w) + bq3.w);
   }
-  f16x8 qf0, qf1;
-  qf0[0] = (f16)qa0.x; qf0[1] = (f16)qa0.y; qf0[2] = (f16)qa0.z; qf0[3] = (f16)qa0.w; qf0[4] = (f16)qa1.x; qf0[5] = (f16)qa1.y; qf0[6] = (f16)qa1.z; qf0[7] = (f16)qa1.w;
-  qf1[0] = (f16)qb0.x; qf1[1] = (f16)qb0.y; qf1[2] = (f16)qb0.z; qf1[3] = (f16)qb0.w; qf1[4] = (f16)qb1.x; qf1[5] = (f16)qb1.y; qf1[6] = (f16)qb1.z; qf1[7] = (f16)qb1.w;
-  if (FOLD == 2) {      // the query is finished (two f16 fragments): now the K and V fragments
-    asm volatile("" : "+v"(qf0), "+v"(qf1));
+  if (FOLD == 2) {
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      int key = klo + 16 * (wave + 4 * i) + l15; if (key > T - 1) key = T - 1;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
-    }
 #pragma unroll
     for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
   }
+  f16x8 qf0, qf1;
+  qf0[0] = (f16)qa0.x; qf0[1] = (f16)qa0.y; qf0[2] = (f16)qa0.z; qf0[3] = (f16)qa0.w; qf0[4] = (f16)qa1.x; qf0[5] = (f16)qa1.y; qf0[6] = (f16)qa1.z; qf0[7] = (f16)qa1.w;
+  qf1[0] = (f16)qb0.x; qf1[1] = (f16)qb0.y; qf1[2] = (f16)qb0.z; qf1[3] = (f16)qb0.w; qf1[4] = (f16)qb1.x; qf1[5] = (f16)qb1.y; qf1[6] = (f16)qb1.z; qf1[7] = (f16)qb1.w;
 
   // ---- scores: D[i = key][j = r]: lane holds r = l15, keys 16t + 4kq + reg
   float lmax = -INFINITY;

@@ -87,7 +87,6 @@ int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // t
 int launch_gemv_frag(hipStream_t st, const GemvP& p);
 // n (2 or 3) such GEMMs of one row count in one launch (f16 weights, no K split, same K / 128 for all): see gemv_frag3_kernel
 int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n);
-int gemv_frag_nb();      // n-tiles per workgroup of the wide batched projections (2, or 1 with WIS_FRAG_NB=1)
 // activation fragment image: element (row m, column k) of an [M][K] matrix, MB = ceil(M / 16) row blocks:
 //   [k / 32][m / 16][lane = (m % 16) + 16 * ((k / 8) % 4)][k % 8]      (one 1 KiB wave load per (k-step, row block))
 __host__ __device__ static inline size_t xf_index(int m, int k, int MB) {

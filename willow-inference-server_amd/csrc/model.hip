@@ -472,8 +472,7 @@ int alloc_buffers(wis_model* m) {
   {
     // measured (decode ms per utterance batch, 17 steps): 8 utterances 40.7 unsplit / 38.6 two slices / 38.9 four; 12: 46.7 two / 46.9 four;
     // 16: 60.9 unsplit / 58.7 two / 59.5 four
-    // (round 4: with two n-tiles per workgroup - gemv_frag2r_kernel - FOUR slices: 160 workgroups of 80 KiB weights + a quarter image)
-    static const int env_ks = getenv("WIS_FRAG_KSPLIT") ? atoi(getenv("WIS_FRAG_KSPLIT")) : (gemv_frag_nb() == 2 ? 4 : 2);      // 1: no split (A/B switch)
+    static const int env_ks = getenv("WIS_FRAG_KSPLIT") ? atoi(getenv("WIS_FRAG_KSPLIT")) : 2;      // 1: no split (A/B switch)
     m->gf_ksplit = env_ks >= 1 && env_ks <= 8 ? env_ks : 2;
     const size_t nt = (size_t)cdiv(d, 16);
     WIS_RET(dalloc(m, &m->gf_part, nt * m->gf_ksplit * (MAX_ROWS / 16) * 64 * 4));
