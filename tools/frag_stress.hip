@@ -6,8 +6,9 @@
 //     (1280 x 5120, residual, K split over two workgroups per n-tile with the in-launch ticket merge), vocabulary (51872 x 1280),
 //     and the three-problem launch of the folded cross-Q (out-projection + two halves of q_raw),
 // launched back to back on FOUR streams at once (what four replicas of a GPU do: workgroups of different launches share CUs), every
-// single launch compared WORD FOR WORD on the device with the result of the same launch done alone on the idle GPU.  With
-// WIS_FRAG_NB=2 in the environment the two-n-tile kernel (off by default) is stressed the same way on its two shapes.
+// single launch compared WORD FOR WORD on the device with the result of the same launch done alone on the idle GPU.  FFN1 and the
+// vocabulary take the two-n-tile kernel (the product default since round 4; WIS_FRAG_NB=1 stresses the one-tile form on them instead;
+// WIS_FRAG_NB=2 set explicitly restricts the run to those two shapes - the round-4 diagnosis runs).
 // Prints one line per (row blocks, shape, weight type) and a final "TOTAL ... mismatching launches"; exit code 1 on any mismatch.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -I include -I willow-inference-server_amd/csrc \
 //        -o tools/bin/frag_stress tools/frag_stress.hip          run: tools/bin/frag_stress [launches per stream = 2500]
