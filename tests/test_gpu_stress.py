@@ -24,3 +24,12 @@ def test_every_shipped_skinny_gemm_instantiation_is_bit_stable_under_four_stream
     total = [l for l in tail if l.startswith("TOTAL")]
     assert total and total[0].startswith("TOTAL: 0 mismatching launches of ")
     assert int(total[0].split(" of ")[1].split()[0]) >= 700000
+
+
+def test_encoder_and_generate_are_bit_repeatable_on_four_replicas():
+    """tools/enc_stress.py: four replicas of one large-v2 model encode / decode the same windows at once (1, 2 and 8 utterances per
+    device batch: every encoder kernel form); every encoder output and every generate result must equal the idle-GPU run bit for bit."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "enc_stress.py"), "3"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-600:])
+    assert r.returncode == 0 and "TOTAL differing: 0" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-400:])

@@ -1,4 +1,4 @@
-"""Assemble the committed round-3 artefacts under profiles/ from what tools/gpu_session.sh left under gpurun_out/<tag>/:
+"""Assemble the committed per-round artefacts (--round r04; default r03) under profiles/ from what tools/gpu_session.sh left under gpurun_out/<tag>/:
 
     python tools/make_profiles.py --stats r3A --pmc r3B --tcc r3s --lab r3c --lab-single r3b --bench r3A
 
@@ -15,6 +15,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
+RND = "r03"      # file prefix under profiles/ (--round)
 P = os.path.join(ROOT, "profiles")
 D = 1280
 ALG_B1 = {"gemv_kernel<1, 2, 0, 1, false> 20480": 8 * D * D, "gemv_kernel<1, 1, 10, 5, false> 81920": 8 * D * D, "gemv_kernel<1, 1, 10, 5, false> 61440": 6 * D * D,
@@ -22,7 +23,9 @@ ALG_B1 = {"gemv_kernel<1, 2, 0, 1, false> 20480": 8 * D * D, "gemv_kernel<1, 1, 
           "dec_cross_attn_kernel 30720": 2 * 2 * 1500 * D}
 ALG_B8 = {"gemv_frag_kernel<3, 8, false> 40960": 8 * D * D,      # FFN2: two K slices per n-tile (grid.y = 2)
           "gemv_frag_kernel<3, 10, false> 81920": 8 * D * D, "gemv_frag_kernel<3, 10, false> 61440": 6 * D * D,
-          "gemv_frag_kernel<3, 10, false> 20480": 2 * D * D, "gemv_frag_kernel<3, 10, false> 829952": 2 * 51872 * D, "dec_cross_attn_kernel 245760": 8 * 2 * 2 * 1500 * D}
+          "gemv_frag_kernel<3, 10, false> 20480": 2 * D * D, "gemv_frag_kernel<3, 10, false> 829952": 2 * 51872 * D, "dec_cross_attn_kernel 245760": 8 * 2 * 2 * 1500 * D,
+          # round 4: FFN1 and the vocabulary on two-tile workgroups (160 / 1621 workgroups), out-projection + the two halves of the folded cross-Q in one launch (240 workgroups)
+          "gemv_frag2_kernel<3, 6, false> 40960": 8 * D * D, "gemv_frag2_kernel<3, 6, false> 414976": 2 * 51872 * D, "gemv_frag3_kernel<3, 10> 61440": 6 * D * D}
 TEMPLATE_NOTE = ("Template arguments: `gemv_kernel<MB, MODE, SC, RM, W8>` (MODE 1 = LayerNorm-folded projection on raw fp32 rows, MODE 2 = f16 activations; SC = compile-time k-steps per wave, 0 = "
                  "generic ring: FFN2), `gemv_dual_kernel<SCA, SCB>` (out-projection + folded cross-Q in one launch), `gemv_frag_kernel<MB, PF, W8>` (batched rows on fragment images: MB 16-row blocks, "
                  "PF k-steps in flight), `dec_cross_attn_kernel<TPW, CM, FOLD, SPIN>` (SPIN = granule hand-off of the chunk partials), `gemm_8p_kernel<Epi, TR>` (8-phase 256 x 256 LDS-DMA GEMM, "
@@ -41,14 +44,14 @@ def kernel_stats(tag):
         st, gr = read(f"{G}/{tag}/kernel_stats_b{B}.txt"), read(f"{G}/{tag}/kernels_by_grid_b{B}.txt")
         if not st:
             continue
-        out = (f"# rocprofv3 --kernel-trace --stats, round 3, Whisper large-v2 beam 5, 3.84 s clip, {what}\n\n"
+        out = (f"# rocprofv3 --kernel-trace --stats, round {int(RND[1:])}, Whisper large-v2 beam 5, 3.84 s clip, {what}\n\n"
                f"Command (GPU box, `bash tools/gpu_session.sh prof{B}`): `WIS_NO_GRAPH=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --batch {B} --no-cpu-baseline --no-extras`\n"
                "(eager launches: rocprofv3 cannot follow a HIP-graph capture; 7 generate calls + the roofline tap's passes over the decoder weight stream + the one-time weight conversion kernels).\n"
                "Aggregated from the rocpd sqlite output (`kernels` view) by `tools/prof_summary.py`.  Durations of kernels in a dependent chain INCLUDE the boundary before them\n"
                "(start(k+1) = end(k) in the trace), so the column sums to the wall time of the chain.\n\n" + TEMPLATE_NOTE + "\n\n```\n" + st + "```\n")
         if gr:
             out += "\nPer kernel and grid size (threads):\n\n```\n" + gr + "```\n"
-        open(f"{P}/r03_kernel_stats_large_beam5_b{B}_eager.md", "w").write(out)
+        open(f"{P}/{RND}_kernel_stats_large_beam5_b{B}_eager.md", "w").write(out)
         print("wrote kernel stats b", B)
 
 
@@ -104,8 +107,8 @@ def pmc_decode(tag):
         res["algorithmic_bytes_per_launch"] = 8294294
         res["traffic_over_algorithmic"] = b1
         res["hbm_bytes_per_launch"] = round(b1 * 8294294)
-    json.dump(res, open(f"{P}/r03_pmc_decode.json", "w"), indent=1)
-    print("wrote r03_pmc_decode.json", b1, res.get("batch_8", {}).get("skinny_gemm_traffic_over_algorithmic"))
+    json.dump(res, open(f"{P}/{RND}_pmc_decode.json", "w"), indent=1)
+    print(f"wrote {RND}_pmc_decode.json", b1, res.get("batch_8", {}).get("skinny_gemm_traffic_over_algorithmic"))
 
 
 def pmc_encoder(tag, tcc_tag=None):
@@ -144,7 +147,7 @@ def pmc_encoder(tag, tcc_tag=None):
             if g("TCC_REQ_sum") <= 0:
                 continue
             lines.append(f"| `{short(name)}` ({grid}) | {cs['TCC_REQ_sum'][0]} | {g('TCC_REQ_sum'):.3g} | {g('TCC_HIT_sum'):.3g} | {g('TCC_MISS_sum'):.3g} | {g('TCC_MISS_sum') / g('TCC_REQ_sum'):.2f} | {g('TCC_EA0_RDREQ_sum'):.3g} |")
-    open(f"{P}/r03_pmc_encoder_sq.md", "w").write("\n".join(lines) + "\n")
+    open(f"{P}/{RND}_pmc_encoder_sq.md", "w").write("\n".join(lines) + "\n")
     print("wrote r03_pmc_encoder_sq.md")
 
 
@@ -162,7 +165,7 @@ def lab(tag_multi, tag_single):
             if fn.startswith("lab_M"):
                 txt = "".join(l for l in open(f"{d}/{fn}") if not l.startswith("  stamps") and "steady" not in l)
                 out += [f"## gpurun_out/{tag}/{fn} - {what}", "", "```", txt.rstrip(), "```", ""]
-    open(f"{P}/r03_gemm_lab.md", "w").write("\n".join(out) + "\n")
+    open(f"{P}/{RND}_gemm_lab.md", "w").write("\n".join(out) + "\n")
     print("wrote r03_gemm_lab.md")
 
 
@@ -170,14 +173,16 @@ def bench(tag):
     src = f"{G}/{tag}/bench_default.json"
     if os.path.exists(src):
         line = [l for l in open(src) if l.startswith("{")][-1]
-        json.dump(json.loads(line), open(f"{P}/r03_bench_large_beam5.json", "w"), indent=1)
+        json.dump(json.loads(line), open(f"{P}/{RND}_bench_large_beam5.json", "w"), indent=1)
         print("wrote r03_bench_large_beam5.json")
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--lab"); ap.add_argument("--lab-single"); ap.add_argument("--bench"); ap.add_argument("--tcc")
     a = ap.parse_args()
+    globals()["RND"] = a.round
     if a.stats: kernel_stats(a.stats)
     if a.pmc: pmc_decode(a.pmc); pmc_encoder(a.pmc, a.tcc)
     if a.lab or a.lab_single: lab(a.lab, a.lab_single)
