@@ -174,7 +174,7 @@ def bench(tag):
     if os.path.exists(src):
         line = [l for l in open(src) if l.startswith("{")][-1]
         json.dump(json.loads(line), open(f"{P}/{RND}_bench_large_beam5.json", "w"), indent=1)
-        print("wrote r03_bench_large_beam5.json")
+        print(f"wrote {RND}_bench_large_beam5.json")
 
 
 if __name__ == "__main__":
