@@ -106,6 +106,7 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
     enc = np.zeros((2, 1500, a["d_model"]), np.float32)
     _lib.check(lib.wis_debug_encode(h, _lib.ptr(mels), _lib.WIS_IN_MEL_HOST, 2, enc.ctypes.data_as(C.POINTER(C.c_float))))
     mem = ref.encode(mels)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 8)))          # the decoder passes below are skinny GEMVs: more threads only add hand-offs (bench.py: 16 beat 32 / 128)
     e = float(np.linalg.norm(enc.astype(np.float64) - mem.numpy()) / np.linalg.norm(mem.numpy().astype(np.float64)))
     print(f"{size}: encoder rel-L2 {e:.3e}, max abs {np.abs(enc - mem.numpy()).max():.3e}")
     assert e <= 2e-3
