@@ -206,12 +206,12 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
         ref_r.w = dict(ref.w)
         ref_r.w["decoder/position_encodings/encodings"] = torch.from_numpy(np.asarray(wr["decoder/position_encodings/encodings"], np.float32))
         memory = mem[0].numpy()
-        # (two prompts whose last token differs: the oracle ends them at steps 22 and 19 - the oracle costs ~1 s per beam-5 step at this
-        # size on the GPU box's host, so every prompt is decoded by it once and shared by the single call and the batch)
-        prompts2 = [[50258, 50259, 50359, 40763], [50258, 50280, 50359, 12603]]
+        # (four prompts whose last token differs: the oracle ends them at steps 22 / 19 / 21 / 20; every prompt is decoded by the oracle once
+        # and shared by the single call and the batch)
+        prompts2 = [[50258, 50259, 50359, 40763], [50258, 50280, 50359, 12603], [50258, 50287, 50359, 9886], [50258, 50266, 50359, 5196]]
         feats1 = ct2.StorageView.from_array(np.ascontiguousarray(mels[:1]))
         r1 = model_r.generate(feats1, [prompts2[0]], beam_size=5)[0]
-        order8 = [0, 1, 0, 1, 1, 0, 0, 1]
+        order8 = [0, 1, 2, 3, 1, 0, 3, 2]
         batch = ct2.StorageView.from_array(np.ascontiguousarray(np.repeat(mels[:1], 8, axis=0)))
         r8 = model_r.generate(batch, [prompts2[i] for i in order8], beam_size=5)
         from wis_hip import weights as W2
@@ -232,10 +232,10 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
                 assert got == ids
             exact += got == ids
         finish = {pi: want[pi][3]["finish_step"] for pi in want}
-        print(f"large, natural EOT: {exact} of 9 identical to the oracle; finish steps of the two prompts {finish}; engine ran {model_r.last_timing()['decode_steps']} steps")
-        assert len(set(finish.values())) == 2 and max(finish.values()) < 60 and exact >= 7
+        print(f"large, natural EOT: {exact} of 9 identical to the oracle; finish steps of the four prompts {finish}; engine ran {model_r.last_timing()['decode_steps']} steps")
+        assert len(set(finish.values())) >= 3 and max(finish.values()) < 60 and exact >= 7          # utterances of ONE device batch end at >= 3 different steps
         assert any(len({len(h[1]) for h in want[pi][3]["hyps"]}) > 1 for pi in want)          # hypotheses of unequal length were ranked
-        assert r8[0].sequences_ids == r8[2].sequences_ids and r8[1].sequences_ids == r8[3].sequences_ids       # same prompt, same answer, whatever the slot
+        assert r8[0].sequences_ids == r8[5].sequences_ids and r8[1].sequences_ids == r8[4].sequences_ids       # same prompt, same answer, whatever the slot
         model_r.close()
     if size == "medium":
         # ---- int8_float16 (reference GPU default, main.py:242) at this size: the oracle on the de-quantised decoder weights, both
