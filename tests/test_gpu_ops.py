@@ -140,6 +140,11 @@ def test_enc_attention(lib, B, T, H):
     k = (rng.standard_normal((B, T, H, 64))).astype(np.float16)
     v = (rng.standard_normal((B, T, H, 64))).astype(np.float16)
     q[0, 3, 0] *= 6.0     # a spiky query row exercises the online-softmax rescale
+    # keys planted late in the sequence that beat everything before them by > 15 in the log2 domain for a few queries: the lazy
+    # softmax reference (enc_attn_lazy_kernel) has to be raised in the MIDDLE of the key loop, in either half of a split pair
+    for t_key, t_q in ((T * 2 // 5, 5), (T * 4 // 5, 40), (T - 1, 7)):
+        if T > 128 and t_q < T:
+            k[0, t_key, 0] = (q[0, t_q, 0].astype(np.float32) / np.linalg.norm(q[0, t_q, 0].astype(np.float32)) * 9.0).astype(np.float16)
     qk = np.concatenate([q.reshape(B, T, d), k.reshape(B, T, d)], axis=2).reshape(B * T, 2 * d)
     # V^T image as the encoder's QKV epilogue writes it: keys in groups of 16 with bits 2 and 3 of the index swapped
     tt = np.arange(T); tp = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)

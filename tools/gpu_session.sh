@@ -8,7 +8,7 @@
 #   bench<N> [ENV=VAL ...]   bench.py at N utterances per device batch (no extras, no CPU baseline); extra words are
 #                   environment assignments for that run and become part of the output name
 #   benchfull       the default bench.py line (what the driver runs)
-#   prof<N>         rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
+#   prof<N> [ENV=VAL ...]   rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
 #   frag2 [iters]   tools/bin/frag2_lab in its three flag variants (as the library / -fno-slp-vectorize / accumulators in AGPRs): the two-n-tile
 #                   skinny GEMM against the shipped kernel, bit for bit, with LDS dump + hardware ids of a failing workgroup -> frag2_*.txt
 #   engine          tools/bin/engine_lab: the persistent decode-layer skeleton against the graph-replayed launch chain (40 / 20 / 8 k-steps of
@@ -49,14 +49,14 @@ while [ $# -gt 0 ]; do
       run_bench "$B" "${envs[@]}" ;;
     benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; tail -c 600 "$O/bench_default.json" ;;
     prof[0-9]*)
-      B=${step#prof}
+      B=${step#prof}; while [ $# -gt 0 ] && [[ $1 == *=* ]]; do export "$1"; B="$B"; PSUF="${PSUF}_${1//[^A-Za-z0-9=]/}"; shift; done
       ( cd /tmp && export TMPDIR=/tmp && WIS_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof_b$B" -o "b$B" -- python "$R/bench.py" --steps 5 --warmup 2 --batch "$B" --no-cpu-baseline --no-extras > "$O/bench_eager_b$B.log" 2>&1 )
       DB=$(find "$O/prof_b$B" -name "*.db" | head -1)
-      python tools/prof_summary.py "$DB" 45 > "$O/kernel_stats_b$B.txt" 2>&1
-      python tools/prof_summary.py "$DB" 45 --by-grid > "$O/kernels_by_grid_b$B.txt" 2>&1
+      python tools/prof_summary.py "$DB" 45 > "$O/kernel_stats_b$B$PSUF.txt" 2>&1
+      python tools/prof_summary.py "$DB" 45 --by-grid > "$O/kernels_by_grid_b$B$PSUF.txt" 2>&1
       [ "$B" = 1 ] && python tools/spread.py "$DB" 32 > "$O/spread_b1.txt" 2>&1
       find "$O/prof_b$B" -name "*.db" -delete
-      head -30 "$O/kernel_stats_b$B.txt" ;;
+      head -30 "$O/kernel_stats_b$B$PSUF.txt"; PSUF="" ;;
     frag2)
       IT=100; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then IT=$1; shift; fi
       for v in frag2_lab frag2_lab_noslp frag2_lab_agpr; do [ -x tools/bin/$v ] && { timeout 120 tools/bin/$v "$IT" > "$O/$v.txt" 2>&1; echo "== $v"; grep -c "differing words" "$O/$v.txt"; grep "^variant\|^shipped\|reference launch" "$O/$v.txt"; }; done ;;

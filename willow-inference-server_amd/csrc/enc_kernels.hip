@@ -1467,6 +1467,245 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same attention with a LAZY softmax reference (r4).  The loop above is bound by the vector ALU: per 64-key tile and wave 16
+// MFMAs (512 cycles of matrix pipe) against ~1050 cycles of VALU issue - 32 v_exp_f32 (quarter rate: 512), 32 fma, 32 adds, 16
+// v_max3, 16 conversions, and in most tiles the accumulator rescale (with 24 key tiles some one of a wave's 32 queries sees a new
+// maximum in three tiles out of four).  None of that but the exponentials and the conversions is needed per tile:
+//  * the scores leave the MFMA already relative to a per-query REFERENCE m_ref: the first Q.K^T MFMA of a tile takes C = -m_ref
+//    (a 16-register splat kept across tiles) instead of 0, and Q arrives pre-multiplied by log2(e) / sqrt(64) (folded into the
+//    query projection at load time), so p = v_exp_f32(accumulator) with no fma in front of it;
+//  * the reference need not be the running maximum: any value within 2^15 below it gives the same quotient O / l in floating
+//    point (P is rounded to f16 RELATIVE to its own magnitude, l and O are fp32), so it is raised only when a tile's weights
+//    would leave the f16 range - which the tile's own row sum shows (sum < 2^15 => every p < 2^15): no maxima in the common path;
+//  * the row sum is taken from the f16 pairs the P.V MFMA consumes, two keys per v_dot2c_f32_f16 (16 instructions, and l is the
+//    sum of exactly the weights that multiply V).
+// Common path per tile: 32 v_exp + 16 v_cvt_pk + 16 v_dot2c + one compare ~ 650 cycles.  A tile whose sum reaches 2^15 (or the
+// first tile of a workgroup, where nothing is known) takes the slow path: scores recomputed, true maximum, reference raised,
+// accumulators rescaled - the textbook step, once or twice per workgroup instead of every tile.
+// a * b that hipcc's SLP pass cannot pair with its neighbour into v_pk_mul_f32 / v_pk_add_f32 (the packed-f32
+// hazard at three waves per SIMD): the product passes through an EMPTY asm, so the vectoriser's seed (a vector build, a store)
+// never reaches the arithmetic.  No instruction lives inside the asm - hipcc still sees, schedules and hazard-checks the v_mul itself
+// (a v_mul written IN asm consumed a v_exp result one instruction too early: the transcendental-use hazard is the compiler's to pad).
+__device__ __forceinline__ float mul_scalar(float a, float b) { float t = a * b; asm("" : "+v"(t)); return t; }
+__device__ __forceinline__ float add_scalar(float a, float b) { float t = a + b; asm("" : "+v"(t)); return t; }
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void enc_attn_lazy_kernel(const f16* __restrict__ qk, const f16* __restrict__ vt,
+                                                            f16* __restrict__ out, int T, int Tpad, int H, int d, float* part, unsigned* counters) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) f16 sK[2][AKT * ASTR];
+  __shared__ __attribute__((aligned(16))) f16 sV[2][64 * ASTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qt = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, half = SPLIT ? (int)blockIdx.x & 1 : 0;
+  const int q_row = qt * 128 + wave * 32 + l31;
+  const int q_c = q_row < T ? q_row : T - 1;
+  const int ld = 2 * d;
+
+  f16x8 qf[4];
+  {
+    const f16* qp = qk + (size_t)(b * T + q_c) * ld + h * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const f16x8*>(qp + kk * 16 + hi * 8);
+  }
+  const f16* kbase = qk + (size_t)b * T * ld + d + h * 64;
+  const f16* vbase = vt + (size_t)(b * H + h) * 64 * Tpad;
+  const int lrow0 = tid >> 3, lrow1 = (tid + 256) >> 3, lch = (tid & 7) * 8;
+  const f16* vp0 = vbase + (size_t)lrow0 * Tpad + lch;
+  const f16* vp1 = vbase + (size_t)lrow1 * Tpad + lch;
+  const int so0 = lrow0 * ASTR + lch, so1 = lrow1 * ASTR + lch;
+  // K / V tile on its way to LDS (loads and their hand-placed wait: see enc_attn_kernel).  Measured and not kept for the split-key
+  // form: a second register set with tile kt+2 requested at the top of tile kt and a counted vmcnt(4) in front of the LDS stores
+  // (correct, 202 VGPRs, 28.47 us per layer at one utterance against 28.46: the tile time there is not the load latency either).
+  u32x4 ra[4];
+#define WIS_GLOAD(kt, R)                                                                   \
+  {                                                                                        \
+    int key0 = (kt) * AKT + lrow0; if (key0 > T - 1) key0 = T - 1;                          \
+    int key1 = (kt) * AKT + lrow1; if (key1 > T - 1) key1 = T - 1;                          \
+    const f16* a0_ = kbase + (size_t)key0 * ld + lch; const f16* a1_ = kbase + (size_t)key1 * ld + lch;   \
+    const f16* a2_ = vp0 + (kt) * AKT; const f16* a3_ = vp1 + (kt) * AKT;                   \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"  \
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"      \
+                 : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
+  }
+#define WIS_SSTORE(buf, R, WAIT)                                                           \
+  asm volatile(WAIT : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) :: "memory");         \
+  *reinterpret_cast<u32x4*>(&sK[buf][so0]) = R[0];                                         \
+  *reinterpret_cast<u32x4*>(&sK[buf][so1]) = R[1];                                         \
+  *reinterpret_cast<u32x4*>(&sV[buf][so0]) = R[2];                                         \
+  *reinterpret_cast<u32x4*>(&sV[buf][so1]) = R[3];
+  // S^T[key][q] - m_ref[q] = K . Q^T + C  (A = K rows, B = Q rows, C = the reference splat); keys >= T (last tile only) -> -inf
+#define WIS_SCORES()                                                                       \
+  _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(&sK[cur][(t2 * 32 + l31) * ASTR + kk * 16 + hi * 8]); \
+      st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? negm : st[t2], 0, 0, 0); \
+    }                                                                                      \
+  }                                                                                        \
+  if (kt == nt_all - 1) {                                                                  \
+    const int key_base = kt * AKT + 4 * hi;                                                \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                       \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+        const int key = key_base + t2 * 32 + (r & 3) + 8 * (r >> 2);                       \
+        if (key >= T) st[t2][r] = -INFINITY;                                               \
+      }                                                                                    \
+  }
+  // weights, their f16 pairs in P.V operand order (k-step s of 16 keys <-> S-tile s>>1, regs 8(s&1)..+7; slot j of half `hi` is
+  // key 16s + 8(j>>2) + 4hi + (j&3): V^T is stored in exactly that order) and the row sum of the ROUNDED weights
+#define WIS_WEIGHTS()                                                                      \
+  rs = 0.f;                                                                                \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                            \
+    _Pragma("unroll") for (int j = 0; j < 8; j += 2) {                                     \
+      const f16x2 pr = {(f16)__builtin_amdgcn_exp2f(st[s >> 1][8 * (s & 1) + j]), (f16)__builtin_amdgcn_exp2f(st[s >> 1][8 * (s & 1) + j + 1])}; \
+      pf[s][j] = pr[0]; pf[s][j + 1] = pr[1];                                              \
+      rs = __builtin_amdgcn_fdot2(pr, f16x2{(f16)1.f, (f16)1.f}, rs, false);               \
+    }
+
+  f32x16 o[2], negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  float m_run = 0.f, l_run = 0.f;      // m_run: the reference (log2 domain), NOT necessarily the running maximum
+
+  const int nt_all = cdiv(T, AKT), nt_half = (nt_all + 1) >> 1;
+  const int t_beg = SPLIT ? half * nt_half : 0;
+  const int ntiles = SPLIT ? (t_beg + nt_half < nt_all ? t_beg + nt_half : nt_all) : nt_all;
+  constexpr float BIG = 32768.f;
+  // one key tile out of LDS buffer CUR: scores, weights, (rarely) the reference step, P.V.  (A macro, not a lambda: with the body behind a
+  // lambda hipcc allocated 182 VGPRs for the unsplit instantiation - 168 with spills when held to three waves per SIMD - against 158 inline.)
+  // In the reference step: on the first tile the reference becomes the tile's maximum whatever its sign (tile t_beg always holds a
+  // key < T, so mx is finite; l and O are zero there, alpha = 0 keeps them so); both key halves of a query share one reference.
+#define WIS_TILE(KT, CUR, FIRST)                                                           \
+  {                                                                                        \
+    const int kt = (KT), cur = (CUR); const bool first = (FIRST);                          \
+    f32x16 st[2];                                                                          \
+    f16x8 pf[4];                                                                           \
+    float rs;                                                                              \
+    bool slow = first;                                                                     \
+    WIS_SCORES()                                                                           \
+    if (!first) {                                                                          \
+      WIS_WEIGHTS()                                                                        \
+      slow = __any(!(rs < BIG));                                                           \
+      if (slow) { WIS_SCORES() }                                                           \
+    }                                                                                      \
+    if (slow) {                                                                            \
+      float mx = st[0][0];                                                                 \
+_Pragma("unroll")                                                                          \
+      for (int t2 = 0; t2 < 2; ++t2)                                                       \
+_Pragma("unroll")                                                                          \
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);                            \
+      mx = fmaxf(mx, __shfl_xor(mx, 32));                                                  \
+      const float delta = first ? mx : fmaxf(mx, 0.f);                                     \
+      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);                    \
+      m_run += delta;                                                                      \
+      l_run *= alpha;                                                                      \
+_Pragma("unroll")                                                                          \
+      for (int r = 0; r < 16; ++r) { o[0][r] = mul_scalar(o[0][r], alpha); o[1][r] = mul_scalar(o[1][r], alpha); negm[r] = -m_run; }\
+_Pragma("unroll")                                                                          \
+      for (int t2 = 0; t2 < 2; ++t2)                                                       \
+_Pragma("unroll")                                                                          \
+        for (int r = 0; r < 16; ++r) st[t2][r] -= delta;                                   \
+      WIS_WEIGHTS()                                                                        \
+    }                                                                                      \
+    l_run += rs;                                                                           \
+_Pragma("unroll")                                                                          \
+    for (int dt = 0; dt < 2; ++dt)                                                         \
+_Pragma("unroll")                                                                          \
+      for (int s = 0; s < 4; ++s) {                                                        \
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(&sV[cur][(dt * 32 + l31) * ASTR + 16 * s + 8 * hi]);\
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[dt], 0, 0, 0);         \
+      }                                                                                    \
+  }
+  WIS_GLOAD(t_beg, ra) WIS_SSTORE(0, ra, "s_waitcnt vmcnt(0)")
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the Q fragments are complete, and hipcc's waitcnt pass knows it (see enc_attn_kernel)
+  __syncthreads();
+  for (int kb = t_beg; kb < ntiles; ++kb) {      // (the tile macro declares kt / cur itself)
+    const int cur0 = (kb - t_beg) & 1;
+    if (kb + 1 < ntiles) WIS_GLOAD(kb + 1, ra)
+    WIS_TILE(kb, cur0, kb == t_beg)
+    if (kb + 1 < ntiles) { WIS_SSTORE(cur0 ^ 1, ra, "s_waitcnt vmcnt(0)") }
+    __syncthreads();
+  }
+#undef WIS_GLOAD
+#undef WIS_SSTORE
+#undef WIS_SCORES
+#undef WIS_WEIGHTS
+#undef WIS_TILE
+  if (SPLIT) {
+    // (hand-off as in enc_attn_kernel; the merge formula holds for references as it does for maxima)
+    __shared__ int s_last;
+    const int nqt = (int)gridDim.x >> 1;
+    const size_t pair = (size_t)(b * H + h) * nqt + qt;
+    float* mine = part + (pair * 2 + half) * ENC_PART_FLOATS + tid;
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine), __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 256), __float_as_uint(l_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(mine + (2 + a * 16 + r) * 256), __float_as_uint(o[a][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(counters + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == 1u;
+      if (last) {
+        __hip_atomic_store(counters + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* other = part + (pair * 2 + (half ^ 1)) * ENC_PART_FLOATS + tid;
+    const float m1 = other[0], l1 = other[256];
+    float o1[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o1[a][r] = other[(2 + a * 16 + r) * 256];
+    const float mm = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[a][r] = add_scalar(mul_scalar(o[a][r], a0), mul_scalar(o1[a][r], a1));      // the sum of two products: symmetric in the two states
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_row < T) {
+    f16* op = out + (size_t)(b * T + q_row) * d + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dh = dt * 32 + 8 * r4 + 4 * hi;
+        f32x4 v = {mul_scalar(o[dt][4 * r4], inv), mul_scalar(o[dt][4 * r4 + 1], inv), mul_scalar(o[dt][4 * r4 + 2], inv), mul_scalar(o[dt][4 * r4 + 3], inv)};
+        st4h(op + dh, v);
+      }
+  }
+}
+
+// Which attention loop the encoder runs, fixed per process (model.hip folds log2(e) into the encoder's query projections for
+// the lazy form: the two must agree).  WIS_ENC_ATTN_LAZY=0/1 is the A/B switch.
+bool enc_attn_lazy() {
+  static const bool on = !(getenv("WIS_ENC_ATTN_LAZY") && atoi(getenv("WIS_ENC_ATTN_LAZY")) == 0);
+  return on;
+}
+
+// op-level entry only (wis_op_enc_attention keeps its contract "Q pre-scaled by 1/sqrt(64)"): the Q half of a [rows][2d] Q|K image
+// times log2(e), in place on a private copy
+__global__ void scale_q_log2e_kernel(f16* __restrict__ qk, int64_t rows, int d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * d) return;
+  f16* p = qk + (i / d) * (2 * (int64_t)d) + i % d;
+  *p = (f16)((float)*p * 1.4426950408889634f);
+}
+void launch_scale_q_log2e(hipStream_t st, f16* qk, int64_t rows, int d) {
+  hipLaunchKernelGGL(scale_q_log2e_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, qk, rows, d);
+}
+
 // part / counters: ENC_PART_FLOATS floats per workgroup and one zeroed counter per (utterance, head, query tile); given and with
 // at most 600 unsplit workgroups (one or two utterances) the key range is split over two workgroups
 size_t enc_attention_part_floats(int B, int T, int H) { return (size_t)B * H * cdiv(T, 128) * 2 * ENC_PART_FLOATS; }
@@ -1475,6 +1714,11 @@ int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out,
   static const int env = getenv("WIS_ENC_ATTN_SPLIT") ? atoi(getenv("WIS_ENC_ATTN_SPLIT")) : -1;      // tuning: 0 never, 1 whenever possible
   const int wgs = cdiv(T, 128) * H * B;
   const bool split = part && counters && (size_t)wgs <= part_cap && cdiv(T, AKT) >= 4 && (env >= 0 ? env == 1 : wgs <= 600);      // never beyond the scratch it was given
+  if (enc_attn_lazy()) {
+    if (split) hipLaunchKernelGGL((enc_attn_lazy_kernel<true>), dim3(2 * cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
+    else hipLaunchKernelGGL((enc_attn_lazy_kernel<false>), dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
+    return WIS_OK;
+  }
   if (split) hipLaunchKernelGGL((enc_attn_kernel<true>), dim3(2 * cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
   else hipLaunchKernelGGL((enc_attn_kernel<false>), dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
   return WIS_OK;

@@ -33,6 +33,9 @@ int launch_gemm_crosskv(hipStream_t st, const GemmP& p, const float* bias, f16* 
 int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H, float* part = nullptr, unsigned* counters = nullptr,
                          size_t part_cap = 0);
 size_t enc_attention_part_floats(int B, int T, int H);
+// true: the lazy-reference loop (enc_attn_lazy_kernel), which expects Q pre-multiplied by log2(e) / sqrt(64); fixed per process
+bool enc_attn_lazy();
+void launch_scale_q_log2e(hipStream_t st, f16* qk, int64_t rows, int d);      // (op-level entry: Q half of a [rows][2d] image times log2(e))
 
 // ---- decoder ---------------------------------------------------------------------------
 constexpr int MAX_ROWS = 96;      // decoder rows per pass: B*beam (decode) or B*P (merged prefill + first step): 16 utterances x beam 5 + slack; wis_hip/ctranslate2.py MAX_DECODER_ROWS

@@ -329,8 +329,10 @@ int load_weights(wis_model* m, const Loader& L) {
       EncLayerW& w = m->enc[l];
       if ((rc = to_f32(m, L, p + "self_attention/layer_norm/gamma", d, &w.ln1_g))) break;
       if ((rc = to_f32(m, L, p + "self_attention/layer_norm/beta", d, &w.ln1_b))) break;
-      if ((rc = to_f16_mat(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.w_qkv, d, qs))) break;
-      if ((rc = to_f32(m, L, p + "self_attention/linear_0/bias", 3 * d, &w.b_qkv, d, qs))) break;
+      // (the lazy-reference attention loop takes exp2 of the MFMA result directly: log2(e) rides on the query projection too)
+      const float qs_enc = enc_attn_lazy() ? qs * 1.4426950408889634f : qs;
+      if ((rc = to_f16_mat(m, L, p + "self_attention/linear_0/weight", 3 * d, d, &w.w_qkv, d, qs_enc))) break;
+      if ((rc = to_f32(m, L, p + "self_attention/linear_0/bias", 3 * d, &w.b_qkv, d, qs_enc))) break;
       if ((rc = to_f16_mat(m, L, p + "self_attention/linear_1/weight", d, d, &w.w_out))) break;
       if ((rc = to_f32(m, L, p + "self_attention/linear_1/bias", d, &w.b_out))) break;
       if ((rc = to_f32(m, L, p + "ffn/layer_norm/gamma", d, &w.ln2_g))) break;
@@ -1459,12 +1461,21 @@ int wis_op_enc_attention(int device, const void* qk, const void* vt, void* out, 
   int rc = WIS_OK;
   if (hipMalloc(reinterpret_cast<void**>(&part), enc_attention_part_floats(B, T, H) * 4) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&counters), ncnt * 4) != hipSuccess) { set_error("wis_op_enc_attention: out of device memory"); rc = WIS_E_NOMEM; }
+  f16* qk2 = nullptr;      // the lazy-reference loop wants log2(e) on Q as well (the engine folds it into the projection): a scaled private copy
+  if (!rc && enc_attn_lazy()) {
+    const size_t n = (size_t)B * T * 2 * H * 64;
+    if (hipMalloc(reinterpret_cast<void**>(&qk2), n * 2) != hipSuccess) { set_error("wis_op_enc_attention: out of device memory"); rc = WIS_E_NOMEM; }
+    else {
+      hipMemcpyAsync(qk2, qk, n * 2, hipMemcpyDeviceToDevice, st);
+      launch_scale_q_log2e(st, qk2, (int64_t)B * T, H * 64);
+    }
+  }
   if (!rc) {
     hipMemsetAsync(counters, 0, ncnt * 4, st);
-    rc = launch_enc_attention(st, reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H, part, counters, ncnt);
+    rc = launch_enc_attention(st, qk2 ? qk2 : reinterpret_cast<const f16*>(qk), reinterpret_cast<const f16*>(vt), reinterpret_cast<f16*>(out), B, T, Tpad, H, part, counters, ncnt);
   }
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(part); hipFree(counters);
+  hipFree(part); hipFree(counters); hipFree(qk2);
   if (rc) return rc;
   if (e != hipSuccess) { set_error("wis_op_enc_attention: %s", hipGetErrorString(e)); return WIS_E_HIP; }
   return WIS_OK;
