@@ -29,7 +29,7 @@ ALG_B8 = {"gemv_frag_kernel<3, 8, false> 40960": 8 * D * D,      # FFN2: two K s
 TEMPLATE_NOTE = ("Template arguments: `gemv_kernel<MB, MODE, SC, RM, W8>` (MODE 1 = LayerNorm-folded projection on raw fp32 rows, MODE 2 = f16 activations; SC = compile-time k-steps per wave, 0 = "
                  "generic ring: FFN2), `gemv_dual_kernel<SCA, SCB>` (out-projection + folded cross-Q in one launch), `gemv_frag_kernel<MB, PF, W8>` (batched rows on fragment images: MB 16-row blocks, "
                  "PF k-steps in flight), `dec_cross_attn_kernel<TPW, CM, FOLD, SPIN>` (SPIN = granule hand-off of the chunk partials), `gemm_8p_kernel<Epi, TR>` (8-phase 256 x 256 LDS-DMA GEMM, "
-                 "persistent over tiles; TR = swapped operands for the V images; EpiResid = bias + fp32 residual), `gemm_8pn_kernel<Epi>` (the same on a 128 x 256 tile: FFN1 of one utterance), `gemm_f16_kernel<Epi, BM, BN, WM, WN>` / `gemm_pp_kernel<Epi>` (register-staged tiles / ping-pong 256 x 128), `enc_attn_kernel<SPLIT>`, "
+                 "persistent over tiles; TR = swapped operands for the V images; EpiResid = bias + fp32 residual), `gemm_8pn_kernel<Epi>` (the same on a 128 x 256 tile: FFN1 of one utterance), `gemm_f16_kernel<Epi, BM, BN, WM, WN>` / `gemm_pp_kernel<Epi>` (register-staged tiles / ping-pong 256 x 128), `enc_attn_lazy_kernel<SPLIT>` (r4: lazy softmax reference; `enc_attn_kernel<SPLIT>` is the A/B form behind WIS_ENC_ATTN_LAZY=0), "
                  "`splitk_reduce_ln_kernel<SPLITS>`, `layernorm_kernel<AFFINE>`.  By-grid table: 20480 threads = 80 tiles (d x d; FFN2 at one utterance), 40960 = FFN2 of the batched path (two K slices), 61440 = QKV, 81920 = FFN1, 829952 = vocabulary projection.")
 
 
