@@ -115,13 +115,13 @@ def pmc_encoder(tag, tcc_tag=None):
     a, b = parse_pmc(f"{G}/{tag}/pmc_sq1_b8.txt"), parse_pmc(f"{G}/{tag}/pmc_sq2_b8.txt")
     if not a:
         return
-    lines = ["# SQ counters of the encoder kernels at 8 utterances per device batch (rocprofv3 --pmc, two passes), round 3", "",
+    lines = [f"# SQ counters of the encoder kernels at 8 utterances per device batch (rocprofv3 --pmc, two passes), round {int(RND[1:])}", "",
              "Command per pass (`bash tools/gpu_session.sh pmc sq1 \"...\" 8`): `WIS_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc <8 SQ counters> --output-format csv -- python bench.py --steps 2 --warmup 1 --batch 8 "
              "--no-cpu-baseline --no-extras --no-roofline` (large-v2).  `SQ_WAVE_CYCLES`, `SQ_WAIT_*`, `SQ_ACTIVE_INST_*` count quad-cycles; `SQ_VALU_MFMA_BUSY_CYCLES` counts cycles "
              "(16 per `v_mfma_f32_16x16x32_f16`, 32 per `32x32x16`), so the MFMA share of wave time = MFMA_BUSY / (4 x WAVE_CYCLES) - with two waves per SIMD (the 8-phase GEMM) the matrix pipe of a SIMD is busy "
-             "for twice that share.  Means per launch.", "",
-             "| kernel (grid threads) | launches | parked on waitcnt / barrier (WAIT_ANY) | issue stall (WAIT_INST_ANY; of which LDS) | issuing (ACTIVE_INST_ANY) | MFMA busy / wave time | MFMA pipe busy per SIMD (x waves per SIMD) | LDS bank-conflict / LDS active cycles |",
-             "|---|---|---|---|---|---|---|---|"]
+             "for twice that share.  Means per launch.  (r4: the attention row is `enc_attn_lazy_kernel`; round 3's `enc_attn_kernel` row read 0.27 / 0.39 (0.05) / 0.34 / 0.15, vector ALU 0.26 of wave time = 0.78 of a SIMD, 4612 VALU instructions per wave.)", "",
+             "| kernel (grid threads) | launches | parked on waitcnt / barrier (WAIT_ANY) | issue stall (WAIT_INST_ANY; of which LDS) | issuing (ACTIVE_INST_ANY) | MFMA busy / wave time | MFMA pipe busy per SIMD (x waves per SIMD) | LDS bank-conflict / LDS active cycles | vector ALU busy / wave time (ACTIVE_INST_VALU; x3 = share of a SIMD at three waves) | VALU instructions per wave (INSTS_VALU / waves) |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
     for (name, grid), cs in sorted(a.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", (0, 0))[1] * kv[1].get("SQ_WAVE_CYCLES", (0, 0))[0]):
         if not any(k in name for k in ("gemm_8p", "gemm_f16", "gemm_pp", "enc_attn", "layernorm")):
             continue
@@ -133,7 +133,8 @@ def pmc_encoder(tag, tcc_tag=None):
         waves = 2 if "gemm_8p" in name or "gemm_pp" in name else 1
         mfma = g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * wc)
         lines.append(f"| `{short(name)}` ({grid}) | {cs['SQ_WAVE_CYCLES'][0]} | {g('SQ_WAIT_ANY') / wc:.2f} | {g('SQ_WAIT_INST_ANY') / wc:.2f} ({g('SQ_WAIT_INST_LDS') / wc:.2f}) | {g('SQ_ACTIVE_INST_ANY') / wc:.2f} | "
-                     f"{mfma:.2f} | {mfma * waves:.2f} | {c2.get('SQ_LDS_BANK_CONFLICT', (0, 0))[1]:.3g} / {c2.get('SQ_LDS_IDX_ACTIVE', (0, 0))[1]:.3g} |")
+                     f"{mfma:.2f} | {mfma * waves:.2f} | {c2.get('SQ_LDS_BANK_CONFLICT', (0, 0))[1]:.3g} / {c2.get('SQ_LDS_IDX_ACTIVE', (0, 0))[1]:.3g} | "
+                     f"{c2.get('SQ_ACTIVE_INST_VALU', (0, 0))[1] / wc:.2f} | {c2.get('SQ_INSTS_VALU', (0, 0))[1] / (int(grid) / 64):.0f} |")
     t = parse_pmc(f"{G}/{tcc_tag}/pmc_tcc_b1.txt") if tcc_tag else {}
     if t:
         lines += ["", "## L2 (TCC) counters of the encoder kernels at ONE utterance (`pmc tcc \"TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum\" 1`)", "",
@@ -148,7 +149,7 @@ def pmc_encoder(tag, tcc_tag=None):
                 continue
             lines.append(f"| `{short(name)}` ({grid}) | {cs['TCC_REQ_sum'][0]} | {g('TCC_REQ_sum'):.3g} | {g('TCC_HIT_sum'):.3g} | {g('TCC_MISS_sum'):.3g} | {g('TCC_MISS_sum') / g('TCC_REQ_sum'):.2f} | {g('TCC_EA0_RDREQ_sum'):.3g} |")
     open(f"{P}/{RND}_pmc_encoder_sq.md", "w").write("\n".join(lines) + "\n")
-    print("wrote r03_pmc_encoder_sq.md")
+    print(f"wrote {RND}_pmc_encoder_sq.md")
 
 
 def lab(tag_multi, tag_single):
@@ -181,9 +182,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", default="r03")
     ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--lab"); ap.add_argument("--lab-single"); ap.add_argument("--bench"); ap.add_argument("--tcc")
+    ap.add_argument("--pmc-enc", help="only the encoder SQ table (passes sq1 / sq2 of that tag)")
     a = ap.parse_args()
     globals()["RND"] = a.round
     if a.stats: kernel_stats(a.stats)
     if a.pmc: pmc_decode(a.pmc); pmc_encoder(a.pmc, a.tcc)
+    if a.pmc_enc: pmc_encoder(a.pmc_enc, a.tcc)
     if a.lab or a.lab_single: lab(a.lab, a.lab_single)
     if a.bench: bench(a.bench)
