@@ -24,6 +24,16 @@
 // per SIMD therefore needs either the Q fragments out of registers (they do not fit in LDS beside four workgroups' K / V buffers:
 // 4 x (32 + 16) KiB > 160) or a hand-allocated loop; neither is a round-4 change.  (An earlier B = 8 run of this lab faulted: the
 // uniform-pointer macro sign-extended the low address half; fixed below.)
+// STAMPS of the shipped loop (lazy_prof below: one wave of a mid-grid workgroup, s_memtime ticks per 64-key tile; profiles/r04_attn_lab.txt):
+//                                           scores ready | weights done | P.V issued | next tile stored | barrier | tile
+//   one utterance, unsplit (ONE wave per SIMD)       508 |          408 |        533 |              168 |     119 | 1736
+//   one utterance, split-key (two per SIMD)          583 |          416 |        490 |              152 |      68 | 1710
+//   eight utterances, unsplit (three per SIMD)       642 |          614 |        575 |              241 |     221 | 2293
+// - a lone wave needs 1736 ticks per tile, 512 of them on the matrix pipe: the tile is a serial chain (LDS read -> MFMA chain -> 32
+//   exponentials -> LDS read -> MFMA chain -> store -> barrier), and a second wave on the SIMD costs the first almost nothing (1710);
+// - 32 v_exp_f32 + 16 v_cvt_pk + 16 v_dot2c take 408 ticks: the exponential costs ~8 ticks per wave instruction here, not the 16 of a
+//   quarter-rate instruction that rounds 2-3 assumed;
+// - at three waves per SIMD every phase stretches by 10-50 % and a SIMD finishes a tile every 764 ticks (matrix pipe 512).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -I include -I willow-inference-server_amd/csrc \
 //        -o tools/bin/attn_lab tools/attn_lab.hip ;  run: tools/bin/attn_lab [B=8] [iters=20]
 #include "../willow-inference-server_amd/csrc/enc_kernels.hip"
@@ -196,6 +206,221 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
   }
 }
 
+// ---- the shipped loop (csrc/enc_kernels.hip enc_attn_lazy_kernel, copied statement for statement by a script) with s_memtime stamps of ONE
+// wave (wave 0 of workgroup `probe_wg`): per key tile t0 top of the iteration, t1 scores of the tile in registers, t2 weights converted
+// and summed (fast path; on a reference step t2 is stale), t3 last P.V MFMA issued, t4 next tile's K / V stored to LDS (behind its
+// vmcnt(0)), t5 behind the barrier.  prof[tile * 8 + i].
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void lazy_prof(const f16* __restrict__ qk, const f16* __restrict__ vt,
+                                          f16* __restrict__ out, int T, int Tpad, int H, int d, float* part, unsigned* counters, unsigned long long* prof, int probe_wg) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) f16 sK[2][AKT * ASTR];
+  __shared__ __attribute__((aligned(16))) f16 sV[2][64 * ASTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qt = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, half = SPLIT ? (int)blockIdx.x & 1 : 0;
+  const int q_row = qt * 128 + wave * 32 + l31;
+  const int q_c = q_row < T ? q_row : T - 1;
+  const int ld = 2 * d;
+
+  f16x8 qf[4];
+  {
+    const f16* qp = qk + (size_t)(b * T + q_c) * ld + h * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const f16x8*>(qp + kk * 16 + hi * 8);
+  }
+  const f16* kbase = qk + (size_t)b * T * ld + d + h * 64;
+  const f16* vbase = vt + (size_t)(b * H + h) * 64 * Tpad;
+  const int lrow0 = tid >> 3, lrow1 = (tid + 256) >> 3, lch = (tid & 7) * 8;
+  const f16* vp0 = vbase + (size_t)lrow0 * Tpad + lch;
+  const f16* vp1 = vbase + (size_t)lrow1 * Tpad + lch;
+  const int so0 = lrow0 * ASTR + lch, so1 = lrow1 * ASTR + lch;
+  // K / V tile on its way to LDS (loads and their hand-placed wait: see enc_attn_kernel).  Measured and not kept for the split-key
+  // form: a second register set with tile kt+2 requested at the top of tile kt and a counted vmcnt(4) in front of the LDS stores
+  // (correct, 202 VGPRs, 28.47 us per layer at one utterance against 28.46: the tile time there is not the load latency either).
+  u32x4 ra[4];
+#define WIS_GLOAD(kt, R)                                                                   \
+  {                                                                                        \
+    int key0 = (kt) * AKT + lrow0; if (key0 > T - 1) key0 = T - 1;                          \
+    int key1 = (kt) * AKT + lrow1; if (key1 > T - 1) key1 = T - 1;                          \
+    const f16* a0_ = kbase + (size_t)key0 * ld + lch; const f16* a1_ = kbase + (size_t)key1 * ld + lch;   \
+    const f16* a2_ = vp0 + (kt) * AKT; const f16* a3_ = vp1 + (kt) * AKT;                   \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"  \
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"      \
+                 : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]) : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory"); \
+  }
+#define WIS_SSTORE(buf, R, WAIT)                                                           \
+  asm volatile(WAIT : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) :: "memory");         \
+  *reinterpret_cast<u32x4*>(&sK[buf][so0]) = R[0];                                         \
+  *reinterpret_cast<u32x4*>(&sK[buf][so1]) = R[1];                                         \
+  *reinterpret_cast<u32x4*>(&sV[buf][so0]) = R[2];                                         \
+  *reinterpret_cast<u32x4*>(&sV[buf][so1]) = R[3];
+  // S^T[key][q] - m_ref[q] = K . Q^T + C  (A = K rows, B = Q rows, C = the reference splat); keys >= T (last tile only) -> -inf
+#define WIS_SCORES()                                                                       \
+  _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(&sK[cur][(t2 * 32 + l31) * ASTR + kk * 16 + hi * 8]); \
+      st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? negm : st[t2], 0, 0, 0); \
+    }                                                                                      \
+  }                                                                                        \
+  if (kt == nt_all - 1) {                                                                  \
+    const int key_base = kt * AKT + 4 * hi;                                                \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                       \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+        const int key = key_base + t2 * 32 + (r & 3) + 8 * (r >> 2);                       \
+        if (key >= T) st[t2][r] = -INFINITY;                                               \
+      }                                                                                    \
+  }
+  // weights, their f16 pairs in P.V operand order (k-step s of 16 keys <-> S-tile s>>1, regs 8(s&1)..+7; slot j of half `hi` is
+  // key 16s + 8(j>>2) + 4hi + (j&3): V^T is stored in exactly that order) and the row sum of the ROUNDED weights
+#define WIS_WEIGHTS()                                                                      \
+  rs = 0.f;                                                                                \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                            \
+    _Pragma("unroll") for (int j = 0; j < 8; j += 2) {                                     \
+      const f16x2 pr = {(f16)__builtin_amdgcn_exp2f(st[s >> 1][8 * (s & 1) + j]), (f16)__builtin_amdgcn_exp2f(st[s >> 1][8 * (s & 1) + j + 1])}; \
+      pf[s][j] = pr[0]; pf[s][j + 1] = pr[1];                                              \
+      rs = __builtin_amdgcn_fdot2(pr, f16x2{(f16)1.f, (f16)1.f}, rs, false);               \
+    }
+
+  const bool probe = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) == probe_wg && wave == 0;
+  unsigned long long tsv[6];
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); tsv[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+  f32x16 o[2], negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  float m_run = 0.f, l_run = 0.f;      // m_run: the reference (log2 domain), NOT necessarily the running maximum
+
+  const int nt_all = cdiv(T, AKT), nt_half = (nt_all + 1) >> 1;
+  const int t_beg = SPLIT ? half * nt_half : 0;
+  const int ntiles = SPLIT ? (t_beg + nt_half < nt_all ? t_beg + nt_half : nt_all) : nt_all;
+  constexpr float BIG = 32768.f;
+  // one key tile out of LDS buffer CUR: scores, weights, (rarely) the reference step, P.V.  (A macro, not a lambda: with the body behind a
+  // lambda hipcc allocated 182 VGPRs for the unsplit instantiation - 168 with spills when held to three waves per SIMD - against 158 inline.)
+  // In the reference step: on the first tile the reference becomes the tile's maximum whatever its sign (tile t_beg always holds a
+  // key < T, so mx is finite; l and O are zero there, alpha = 0 keeps them so); both key halves of a query share one reference.
+#define WIS_TILE(KT, CUR, FIRST)                                                           \
+  {                                                                                        \
+    const int kt = (KT), cur = (CUR); const bool first = (FIRST);                          \
+    f32x16 st[2];                                                                          \
+    f16x8 pf[4];                                                                           \
+    float rs;                                                                              \
+    bool slow = first;                                                                     \
+    WIS_SCORES()                                                                           \
+    asm volatile("" :: "v"(st[0][15]), "v"(st[1][15])); STAMP(1)                           \
+    if (!first) {                                                                          \
+      WIS_WEIGHTS()                                                                        \
+      asm volatile("" :: "v"(rs)); STAMP(2)                                                \
+      slow = __any(!(rs < BIG));                                                           \
+      if (slow) { WIS_SCORES() }                                                           \
+    }                                                                                      \
+    if (slow) {                                                                            \
+      float mx = st[0][0];                                                                 \
+_Pragma("unroll")                                                                          \
+      for (int t2 = 0; t2 < 2; ++t2)                                                       \
+_Pragma("unroll")                                                                          \
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);                            \
+      mx = fmaxf(mx, __shfl_xor(mx, 32));                                                  \
+      const float delta = first ? mx : fmaxf(mx, 0.f);                                     \
+      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);                    \
+      m_run += delta;                                                                      \
+      l_run *= alpha;                                                                      \
+_Pragma("unroll")                                                                          \
+      for (int r = 0; r < 16; ++r) { o[0][r] = mul_scalar(o[0][r], alpha); o[1][r] = mul_scalar(o[1][r], alpha); negm[r] = -m_run; }\
+_Pragma("unroll")                                                                          \
+      for (int t2 = 0; t2 < 2; ++t2)                                                       \
+_Pragma("unroll")                                                                          \
+        for (int r = 0; r < 16; ++r) st[t2][r] -= delta;                                   \
+      WIS_WEIGHTS()                                                                        \
+    }                                                                                      \
+    l_run += rs;                                                                           \
+_Pragma("unroll")                                                                          \
+    for (int dt = 0; dt < 2; ++dt)                                                         \
+_Pragma("unroll")                                                                          \
+      for (int s = 0; s < 4; ++s) {                                                        \
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(&sV[cur][(dt * 32 + l31) * ASTR + 16 * s + 8 * hi]);\
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[dt], 0, 0, 0);         \
+      }                                                                                    \
+    STAMP(3)                                                                               \
+  }
+  WIS_GLOAD(t_beg, ra) WIS_SSTORE(0, ra, "s_waitcnt vmcnt(0)")
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the Q fragments are complete, and hipcc's waitcnt pass knows it (see enc_attn_kernel)
+  __syncthreads();
+  for (int kb = t_beg; kb < ntiles; ++kb) {      // (the tile macro declares kt / cur itself)
+    const int cur0 = (kb - t_beg) & 1;
+    STAMP(0)
+    if (kb + 1 < ntiles) WIS_GLOAD(kb + 1, ra)
+    WIS_TILE(kb, cur0, kb == t_beg)
+    if (kb + 1 < ntiles) { WIS_SSTORE(cur0 ^ 1, ra, "s_waitcnt vmcnt(0)") }
+    STAMP(4)
+    __syncthreads();
+    STAMP(5)
+    if (probe && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) prof[(kb - t_beg) * 8 + i] = tsv[i];
+    }
+  }
+#undef WIS_GLOAD
+#undef WIS_SSTORE
+#undef WIS_SCORES
+#undef WIS_WEIGHTS
+#undef WIS_TILE
+#undef STAMP
+  if (SPLIT) {
+    // (hand-off as in enc_attn_kernel; the merge formula holds for references as it does for maxima)
+    __shared__ int s_last;
+    const int nqt = (int)gridDim.x >> 1;
+    const size_t pair = (size_t)(b * H + h) * nqt + qt;
+    float* mine = part + (pair * 2 + half) * ENC_PART_FLOATS + tid;
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine), __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 256), __float_as_uint(l_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(mine + (2 + a * 16 + r) * 256), __float_as_uint(o[a][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(counters + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == 1u;
+      if (last) {
+        __hip_atomic_store(counters + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* other = part + (pair * 2 + (half ^ 1)) * ENC_PART_FLOATS + tid;
+    const float m1 = other[0], l1 = other[256];
+    float o1[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o1[a][r] = other[(2 + a * 16 + r) * 256];
+    const float mm = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[a][r] = add_scalar(mul_scalar(o[a][r], a0), mul_scalar(o1[a][r], a1));      // the sum of two products: symmetric in the two states
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_row < T) {
+    f16* op = out + (size_t)(b * T + q_row) * d + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dh = dt * 32 + 8 * r4 + 4 * hi;
+        f32x4 v = {mul_scalar(o[dt][4 * r4], inv), mul_scalar(o[dt][4 * r4 + 1], inv), mul_scalar(o[dt][4 * r4 + 2], inv), mul_scalar(o[dt][4 * r4 + 3], inv)};
+        st4h(op + dh, v);
+      }
+  }
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 8, iters = argc > 2 ? atoi(argv[2]) : 20;
   const int T = 1500, H = 20, d = H * 64, Tpad = 1536;
@@ -232,5 +457,30 @@ int main(int argc, char** argv) {
   timeit("attn4<v_sub, 3 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<false, 3>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_b, false);
   timeit("attn4<splat, 4 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<true, 4>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_a, false);
   timeit("attn4<v_sub, 4 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<false, 4>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_b, false);
+  // stamps of one wave of a mid-grid workgroup: unsplit form at this B, and the split form (what one and two utterances run)
+  unsigned long long* prof; CK(hipMalloc(&prof, 32 * 8 * 8));
+  float* part; unsigned* cnt; CK(hipMalloc(&part, wis::enc_attention_part_floats(B, T, H) * 4)); CK(hipMalloc(&cnt, (size_t)B * H * cdiv(T, 128) * 4)); CK(hipMemset(cnt, 0, (size_t)B * H * cdiv(T, 128) * 4));
+  for (int split = 0; split < 2; ++split) {
+    const dim3 g(split ? 2 * cdiv(T, 128) : cdiv(T, 128), H, B);
+    const int probe_wg = (int)(g.x * g.y * g.z / 2 + 3);
+    CK(hipMemset(prof, 0, 32 * 8 * 8));
+    for (int rep = 0; rep < 3; ++rep) {
+      if (split) hipLaunchKernelGGL((lazy_prof<true>), g, blk, 0, 0, qk, vt, o_a, T, Tpad, H, d, part, cnt, prof, probe_wg);
+      else hipLaunchKernelGGL((lazy_prof<false>), g, blk, 0, 0, qk, vt, o_a, T, Tpad, H, d, part, cnt, prof, probe_wg);
+      CK(hipDeviceSynchronize());
+    }
+    std::vector<unsigned long long> hp(32 * 8); CK(hipMemcpy(hp.data(), prof, 32 * 8 * 8, hipMemcpyDeviceToHost));
+    const int nt = split ? 12 : 24;
+    printf("stamps (%s form, %u workgroups, probe %d; s_memtime ticks per tile: scores ready | weights done | P.V issued | next tile stored | barrier | tile total)\n", split ? "split-key" : "unsplit", g.x * g.y * g.z, probe_wg);
+    double sum[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+    for (int t = 0; t < nt; ++t) {
+      const unsigned long long* s = &hp[t * 8];
+      if (!s[5]) continue;
+      const long long d1 = s[1] - s[0], d2 = s[2] - s[1], d3 = s[3] - s[2], d4 = s[4] - s[3], d5 = s[5] - s[4], tot = s[5] - s[0];
+      if (t < 4 || t == nt - 1) printf("  tile %2d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", t, d1, d2, d3, d4, d5, tot);
+      if (t >= 1 && t < nt - 1) { sum[0] += d1; sum[1] += d2; sum[2] += d3; sum[3] += d4; sum[4] += d5; sum[5] += tot; ++n; }
+    }
+    if (n) printf("  mean of tiles 1..%d: %6.0f %6.0f %6.0f %6.0f %6.0f | %6.0f ticks\n", nt - 2, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n);
+  }
   return 0;
 }
