@@ -35,7 +35,7 @@
 //   quarter-rate instruction that rounds 2-3 assumed;
 // - at three waves per SIMD every phase stretches by 10-50 % and a SIMD finishes a tile every 764 ticks (matrix pipe 512).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -I include -I willow-inference-server_amd/csrc \
-//        -o tools/bin/attn_lab tools/attn_lab.hip ;  run: tools/bin/attn_lab [B=8] [iters=20]
+//        -o tools/bin/attn_lab tools/attn_lab.hip ;  run: tools/bin/attn_lab [B=8] [iters=20] [load: only the shipped kernel]
 #include "../willow-inference-server_amd/csrc/enc_kernels.hip"
 #include <cstdarg>
 #include <cstring>
@@ -282,8 +282,13 @@ __global__ __launch_bounds__(256) void lazy_prof(const f16* __restrict__ qk, con
       rs = __builtin_amdgcn_fdot2(pr, f16x2{(f16)1.f, (f16)1.f}, rs, false);               \
     }
 
-  const bool probe = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) == probe_wg && wave == 0;
-  unsigned long long tsv[6];
+  const int wg_id = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const bool probe = wg_id == probe_wg && wave == 0;
+  const bool probe2 = (wg_id | 1) == (probe_wg | 1) && wave == 0;      // both workgroups of the probe's split pair: kernel phases
+  unsigned long long tsv[6], ph[8];
+  ph[0] = __builtin_amdgcn_s_memtime();
+#define PHASE(i) { __builtin_amdgcn_sched_barrier(0); ph[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define PHASE_OUT(n) if (probe2 && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) prof[(28 + 2 * (wg_id & 1)) * 8 + i_] = ph[i_]; prof[(29 + 2 * (wg_id & 1)) * 8] = (n); }
 #define STAMP(i) { __builtin_amdgcn_sched_barrier(0); tsv[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
   f32x16 o[2], negm;
 #pragma unroll
@@ -345,6 +350,7 @@ _Pragma("unroll")                                                               
   WIS_GLOAD(t_beg, ra) WIS_SSTORE(0, ra, "s_waitcnt vmcnt(0)")
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the Q fragments are complete, and hipcc's waitcnt pass knows it (see enc_attn_kernel)
   __syncthreads();
+  PHASE(1)
   for (int kb = t_beg; kb < ntiles; ++kb) {      // (the tile macro declares kt / cur itself)
     const int cur0 = (kb - t_beg) & 1;
     STAMP(0)
@@ -365,6 +371,7 @@ _Pragma("unroll")                                                               
 #undef WIS_WEIGHTS
 #undef WIS_TILE
 #undef STAMP
+  PHASE(2)
   if (SPLIT) {
     // (hand-off as in enc_attn_kernel; the merge formula holds for references as it does for maxima)
     __shared__ int s_last;
@@ -380,6 +387,7 @@ _Pragma("unroll")                                                               
         __hip_atomic_store(reinterpret_cast<unsigned*>(mine + (2 + a * 16 + r) * 256), __float_as_uint(o[a][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PHASE(3)
     if (tid == 0) {
       const unsigned prev = __hip_atomic_fetch_add(counters + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = prev == 1u;
@@ -390,7 +398,8 @@ _Pragma("unroll")                                                               
       s_last = last;
     }
     __syncthreads();
-    if (!s_last) return;
+    PHASE(4)
+    if (!s_last) { PHASE_OUT(5) return; }
     const float* other = part + (pair * 2 + (half ^ 1)) * ENC_PART_FLOATS + tid;
     const float m1 = other[0], l1 = other[256];
     float o1[2][16];
@@ -405,6 +414,7 @@ _Pragma("unroll")                                                               
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[a][r] = add_scalar(mul_scalar(o[a][r], a0), mul_scalar(o1[a][r], a1));      // the sum of two products: symmetric in the two states
+    asm volatile("" :: "v"(o[1][15])); PHASE(5)
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
@@ -419,6 +429,9 @@ _Pragma("unroll")                                                               
         st4h(op + dh, v);
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PHASE(6)
+  PHASE_OUT(7)
 }
 
 int main(int argc, char** argv) {
@@ -451,6 +464,10 @@ int main(int argc, char** argv) {
            outp == o_ref ? "" : (exact ? (nd ? "   <-- MUST BE IDENTICAL" : "   (identical)") : ""));
   };
   printf("encoder attention lab: B=%d T=%d H=%d, %d launches each\n", B, T, H, iters);
+  if (argc > 3) {      // "load" mode: only the shipped kernel, `iters` launches back to back (for sampling the shader clock with rocm-smi meanwhile)
+    timeit("shipped enc_attn_lazy_kernel<false>", [&](f16* o) { hipLaunchKernelGGL((enc_attn_lazy_kernel<false>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d, (float*)nullptr, (unsigned*)nullptr); }, o_ref, true);
+    return 0;
+  }
   timeit("shipped enc_attn_lazy_kernel<false>", [&](f16* o) { hipLaunchKernelGGL((enc_attn_lazy_kernel<false>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d, (float*)nullptr, (unsigned*)nullptr); }, o_ref, true);
   timeit("round-2 enc_attn_kernel<false>", [&](f16* o) { hipLaunchKernelGGL((enc_attn_kernel<false>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d, (float*)nullptr, (unsigned*)nullptr); }, o_a, false);
   timeit("attn4<splat, 3 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<true, 3>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_a, false);
@@ -479,6 +496,14 @@ int main(int argc, char** argv) {
       const long long d1 = s[1] - s[0], d2 = s[2] - s[1], d3 = s[3] - s[2], d4 = s[4] - s[3], d5 = s[5] - s[4], tot = s[5] - s[0];
       if (t < 4 || t == nt - 1) printf("  tile %2d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", t, d1, d2, d3, d4, d5, tot);
       if (t >= 1 && t < nt - 1) { sum[0] += d1; sum[1] += d2; sum[2] += d3; sum[3] += d4; sum[4] += d5; sum[5] += tot; ++n; }
+    }
+    for (int w = 0; w < 2; ++w) {
+      const unsigned long long* q = &hp[(28 + 2 * w) * 8]; const int np = (int)hp[(29 + 2 * w) * 8];
+      if (!np || (!split && w != (probe_wg & 1))) continue;
+      printf("  kernel phases of workgroup %d (ticks since entry): loop starts %lld, loop ends %lld", (probe_wg & ~1) + w, (long long)(q[1] - q[0]), (long long)(q[2] - q[0]));
+      if (split) printf(", partials published %lld, ticket drawn %lld%s", (long long)(q[3] - q[0]), (long long)(q[4] - q[0]), np == 5 ? " (first to arrive: returns)" : "");
+      if (np == 7) { if (split) printf(", merged %lld", (long long)(q[5] - q[0])); printf(", rows stored %lld", (long long)(q[6] - q[0])); }
+      printf("\n");
     }
     if (n) printf("  mean of tiles 1..%d: %6.0f %6.0f %6.0f %6.0f %6.0f | %6.0f ticks\n", nt - 2, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n);
   }
