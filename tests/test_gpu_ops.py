@@ -128,7 +128,7 @@ def test_layernorm(lib, M, d):
     assert e < 1e-3
 
 
-# grids of <= 600 workgroups with >= 4 key tiles take the split-key form (two workgroups per query tile and head, merged in the
+# grids of <= 256 workgroups with >= 4 key tiles take the split-key form (two workgroups per query tile and head, merged in the
 # launch by whichever arrives last): (1, 200, 2), (2, 1500, 3) and the large-v2 shape (1, 1500, 20); (3, 1500, 20) and the short ones do not
 @pytest.mark.parametrize("B,T,H", [(1, 200, 2), (2, 1500, 3), (1, 64, 1), (1, 129, 2), (1, 1500, 20), (3, 1500, 20)])
 def test_enc_attention(lib, B, T, H):

@@ -464,8 +464,13 @@ int main(int argc, char** argv) {
            outp == o_ref ? "" : (exact ? (nd ? "   <-- MUST BE IDENTICAL" : "   (identical)") : ""));
   };
   printf("encoder attention lab: B=%d T=%d H=%d, %d launches each\n", B, T, H, iters);
-  if (argc > 3) {      // "load" mode: only the shipped kernel, `iters` launches back to back (for sampling the shader clock with rocm-smi meanwhile)
+  if (argc > 3) {      // "load" mode: only the shipped kernel, `iters` launches back to back (for sampling the shader clock with rocm-smi meanwhile); "split": then its split-key form too
     timeit("shipped enc_attn_lazy_kernel<false>", [&](f16* o) { hipLaunchKernelGGL((enc_attn_lazy_kernel<false>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d, (float*)nullptr, (unsigned*)nullptr); }, o_ref, true);
+    if (!strcmp(argv[3], "split")) {
+      float* part2; unsigned* cnt2; CK(hipMalloc(&part2, wis::enc_attention_part_floats(B, T, H) * 4)); CK(hipMalloc(&cnt2, (size_t)B * H * cdiv(T, 128) * 4)); CK(hipMemset(cnt2, 0, (size_t)B * H * cdiv(T, 128) * 4));
+      const dim3 g2(2 * cdiv(T, 128), H, B);
+      timeit("shipped enc_attn_lazy_kernel<true> (split-key)", [&](f16* o) { hipLaunchKernelGGL((enc_attn_lazy_kernel<true>), g2, blk, 0, 0, qk, vt, o, T, Tpad, H, d, part2, cnt2); }, o_a, false);
+    }
     return 0;
   }
   timeit("shipped enc_attn_lazy_kernel<false>", [&](f16* o) { hipLaunchKernelGGL((enc_attn_lazy_kernel<false>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d, (float*)nullptr, (unsigned*)nullptr); }, o_ref, true);

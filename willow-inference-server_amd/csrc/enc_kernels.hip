@@ -1707,13 +1707,13 @@ void launch_scale_q_log2e(hipStream_t st, f16* qk, int64_t rows, int d) {
 }
 
 // part / counters: ENC_PART_FLOATS floats per workgroup and one zeroed counter per (utterance, head, query tile); given and with
-// at most 600 unsplit workgroups (one or two utterances) the key range is split over two workgroups
+// at most 256 unsplit workgroups (one utterance of large-v2; round 3 split up to 600) the key range is split over two workgroups
 size_t enc_attention_part_floats(int B, int T, int H) { return (size_t)B * H * cdiv(T, 128) * 2 * ENC_PART_FLOATS; }
 int launch_enc_attention(hipStream_t st, const f16* qk, const f16* vt, f16* out, int B, int T, int Tpad, int H, float* part, unsigned* counters, size_t part_cap) {
   if (Tpad < cdiv(T, AKT) * AKT || Tpad % 8) { set_error("enc_attention: Tpad=%d too small for T=%d", Tpad, T); return WIS_E_ARG; }
   static const int env = getenv("WIS_ENC_ATTN_SPLIT") ? atoi(getenv("WIS_ENC_ATTN_SPLIT")) : -1;      // tuning: 0 never, 1 whenever possible
   const int wgs = cdiv(T, 128) * H * B;
-  const bool split = part && counters && (size_t)wgs <= part_cap && cdiv(T, AKT) >= 4 && (env >= 0 ? env == 1 : wgs <= 600);      // never beyond the scratch it was given
+  const bool split = part && counters && (size_t)wgs <= part_cap && cdiv(T, AKT) >= 4 && (env >= 0 ? env == 1 : wgs <= 256);      // never beyond the scratch it was given; split only while the unsplit grid leaves CUs empty (r4, sustained launches of the lazy loop, large-v2: one utterance = 240 workgroups 24.4 us unsplit / 23.6 split; two = 480: 35.8 / 41.9; three 49.7 / 57.6)
   if (enc_attn_lazy()) {
     if (split) hipLaunchKernelGGL((enc_attn_lazy_kernel<true>), dim3(2 * cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
     else hipLaunchKernelGGL((enc_attn_lazy_kernel<false>), dim3(cdiv(T, 128), H, B), dim3(256), 0, st, qk, vt, out, T, Tpad, H, H * 64, part, counters);
