@@ -24,6 +24,9 @@
 // per SIMD therefore needs either the Q fragments out of registers (they do not fit in LDS beside four workgroups' K / V buffers:
 // 4 x (32 + 16) KiB > 160) or a hand-allocated loop; neither is a round-4 change.  (An earlier B = 8 run of this lab faulted: the
 // uniform-pointer macro sign-extended the low address half; fixed below.)
+// One utterance, where registers are free (W = 2: V^T fragments requested at the top of the tile, score halves allowed to overlap; 223
+// VGPRs): 23.8 us unsplit against 25.1 for the shipped unsplit loop and 23.6 for the shipped split-key form (3000 launches each) - the
+// serial chain gives back 5 %, not worth a third loop variant.
 // STAMPS of the shipped loop (lazy_prof below: one wave of a mid-grid workgroup, s_memtime ticks per 64-key tile; profiles/r04_attn_lab.txt):
 //                                           scores ready | weights done | P.V issued | next tile stored | barrier | tile
 //   one utterance, unsplit (ONE wave per SIMD)       508 |          408 |        533 |              168 |     119 | 1736
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
         pf[2 * t2 + s2][j] = pr[0]; pf[2 * t2 + s2][j + 1] = pr[1];                        \
         rs = __builtin_amdgcn_fdot2(pr, f16x2{(f16)1.f, (f16)1.f}, rs, false);             \
       }                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);      /* the halves do NOT overlap: 16 score registers, not 32 */ \
+    if (W > 2) __builtin_amdgcn_sched_barrier(0);      /* the halves do NOT overlap: 16 score registers, not 32 (W = 2: registers are free, let them overlap) */ \
   }
   // one key tile: the fast path; when its row sums leave the f16 range (or nothing is known yet: first tile) the reference is raised to
   // the tile's maximum and the fast path is simply run again, now relative to the new reference
@@ -143,6 +146,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
   {                                                                                        \
     const int kt = (KT); const bool first = (FIRST);                                       \
     f16x8 pf[4];                                                                           \
+    f16x8 vfa[2][4];      /* W = 2: the V^T fragments are requested at the top of the tile, their LDS latency under the scores and the softmax */ \
+    if (W == 2) { _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) _Pragma("unroll") for (int s = 0; s < 4; ++s) vfa[dt][s] = *reinterpret_cast<const f16x8*>(&SV[dt * 32 * 64 + fo[s]]); } \
     float rs = 0.f;                                                                        \
     bool slow = true;                                                                      \
     if (!first) { LAB_FAST(SK, MASK) slow = __any(!(rs < 32768.f)); }                            \
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
     l_run += rs;                                                                           \
     _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                     \
       f16x8 vf[4];                                                                         \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s) vf[s] = *reinterpret_cast<const f16x8*>(&SV[dt * 32 * 64 + fo[s]]); \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) vf[s] = W == 2 ? vfa[dt][s] : *reinterpret_cast<const f16x8*>(&SV[dt * 32 * 64 + fo[s]]); \
       _Pragma("unroll") for (int s = 0; s < 4; ++s) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s], pf[s], o[dt], 0, 0, 0); \
     }                                                                                      \
   }
@@ -477,6 +482,8 @@ int main(int argc, char** argv) {
   timeit("round-2 enc_attn_kernel<false>", [&](f16* o) { hipLaunchKernelGGL((enc_attn_kernel<false>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d, (float*)nullptr, (unsigned*)nullptr); }, o_a, false);
   timeit("attn4<splat, 3 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<true, 3>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_a, false);
   timeit("attn4<v_sub, 3 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<false, 3>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_b, false);
+  timeit("attn4<v_sub, 2 waves/SIMD> (DMA, V early)", [&](f16* o) { hipLaunchKernelGGL((attn4<false, 2>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_b, false);
+  timeit("attn4<splat, 2 waves/SIMD> (DMA, V early)", [&](f16* o) { hipLaunchKernelGGL((attn4<true, 2>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_b, false);
   timeit("attn4<splat, 4 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<true, 4>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_a, false);
   timeit("attn4<v_sub, 4 waves/SIMD> (DMA)", [&](f16* o) { hipLaunchKernelGGL((attn4<false, 4>), grid, blk, 0, 0, qk, vt, o, T, Tpad, H, d); }, o_b, false);
   // stamps of one wave of a mid-grid workgroup: unsplit form at this B, and the split form (what one and two utterances run)
