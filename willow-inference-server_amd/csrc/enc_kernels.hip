@@ -1480,7 +1480,9 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const f16* __restrict__ q
 //    would leave the f16 range - which the tile's own row sum shows (sum < 2^15 => every p < 2^15): no maxima in the common path;
 //  * the row sum is taken from the f16 pairs the P.V MFMA consumes, two keys per v_dot2c_f32_f16 (16 instructions, and l is the
 //    sum of exactly the weights that multiply V).
-// Common path per tile: 32 v_exp + 16 v_cvt_pk + 16 v_dot2c + one compare ~ 650 cycles.  A tile whose sum reaches 2^15 (or the
+// Common path per tile: 32 v_exp + 16 v_cvt_pk + 16 v_dot2c + one compare - 408 ticks by s_memtime stamps (tools/attn_lab.hip: the
+// exponential costs ~8 per wave instruction here, not the 16 the estimates above assume; a lone wave's whole tile takes 1736, 512 of
+// them on the matrix pipe: the loop is a serial chain per wave, and what it lacks at 158 VGPRs is a fourth wave per SIMD).  A tile whose sum reaches 2^15 (or the
 // first tile of a workgroup, where nothing is known) takes the slow path: scores recomputed, true maximum, reference raised,
 // accumulators rescaled - the textbook step, once or twice per workgroup instead of every tile.
 // a * b that hipcc's SLP pass cannot pair with its neighbour into v_pk_mul_f32 / v_pk_add_f32 (the packed-f32
