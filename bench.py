@@ -283,6 +283,38 @@ def rest_base_beam1(dev, clip_bytes, audio_ms):
             "p50_request_ms": round(p50(lat), 3), "x_realtime": round(audio_ms / p50(lat), 1)}
 
 
+def natural_eot(lib, a, weights, dev, pcm, beam, audio_ms, make_step, timed, last_timing, batch=8):
+    """The termination path every reference request takes (main.py:687-693 passes no max_length): the search ends on EOT by itself.
+    Seeded weights never prefer EOT, so a second replica carries the SAME weights with an EOT ramp on the learned decoder positions
+    (tests/eot_ramp.py: start 3, slope 1.2 - the torch-fp32 oracle ends this utterance after 17 decoder passes, the count of the S = 16
+    convention); nothing masked, nothing forced.  Reported next to the fixed-length call with the SAME number of decoder passes on the
+    same handle: what the host-side termination protocol costs (progress record in mapped host memory, two passes in the queue)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from eot_ramp import with_eot_ramp
+    from wis_hip import _lib, ctranslate2 as ct2, weights as W
+    wr = with_eot_ramp(weights, start=3, slope=1.2)
+    arena, index = W.build_arena(wr)
+    h = ct2.create_handle(a, arena, index, dev, max_batch=batch, max_beam=max(beam, 1))
+    del arena, wr
+    rows = {}
+    try:
+        for B in (1, batch):
+            st_nat, (_k, lens) = make_step(h, pcm, beam, B, 0, _lib.WIS_IN_PCM_DEV)
+            l_nat = timed(st_nat, 20 if B == 1 else 10, 3)
+            tm = last_timing(h)
+            ran, needed, n_tok = int(tm["decode_steps"]), int(tm["decode_steps_needed"]), int(lens[0])
+            st_fix, _k2 = make_step(h, pcm, beam, B, max(needed - 1, 1), _lib.WIS_IN_PCM_DEV)       # S + 1 passes = the passes the natural search needed
+            l_fix = timed(st_fix, 20 if B == 1 else 10, 3)
+            tf = last_timing(h)
+            rows[f"batch_{B}"] = {"natural_eot_p50_ms": round(p50(l_nat), 3), "fixed_length_same_passes_p50_ms": round(p50(l_fix), 3),
+                                  "natural_over_fixed": round(p50(l_nat) / p50(l_fix), 4), "x_realtime_natural": round(B * audio_ms / p50(l_nat), 1),
+                                  "tokens_returned": n_tok, "decoder_passes_needed": needed, "decoder_passes_enqueued": ran, "overrun_passes": ran - needed,
+                                  "decode_ms_natural (device clock, first beam step -> last utterance finished)": tm["decode_ms"], "decode_ms_fixed": tf["decode_ms"]}
+    finally:
+        lib.wis_model_destroy(h)
+    return {"workload": f"large-v2 beam {beam}, 3sec.flac, EOT-ramp weights (start 3, slope 1.2), fixed_new_tokens = 0: the search ends on EOT; queue depth 2", **rows}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +328,8 @@ def main():
                     help="decoder weight storage; the headline number is float16 (int8_float16 mirrors the reference's GPU default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--natural-eot", action="store_true", help="run the natural-EOT row even with --no-extras")
+    ap.add_argument("--no-natural-eot", action="store_true", help="skip the natural-EOT row (a second large-v2 replica on EOT-ramp weights)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configurations, the batch-8 line, the boundary variants and the REST load replay")
     ap.add_argument("--rest-clients", type=int, default=64)
     args = ap.parse_args()
@@ -564,6 +598,14 @@ def main():
             extra["streaming"] = streaming_bench(handle, a, dev, os.path.join(ROOT, "tests", "golden", "clips", "30sec.flac"))
         except Exception as e:
             extra["streaming"] = {"failed": repr(e)}
+
+    if rank == 0 and (extras or args.natural_eot) and not args.no_natural_eot and not dry and args.model == "large" and args.compute_type == "float16":
+        try:
+            if weights is None:
+                weights = W.synthetic_weights(args.model, seed=1234)
+            extra["natural_eot"] = natural_eot(lib, a, weights, dev, pcm, args.beam, audio_ms, make_step, timed, last_timing)
+        except Exception as e:
+            extra["natural_eot"] = {"failed": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

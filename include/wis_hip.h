@@ -145,7 +145,9 @@ typedef struct {
   int32_t suppress_default; /* CT2 suppress_tokens=[-1]: mask cfg.suppress_ids every step */
   int32_t fixed_new_tokens; /* measurement convention: EOT masked until this many
                                tokens were generated, then forced.  0 = off (product default) */
-  int32_t sync_every;       /* decode steps enqueued between host checks of the done flag; 0 => 4 */
+  int32_t queue_depth;      /* searches that end on EOT: decode steps kept enqueued beyond the last one the host has seen
+                               complete (the host polls a progress record the device writes to mapped host memory after every
+                               step - no stream round trip); 0 => 2: one step running, one queued, over-run <= 1 step */
 } wis_gen_opts_t;
 
 /* out_ids: [B][max_new] (max_new = resolved max_new_tokens), out_len: [B], out_score: [B]
@@ -194,8 +196,8 @@ int wis_debug_handoff(wis_model_t* m, int raise_flag, int* retries, int* spin_di
 /* ---- timing taps: wall/device ms of the stages of the LAST wis_generate on this handle */
 typedef struct {
   float logmel_ms, encoder_ms, crosskv_ms, prefill_ms, decode_ms, total_ms;
-  int32_t decode_steps;
-  int32_t reserved;
+  int32_t decode_steps;          /* decoder passes enqueued (the merged prefill + first step counts as one) */
+  int32_t decode_steps_needed;   /* passes after which every utterance had finished; decode_steps - this = over-run */
 } wis_timing_t;
 int wis_last_timing(const wis_model_t* m, wis_timing_t* t);
 

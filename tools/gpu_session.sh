@@ -7,6 +7,7 @@
 #   smoke           __graft_entry__.smoke()
 #   bench<N> [ENV=VAL ...]   bench.py at N utterances per device batch (no extras, no CPU baseline); extra words are
 #                   environment assignments for that run and become part of the output name
+#   eot             bench.py --natural-eot: the search that ends on EOT against the fixed-length call of the same number of passes
 #   benchfull       the default bench.py line (what the driver runs)
 #   prof<N> [ENV=VAL ...]   rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
 #   frag2 [iters]   tools/bin/frag2_lab in its three flag variants (as the library / -fno-slp-vectorize / accumulators in AGPRs): the two-n-tile
@@ -16,7 +17,7 @@
 #   dbgfrag2        tools/debug_frag2.py with WIS_FRAG_NB=2 (the round-3 reproducer of the two-tile kernel's wrong tiles) -> dbgfrag2.txt
 #   pmc <tag> "<COUNTER ...>" [batch]   one rocprofv3 --pmc pass of the eager bench (default 8 utterances) -> pmc_<tag>_b<batch>.txt (per kernel and grid: launches, mean per launch)
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${WIS_TAG:-r4}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
+TAG=${WIS_TAG:-r5}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
 R=$GRAFT_REPO_ROOT
 run_bench() {   # $1 = batch, rest = env assignments
   local B=$1; shift
@@ -47,6 +48,16 @@ while [ $# -gt 0 ]; do
     bench[0-9]*)
       B=${step#bench}; envs=(); while [ $# -gt 0 ] && [[ $1 == *=* ]]; do envs+=("$1"); shift; done
       run_bench "$B" "${envs[@]}" ;;
+    eot) timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-roofline --natural-eot > "$O/bench_eot.json" 2> "$O/bench_eot.err"
+      python - "$O/bench_eot.json" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    print("headline ms", d["p50_ms"]); print(json.dumps(d.get("natural_eot"), indent=1))
+except Exception as e:
+    print("bench output unreadable:", e)
+PY
+      ;;
     benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; tail -c 600 "$O/bench_default.json" ;;
     prof[0-9]*)
       B=${step#prof}; while [ $# -gt 0 ] && [[ $1 == *=* ]]; do export "$1"; B="$B"; PSUF="${PSUF}_${1//[^A-Za-z0-9=]/}"; shift; done

@@ -1,0 +1,105 @@
+"""Build-time lint over the gfx950 code objects of the library (willow-inference-server_amd/build.py runs it after every build).
+
+    python tools/isa_lint.py [--table] build/*.hip.o
+
+Rule: NO kernel that contains MFMA instructions and can run three or more waves per SIMD (<= 168 unified VGPRs) may contain
+packed-f32 VALU arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  Round 3/4 finding ("The two-tile
+kernel's corruption"): the two-n-tile skinny GEMM's 168-VGPR instantiation returned wrong LOW halves of v_pk_*_f32 results in
+lanes 48-63 in about half of its launches on every box it was tried on with hipcc's SLP-vectorised epilogue; the same source with
+scalar f32 arithmetic (same registers, same occupancy) and every two-waves-per-SIMD form are clean.  The static scan
+(tools/isa_hazard_scan.py) shows no MFMA-result -> packed-VALU register dependence in that kernel (the accumulators pass through
+LDS and a barrier first), so no ISA wait-state rule explains it; until it is understood the combination is kept out of the
+library by this check instead of by convention.
+
+The occupancy bound is the register bound only (LDS and workgroup size can only lower it): conservative."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get("WIS_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+PK = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+MAX_VGPR_3_WAVES = 168          # 512 unified VGPRs per SIMD lane, allocation granule 8: 3 x 168 = 504
+
+
+def code_object(path, tmp):
+    """device code object of a host object / shared library built by hipcc (None if it carries no gfx950 image)"""
+    fb = os.path.join(tmp, os.path.basename(path) + ".fatbin")
+    r = subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, path, os.devnull], capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(fb) or os.path.getsize(fb) == 0:
+        return None
+    co = fb + ".co"
+    r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb, "--targets=" + TARGET, "--output=" + co], capture_output=True, text=True)
+    return co if r.returncode == 0 and os.path.exists(co) else None
+
+
+def kernels(co):
+    """-> {kernel: dict(vgpr, agpr, mfma, pk, n_instr)}"""
+    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    meta, cur = {}, {}
+    for ln in notes.split("\n"):
+        m = re.match(r"\s*-?\s*\.(agpr_count|vgpr_count|name|private_segment_fixed_size):\s*(\S+)", ln)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if ln.lstrip().startswith("- ."):          # first key of a kernel record
+            cur = {}
+        cur[k] = v
+        if "name" in cur and "vgpr_count" in cur:
+            meta[cur["name"]] = {"vgpr": int(cur["vgpr_count"]), "agpr": int(cur.get("agpr_count", 0)), "scratch": int(cur.get("private_segment_fixed_size", 0))}
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    out, name = {}, None
+    for ln in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            name = m.group(1)
+            if name in meta:
+                out[name] = dict(meta[name], mfma=0, pk=0, n_instr=0)
+            else:
+                name = None
+            continue
+        if name is None:
+            continue
+        t = ln.strip()
+        if not t:
+            continue
+        out[name]["n_instr"] += 1
+        if t.startswith("v_mfma") or t.startswith("v_smfmac"):
+            out[name]["mfma"] += 1
+        elif PK.search(t):
+            out[name]["pk"] += 1
+    return out
+
+
+def lint(paths, table=False):
+    bad, rows = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        for p in paths:
+            co = code_object(p, tmp)
+            if co is None:
+                continue
+            for name, k in sorted(kernels(co).items()):
+                waves = min(8, 512 // (((k["vgpr"] + 7) // 8) * 8)) if k["vgpr"] else 8
+                rows.append((os.path.basename(p), name, k["vgpr"], waves, k["mfma"], k["pk"], k["scratch"]))
+                if k["mfma"] and k["pk"] and k["vgpr"] <= MAX_VGPR_3_WAVES:
+                    bad.append(rows[-1])
+    if table:
+        print(f"{'object':22s} {'VGPRs':>5s} {'waves/SIMD':>10s} {'MFMA':>6s} {'v_pk f32':>8s}  kernel")
+        for o, n, v, w, mf, pk, sc in rows:
+            if mf or pk or sc:
+                print(f"{o:22s} {v:5d} {w:10d} {mf:6d} {pk:8d}  {n}" + (f"  [scratch {sc} B]" if sc else ""))
+    return bad, rows
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    bad, rows = lint(args, table="--table" in sys.argv)
+    for o, n, v, w, mf, pk, sc in bad:
+        print(f"isa_lint: {o}: {n}: {mf} MFMAs and {pk} packed-f32 VALU instructions at {v} VGPRs ({w} waves per SIMD possible)", file=sys.stderr)
+    scratch = [r for r in rows if r[6]]
+    for o, n, v, w, mf, pk, sc in scratch:
+        print(f"isa_lint: {o}: {n}: {sc} bytes of scratch per lane", file=sys.stderr)
+    print(f"isa_lint: {len(rows)} kernels, {len(bad)} packed-f32 violations, {len(scratch)} kernels with scratch")
+    sys.exit(1 if bad or scratch else 0)

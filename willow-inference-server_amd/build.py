@@ -20,22 +20,26 @@ LIB = os.path.join(LIBDIR, "libwis_hip.so")
 HIP_SOURCES = ["logmel.hip", "enc_kernels.hip", "dec_kernels.hip", "model.hip"]
 C_SOURCES = ["audio_io.c"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join(ROOT, "include", "wis_hip.h")]
+EXPORTS = os.path.join(CSRC, "exports.map")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx90a+ unified register file) instead of AGPRs.  hipcc's default put
 # the encoder attention's score tiles in AGPRs and moved them with 64 v_accvgpr_write / v_accvgpr_read per key tile and wave
 # (zero-initialisation and hand-over to the softmax arithmetic, ~20 % of the loop's vector-ALU time); in VGPR form the first MFMA
 # of a tile takes the inline constant 0 as its C operand and the softmax reads the result registers directly.  No kernel spills.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
+             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
 C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
-# Per-source flags.  dec_kernels.hip is built WITHOUT SLP vectorisation: hipcc's SLP pass turns the skinny GEMMs' epilogue arithmetic
-# (adjacent scalar f32 adds / multiplies on float4 values) into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 /
-# v_pk_fma_f32), and the two-n-tile skinny GEMM's 3-waves-per-SIMD instantiation (168 VGPRs) returned WRONG low halves of those
-# packed results in lanes 48-63 on some MI355X chips of the pool (round 3's "features 12 and 14" corruption: 10 808 of 96 000
-# launches wrong on a failing chip with SLP, 0 of 240 000 without, same registers, same occupancy, same chip - tools/frag_stress.hip,
-# tools/frag2_lab.hip).  Scalar f32 code is also what the guide recommends beside MFMAs (packed f32 is "an
-# anti-lever" there); measured cost: none at 1 and 8 utterances (22.54 vs 22.55 ms and 36.50 vs 36.50 ms of decode).
-SOURCE_FLAGS = {"dec_kernels.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize, every HIP source: hipcc's SLP pass turns adjacent scalar f32 adds / multiplies (epilogue arithmetic on float4
+# values) into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), and the two-n-tile skinny GEMM's
+# 3-waves-per-SIMD instantiation (168 VGPRs) returned WRONG low halves of those packed results in lanes 48-63 in about half of its
+# launches on every box it was tried on (round 3's "features 12 and 14" corruption: 10 808 of 96 000 launches wrong with SLP, 0 of
+# 240 000 without, same registers, same occupancy, same chip - tools/frag_stress.hip, tools/frag2_lab.hip).
+# Scalar f32 code is also what the guide recommends beside MFMAs (packed f32 is "an anti-lever" there).  The flag alone does not
+# remove every packed op (sums on ext-vector types still lower to v_pk_add_f32: the encoder epilogues add component-wise, add4), so
+# the rule is ENFORCED on the built code objects: tools/isa_lint.py, run by build() below - no kernel with MFMAs that can run three
+# or more waves per SIMD may contain v_pk_{add,mul,fma}_f32, and no kernel may use scratch (a spill inside the 8-phase GEMM loop
+# would move its hand-counted vmcnt waits).
+SOURCE_FLAGS = {}
 
 
 def _digest(paths):
@@ -82,11 +86,31 @@ def build(force=False, verbose=True, variant=None, extra_flags=()):
                 f.write(dig)
         objs.append(obj)
     newest = max(os.path.getmtime(o) for o in objs)
+    newest = max(newest, os.path.getmtime(EXPORTS))
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
         if verbose:
             print("[build] linking", os.path.relpath(lib, ROOT), flush=True)
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS] + objs + ["-o", lib])
+    if not variant or os.environ.get("WIS_LINT_VARIANTS"):
+        lint_objects([o for o in objs if o.endswith(".hip.o")])
     return lib
+
+
+def lint_objects(objs):
+    """tools/isa_lint.py over the device code objects: fails the build on a packed-f32 / MFMA / >= 3 waves per SIMD kernel or on scratch use"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wis_isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, rows = mod.lint(objs)
+    scratch = [r for r in rows if r[6]]
+    if bad or scratch:
+        for o, n, v, w, mf, pk, sc in bad:
+            sys.stderr.write(f"[build] isa_lint: {o}: {n}: {mf} MFMAs + {pk} packed-f32 VALU instructions at {v} VGPRs ({w} waves per SIMD possible)\n")
+        for o, n, v, w, mf, pk, sc in scratch:
+            sys.stderr.write(f"[build] isa_lint: {o}: {n}: {sc} bytes of scratch per lane (register spill)\n")
+        raise RuntimeError(f"build failed: isa_lint ({len(bad)} packed-f32 violations, {len(scratch)} kernels with scratch)")
+    return len(rows)
 
 
 if __name__ == "__main__":

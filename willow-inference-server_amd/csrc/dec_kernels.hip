@@ -1694,6 +1694,32 @@ int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_al
 // trip; the pool lives in registers (<= 32 entries per thread), the n_cand selection rounds are wave arg-bests joined through a
 // double-buffered 4-entry LDS exchange (one barrier per round).
 // PSL = pool entries per thread: 16 covers beam <= 5 (5 x 64 x 10 = 3200 entries), 32 the largest beam (8 x 64 x 16)
+// End of a beam step for one workgroup (thread 0, after the workgroup's global writes are fenced): count it; the workgroup that
+// ends the step as the LAST of the grid publishes the step to the host-mapped progress block - one 8-byte system-scope release
+// store that the host polls between graph launches (model.hip generate_impl), so a search that ends on EOT is noticed without a
+// stream round trip.  Results of finished utterances were written to the same block (and fenced at system scope) before their
+// workgroup's count, so whoever reads "done = B" in the record finds them there.
+__device__ __forceinline__ void publish_step(const BeamState& bs) {
+  __threadfence();
+  const unsigned B = gridDim.x;
+  const unsigned n = atomicAdd(bs.tick, 1u) + 1u;
+  if (n % B != 0u) return;
+  __threadfence();
+  const unsigned steps = n / B;
+  const unsigned done = (unsigned)__hip_atomic_load(bs.all_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned gen = __hip_atomic_load(bs.tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned gu = bs.giveup ? (__hip_atomic_load(bs.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1u : 0u) : 0u;
+  const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+  if (steps == 1u) __hip_atomic_store(bs.host + HP_STAMP0, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(bs.host + HP_STAMP, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (done >= B && atomicCAS(bs.tick + 2, 0u, steps) == 0u) {
+    __hip_atomic_store(bs.host + HP_DONE_STEP, (unsigned long long)steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(bs.host + HP_DONE_STAMP, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const unsigned long long rec = ((unsigned long long)(gen & 0xFFFFu) << 48) | ((unsigned long long)(steps & 0xFFFFu) << 32) | ((unsigned long long)gu << 16) | (done & 0xFFFFu);
+  __hip_atomic_store(bs.host + HP_REC, rec, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int PSL>
 __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ st_max, const float* __restrict__ st_sum,
                                                         const float* __restrict__ st_val, const int* __restrict__ st_idx,
@@ -1735,7 +1761,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
   const int done_b = bs.done[b];
   const int step = bs.step_u[b];
   const int nh0 = bs.n_hyp[b];
-  if (done_b) return;
+  if (done_b) { if (tid == 0) publish_step(bs); return; }
 
   stamp(pf, 1);
 #pragma unroll
@@ -1856,12 +1882,17 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
       bs.out_len[b] = bs.hyp_len[b * cfg.max_hyp + best];
       bs.out_score[b] = bsc;
       bs.done[b] = 1;
-      atomicAdd(bs.all_done, 1);
+      hp_out_len(bs.host)[b] = bs.hyp_len[b * cfg.max_hyp + best];      // the host's copy of the result (fenced below, before the step is published)
+      hp_out_score(bs.host)[b] = bsc;
     }
     __syncthreads();
     const int best = cand_org[0], n = bs.hyp_len[b * cfg.max_hyp + best];
     const int* src = bs.hyp_tok + ((size_t)b * cfg.max_hyp + best) * cfg.max_new;
-    for (int t = tid; t < n; t += 256) bs.out_ids[(size_t)b * cfg.max_new + t] = src[t];
+    int* hids = hp_out_ids(bs.host) + (size_t)b * cfg.max_new;
+    for (int t = tid; t < n; t += 256) { const int v = src[t]; bs.out_ids[(size_t)b * cfg.max_new + t] = v; hids[t] = v; }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { atomicAdd(bs.all_done, 1); publish_step(bs); }
     return;
   }
   stamp(pf, 7);
@@ -1881,6 +1912,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     }
   }
   if (tid == 0) bs.step_u[b] = step + 1;
+  __syncthreads();
+  if (tid == 0) publish_step(bs);
   stamp(pf, 8);
 }
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,

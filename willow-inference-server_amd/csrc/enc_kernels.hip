@@ -847,7 +847,9 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   // 256 x 256: the 8-phase LDS-DMA kernel (WIS_GEMM_8P=0: the register-staged 2 x 4-wave tile, A/B tuning switch); it needs two k-tiles
   static const bool use_8p = !(getenv("WIS_GEMM_8P") && atoi(getenv("WIS_GEMM_8P")) == 0);
   const int nk_ = (p.klen > 0 ? p.klen : p.K) / BK;
-  if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) {
+  // (the run-time-flag functor keeps to the register-staged tile: beside the 8-phase loop's 128 accumulators its five operands spill, and a
+  // scratch access inside that loop would also move its hand-counted vmcnt waits)
+  if constexpr (Epi::USE_8P) if (bm == 256 && bn == 256 && use_8p && nk_ >= 2) {
     const int rc = launch_gemm_8p(st, p, epi);
     if (rc <= 0) return rc;
   }
@@ -861,6 +863,11 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
   else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
   return WIS_OK;
 }
+// f32x4 sums of the epilogues, component by component and pinned in VGPRs: `a + b` on the vector type compiles to v_pk_add_f32, which the
+// library keeps away from MFMA kernels that can run three waves per SIMD (tools/isa_lint.py)
+__device__ __forceinline__ float add_s(float a, float b) { return a + b; }
+__device__ __forceinline__ float add_p(float a, float b) { float t = a + b; asm("" : "+v"(t)); return t; }
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return f32x4{add_p(a[0], b[0]), add_s(a[1], b[1]), add_p(a[2], b[2]), add_s(a[3], b[3])}; }
 __device__ __forceinline__ f32x4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return f32x4{t.x, t.y, t.z, t.w}; }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void st4h(f16* p, f32x4 v) { f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; *reinterpret_cast<f16x4*>(p) = o; }
@@ -872,29 +879,29 @@ __device__ __forceinline__ f32x4 gelu4(f32x4 v) { return f32x4{gelu_erf(v[0]), g
 
 // generic runtime-flag epilogue (wis_op_gemm, FFN, out-proj)
 struct EpiGeneric {
-  static constexpr bool HAS_T = false, HAS_RES = false;
+  static constexpr bool USE_8P = false, HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   const float* bias; const float* resid; void* C; int N; int flags;  // 1 gelu, 2 resid, 4 out f32
   __device__ void operator()(int m, int n, f32x4 v) const {
-    if (bias) v += ld4(bias + n);
+    if (bias) v = add4(v, ld4(bias + n));
     if (flags & 1) v = gelu4(v);
     const size_t o = (size_t)m * N + n;
-    if (flags & 2) v += ld4(resid + o);
+    if (flags & 2) v = add4(v, ld4(resid + o));
     if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
   }
   // register-staged tiles (epilogue_32): bias and residual quads arrive in registers
   __device__ bool has_res() const { return (flags & 2) != 0; }
   __device__ f32x4 res4(int m, int n) const { return ld4(resid + (size_t)m * N + n); }
   __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const {
-    v += b;
+    v = add4(v, b);
     if (flags & 1) v = gelu4(v);
     const size_t o = (size_t)m * N + n;
     if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
   }
   __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
-    v += b;
+    v = add4(v, b);
     if (flags & 1) v = gelu4(v);
-    v += r;
+    v = add4(v, r);
     const size_t o = (size_t)m * N + n;
     if (flags & 4) st4(reinterpret_cast<float*>(C) + o, v); else st4h(reinterpret_cast<f16*>(C) + o, v);
   }
@@ -904,25 +911,42 @@ struct EpiGeneric {
   __device__ float bias1(int) const { return 0.f; }
   __device__ void fin_t(int, int, f32x4, float) const {}
   __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const {
-    a += ba; b += bb;
+    a = add4(a, ba); b = add4(b, bb);
     if (flags & 1) { a = gelu4(a); b = gelu4(b); }
     const size_t o = (size_t)m * N + n;
-    if (flags & 2) { a += ld4(resid + o); b += ld4(resid + o + 4); }
+    if (flags & 2) { a = add4(a, ld4(resid + o)); b = add4(b, ld4(resid + o + 4)); }
     if (flags & 4) { st4(reinterpret_cast<float*>(C) + o, a); st4(reinterpret_cast<float*>(C) + o + 4, b); } else st8h(reinterpret_cast<f16*>(C) + o, a, b);
   }
   // 8 consecutive features of one row (the 8-phase kernel: n % 8 == 0): f16 outputs leave as ONE 16-byte store
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const {
-    if (bias) { a += ld4(bias + n); b += ld4(bias + n + 4); }
+    if (bias) { a = add4(a, ld4(bias + n)); b = add4(b, ld4(bias + n + 4)); }
     if (flags & 1) { a = gelu4(a); b = gelu4(b); }
     const size_t o = (size_t)m * N + n;
-    if (flags & 2) { a += ld4(resid + o); b += ld4(resid + o + 4); }
+    if (flags & 2) { a = add4(a, ld4(resid + o)); b = add4(b, ld4(resid + o + 4)); }
     if (flags & 4) { st4(reinterpret_cast<float*>(C) + o, a); st4(reinterpret_cast<float*>(C) + o + 4, b); } else st8h(reinterpret_cast<f16*>(C) + o, a, b);
   }
+};
+// bias + GELU -> f16 rows (the encoder's FFN1 on every tile shape): the generic functor without its run-time flags, residual and fp32
+// output - three pointers and two words fewer to keep alive across the k-loop of the 256-register kernels
+struct EpiGelu {
+  static constexpr bool USE_8P = true, HAS_T = false, HAS_RES = false;
+  __device__ void store_t(int, int, f32x4) const {}
+  __device__ void fin_t(int, int, f32x4, float) const {}
+  const float* bias; f16* C; int N;
+  __device__ void operator()(int m, int n, f32x4 v) const { st4h(C + (size_t)m * N + n, gelu4(add4(v, ld4(bias + n)))); }
+  __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { fin(m, n, a, b, ld4(bias + n), ld4(bias + n + 4)); }
+  __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
+  __device__ float bias1(int) const { return 0.f; }
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { st8h(C + (size_t)m * N + n, gelu4(add4(a, ba)), gelu4(add4(b, bb))); }
+  __device__ bool has_res() const { return false; }
+  __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const { st4h(C + (size_t)m * N + n, gelu4(add4(v, b))); }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
 };
 // bias + fp32 residual -> fp32 (out-projection, FFN2) for the 8-phase kernel: HAS_RES = the kernel requests the residual values of TWO
 // row blocks (res8) before it stores any of them (fin2) - four load rounds per tile instead of one load + wait per store
 struct EpiResid {
-  static constexpr bool HAS_T = false, HAS_RES = true;
+  static constexpr bool USE_8P = true, HAS_T = false, HAS_RES = true;
   const float* bias; const float* resid; float* C; int N;
   __device__ void store_t(int, int, f32x4) const {}
   __device__ void fin_t(int, int, f32x4, float) const {}
@@ -931,28 +955,28 @@ struct EpiResid {
   __device__ void res8(int m, int n, f32x4& ra, f32x4& rb) const { const size_t o = (size_t)m * N + n; ra = ld4(resid + o); rb = ld4(resid + o + 4); }
   __device__ void fin2(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb, f32x4 ra, f32x4 rb) const {
     const size_t o = (size_t)m * N + n;
-    st4(C + o, a + ba + ra); st4(C + o + 4, b + bb + rb);
+    st4(C + o, add4(add4(a, ba), ra)); st4(C + o + 4, add4(add4(b, bb), rb));
   }
   __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { f32x4 ra, rb; res8(m, n, ra, rb); fin2(m, n, a, b, ba, bb, ra, rb); }
   __device__ bool has_res() const { return true; }
   __device__ f32x4 res4(int m, int n) const { return ld4(resid + (size_t)m * N + n); }
-  __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const { st4(C + (size_t)m * N + n, v + b + res4(m, n)); }
-  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const { st4(C + (size_t)m * N + n, v + b + r); }
-  __device__ void operator()(int m, int n, f32x4 v) const { const size_t o = (size_t)m * N + n; st4(C + o, v + ld4(bias + n) + ld4(resid + o)); }
+  __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const { st4(C + (size_t)m * N + n, add4(add4(v, b), res4(m, n))); }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const { st4(C + (size_t)m * N + n, add4(add4(v, b), r)); }
+  __device__ void operator()(int m, int n, f32x4 v) const { const size_t o = (size_t)m * N + n; st4(C + o, add4(add4(v, ld4(bias + n)), ld4(resid + o))); }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { fin(m, n, a, b, bias4(n), bias4(n + 4)); }
 };
 // conv1: GELU(acc + b) -> f16 time-major padded image [B][T+2][N], row t+1
 struct EpiConv1 {
-  static constexpr bool HAS_T = false, HAS_RES = false;
+  static constexpr bool USE_8P = true, HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   const float* bias; f16* C; int N; int T;
   __device__ void operator()(int m, int n, f32x4 v) const {
-    v = gelu4(v + ld4(bias + n));
+    v = gelu4(add4(v, ld4(bias + n)));
     const int b = m / T, t = m - b * T;
     st4h(C + ((size_t)b * (T + 2) + t + 1) * N + n, v);
   }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 c) const {
-    a = gelu4(a + ld4(bias + n)); c = gelu4(c + ld4(bias + n + 4));
+    a = gelu4(add4(a, ld4(bias + n))); c = gelu4(add4(c, ld4(bias + n + 4)));
     const int b = m / T, t = m - b * T;
     st8h(C + ((size_t)b * (T + 2) + t + 1) * N + n, a, c);
   }
@@ -960,7 +984,7 @@ struct EpiConv1 {
   __device__ float bias1(int) const { return 0.f; }
   __device__ void fin_t(int, int, f32x4, float) const {}
   __device__ void fin(int m, int n, f32x4 a, f32x4 c, f32x4 ba, f32x4 bb) const {
-    a = gelu4(a + ba); c = gelu4(c + bb);
+    a = gelu4(add4(a, ba)); c = gelu4(add4(c, bb));
     const int b = m / T, t = m - b * T;
     st8h(C + ((size_t)b * (T + 2) + t + 1) * N + n, a, c);
   }
@@ -968,20 +992,20 @@ struct EpiConv1 {
   __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
   __device__ void fin4(int m, int n, f32x4 v, f32x4 bq) const {
-    v = gelu4(v + bq);
+    v = gelu4(add4(v, bq));
     const int b = m / T, t = m - b * T;
     st4h(C + ((size_t)b * (T + 2) + t + 1) * N + n, v);
   }
 };
 // conv2: GELU(acc + b) + pos[t] -> fp32 residual stream [B*T][N]
 struct EpiConv2 {
-  static constexpr bool HAS_T = false, HAS_RES = false;
+  static constexpr bool USE_8P = true, HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   const float* bias; const float* pos; float* X; int N; int T;
   __device__ void operator()(int m, int n, f32x4 v) const {
-    v = gelu4(v + ld4(bias + n));
+    v = gelu4(add4(v, ld4(bias + n)));
     const int t = m % T;
-    v += ld4(pos + (size_t)t * N + n);
+    v = add4(v, ld4(pos + (size_t)t * N + n));
     st4(X + (size_t)m * N + n, v);
   }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const { (*this)(m, n, a); (*this)(m, n + 4, b); }
@@ -990,20 +1014,20 @@ struct EpiConv2 {
   __device__ void fin_t(int, int, f32x4, float) const {}
   __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const {
     const int t = m % T;
-    a = gelu4(a + ba) + ld4(pos + (size_t)t * N + n); b = gelu4(b + bb) + ld4(pos + (size_t)t * N + n + 4);
+    a = add4(gelu4(add4(a, ba)), ld4(pos + (size_t)t * N + n)); b = add4(gelu4(add4(b, bb)), ld4(pos + (size_t)t * N + n + 4));
     st4(X + (size_t)m * N + n, a); st4(X + (size_t)m * N + n + 4, b);
   }
   // (the positional rows play the residual's part: one quad per (row, column quad))
   __device__ bool has_res() const { return true; }
   __device__ f32x4 res4(int m, int n) const { return ld4(pos + (size_t)(m % T) * N + n); }
   __device__ void fin4(int m, int n, f32x4 v, f32x4 b) const { fin4r(m, n, v, b, res4(m, n)); }
-  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const { st4(X + (size_t)m * N + n, gelu4(v + b) + r); }
+  __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4 r) const { st4(X + (size_t)m * N + n, add4(gelu4(add4(v, b)), r)); }
 };
 // fused QKV: [Q*s | K] -> f16 [M][2d]; V -> V^T f16 [B][H][64][Tpad]
 struct EpiQKV {
   // V tiles of the 8-phase kernel run their MFMAs with the operands swapped (D transposed): a lane then holds 4 CONSECUTIVE rows (keys) of
   // one feature, i.e. 8 contiguous bytes of the transposed V image instead of four scattered 2-byte stores
-  static constexpr bool HAS_T = true, HAS_RES = false;
+  static constexpr bool USE_8P = true, HAS_T = true, HAS_RES = false;
   void split(int N, GemmP* plain, GemmP* tr) const {      // [Q | K] = columns [0, 2d) plain, V = [2d, 3d) transposed
     plain->N = 2 * d; plain->n_span = 2 * d; plain->n_period = 0; plain->n_phase = 0;
     tr->N = N - 2 * d; tr->n_span = N - 2 * d; tr->n_period = 0; tr->n_phase = 2 * d;
@@ -1012,11 +1036,11 @@ struct EpiQKV {
     const float bv = bias[n];
     const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
     const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-    st4h(vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+    st4h(vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp, add4(v, f32x4{bv, bv, bv, bv}));
   }
   const float* bias; f16* qk; f16* vt; int d; int T; int Tpad; int H;
   __device__ void operator()(int m, int n, f32x4 v) const {
-    v += ld4(bias + n);
+    v = add4(v, ld4(bias + n));
     if (n < 2 * d) { st4h(qk + (size_t)m * 2 * d + n, v); return; }
     const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
     // keys are stored with bits 2 and 3 of their index swapped inside every group of 16: the 8 keys a lane of the attention
@@ -1029,16 +1053,16 @@ struct EpiQKV {
   }
   __device__ void operator()(int m, int n, f32x4 a, f32x4 b) const {
     // only reached for the Q | K tiles (the 8-phase kernel sends the V tiles through store_t)
-    a += ld4(bias + n); b += ld4(bias + n + 4); st8h(qk + (size_t)m * 2 * d + n, a, b);
+    a = add4(a, ld4(bias + n)); b = add4(b, ld4(bias + n + 4)); st8h(qk + (size_t)m * 2 * d + n, a, b);
   }
   __device__ f32x4 bias4(int n) const { return ld4(bias + n); }
   __device__ float bias1(int n) const { return bias[n]; }
-  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { st8h(qk + (size_t)m * 2 * d + n, a + ba, b + bb); }
+  __device__ void fin(int m, int n, f32x4 a, f32x4 b, f32x4 ba, f32x4 bb) const { st8h(qk + (size_t)m * 2 * d + n, add4(a, ba), add4(b, bb)); }
   __device__ bool has_res() const { return false; }
   __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
   __device__ void fin4(int m, int n, f32x4 v, f32x4 bq) const {
-    v += bq;
+    v = add4(v, bq);
     if (n < 2 * d) { st4h(qk + (size_t)m * 2 * d + n, v); return; }
     const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
     const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
@@ -1049,7 +1073,7 @@ struct EpiQKV {
   __device__ void fin_t(int m, int n, f32x4 v, float bv) const {
     const int nn = n - 2 * d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
     const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-    st4h(vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+    st4h(vt + ((size_t)(b * H + h) * 64 + dh) * Tpad + tp, add4(v, f32x4{bv, bv, bv, bv}));
   }
 };
 // cross-attention K/V projection of the encoder memory for ONE decoder layer:
@@ -1060,7 +1084,7 @@ struct EpiQKV {
 // 256-wide tile never straddles layers because 2d is a multiple of 256 for every Whisper size but tiny (768: multiple of 128
 // and of 256).
 struct EpiCrossKV {
-  static constexpr bool HAS_T = true, HAS_RES = false;
+  static constexpr bool USE_8P = true, HAS_T = true, HAS_RES = false;
   void split(int N, GemmP* plain, GemmP* tr) const {      // per layer: K = columns [0, d) plain, V = [d, 2d) transposed; N = layers x 2d
     plain->N = N / 2; plain->n_span = d; plain->n_period = 2 * d; plain->n_phase = 0;
     tr->N = N / 2; tr->n_span = d; tr->n_period = 2 * d; tr->n_phase = d;
@@ -1068,11 +1092,11 @@ struct EpiCrossKV {
   __device__ void store_t(int m, int n_all, f32x4 v) const {
     const float bv = bias[n_all];
     const int l = n_all / (2 * d), nn = n_all - l * 2 * d - d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
-    st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+    st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, add4(v, f32x4{bv, bv, bv, bv}));
   }
   const float* bias; f16* kx; f16* vt; int d; int T; int Tpad; int H; int64_t kx_lstride, vt_lstride;
   __device__ void operator()(int m, int n_all, f32x4 v) const {
-    v += ld4(bias + n_all);
+    v = add4(v, ld4(bias + n_all));
     const int l = n_all / (2 * d), n = n_all - l * 2 * d;
     f16* kx = this->kx + l * kx_lstride; f16* vt = this->vt + l * vt_lstride;
     const int b = m / T, t = m - b * T;
@@ -1089,7 +1113,7 @@ struct EpiCrossKV {
   __device__ void operator()(int m, int n_all, f32x4 a, f32x4 c) const {
     // only reached for the K tiles (the V tiles go through store_t): the 8 values are one (t, dh-group) cell of the K image - a single 16-byte store
     const int l = n_all / (2 * d), n = n_all - l * 2 * d;
-    a += ld4(bias + n_all); c += ld4(bias + n_all + 4);
+    a = add4(a, ld4(bias + n_all)); c = add4(c, ld4(bias + n_all + 4));
     const int b = m / T, t = m - b * T, h = n >> 6, g = (n & 63) >> 3;
     st8h(kx + l * kx_lstride + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8), a, c);
   }
@@ -1098,17 +1122,17 @@ struct EpiCrossKV {
   __device__ void fin(int m, int n_all, f32x4 a, f32x4 c, f32x4 ba, f32x4 bb) const {
     const int l = n_all / (2 * d), n = n_all - l * 2 * d;
     const int b = m / T, t = m - b * T, h = n >> 6, g = (n & 63) >> 3;
-    st8h(kx + l * kx_lstride + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8), a + ba, c + bb);
+    st8h(kx + l * kx_lstride + ((((size_t)(b * H + h) * 8 + g) * T + t) * 8), add4(a, ba), add4(c, bb));
   }
   __device__ void fin_t(int m, int n_all, f32x4 v, float bv) const {
     const int l = n_all / (2 * d), nn = n_all - l * 2 * d - d, h = nn >> 6, dh = nn & 63, b = m / T, t = m - b * T;
-    st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv});
+    st4h(vt + l * vt_lstride + ((size_t)(b * H + h) * 64 + dh) * Tpad + t, add4(v, f32x4{bv, bv, bv, bv}));
   }
   __device__ bool has_res() const { return false; }
   __device__ f32x4 res4(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   __device__ void fin4r(int m, int n, f32x4 v, f32x4 b, f32x4) const { fin4(m, n, v, b); }
   __device__ void fin4(int m, int n_all, f32x4 v, f32x4 bq) const {
-    v += bq;
+    v = add4(v, bq);
     const int l = n_all / (2 * d), n = n_all - l * 2 * d;
     f16* kx = this->kx + l * kx_lstride; f16* vt = this->vt + l * vt_lstride;
     const int b = m / T, t = m - b * T;
@@ -1126,7 +1150,7 @@ struct EpiCrossKV {
 
 // split-K partial tile: fp32 [blockIdx.z][M][N]
 struct EpiPartial {
-  static constexpr bool HAS_T = false, HAS_RES = false;
+  static constexpr bool USE_8P = true, HAS_T = false, HAS_RES = false;
   __device__ void store_t(int, int, f32x4) const {}
   float* C; int N; int64_t zstride;
   __device__ void operator()(int m, int n, f32x4 v) const { st4(C + (int64_t)blockIdx.z * zstride + (size_t)m * N + n, v); }
@@ -1241,6 +1265,7 @@ int launch_gemm_generic(hipStream_t st, const GemmP& p, const float* bias, const
     static const bool use_res = !(getenv("WIS_GEMM_RESID") && atoi(getenv("WIS_GEMM_RESID")) == 0);      // 0: the generic functor (A/B switch)
     if (use_res && use_8p && bm == 256 && bn == 256) { launch_8p_part<EpiResid, false>(st, p, EpiResid{bias, resid, reinterpret_cast<float*>(C), p.N}); return WIS_OK; }
   }
+  if (flags == 1 && bias) return launch_gemm_t(st, p, EpiGelu{bias, reinterpret_cast<f16*>(C), p.N});      // FFN1
   EpiGeneric e{bias, resid, C, p.N, flags};
   return launch_gemm_t(st, p, e);
 }

@@ -141,9 +141,26 @@ struct BeamState {
   float* hyp_score; // [B][max_hyp] raw cumulative score
   int* hyp_len;     // [B][max_hyp]
   int* hyp_tok;     // [B][max_hyp][max_new]
-  int* all_done;    // [1] (also mirrored to pinned host memory by the driver)
+  int* all_done;    // [1] utterances finished so far
   int* out_ids; int* out_len; float* out_score;   // final result [B][max_new], [B], [B]
+  // progress of the search, published to the host without a stream round trip (model.hip generate_impl's pacing loop):
+  unsigned* tick;                 // device [4]: {workgroups of beam_step_kernel that ended since init, call generation, step at which all_done reached B, -}
+  const unsigned* giveup;         // word 0 of the cross-attention hand-off's epoch block (a combiner's bounded spin ran out)
+  unsigned long long* host;       // device address of the HOST-mapped (fine-grained) progress block, layout HP_* below
 };
+// host-mapped progress block (uint64 words).  The workgroup of a beam step that ends LAST writes HP_REC with one system-scope
+// release store after everything else of the step - finished utterances' results included - has been made visible to the host.
+enum { HP_REC = 0,          // (generation << 48) | (steps completed << 32) | (give-up flag << 16) | utterances done
+       HP_STAMP0 = 1,       // 100 MHz constant clock at the end of the first beam step of the call (merged prefill + first step)
+       HP_STAMP = 2,        // ... at the end of the latest beam step
+       HP_DONE_STEP = 3,    // steps completed when the last utterance finished (0 until then)
+       HP_DONE_STAMP = 4,   // constant clock at that moment
+       HP_WORDS = 8,        // results follow: int out_len[HP_MAXB], float out_score[HP_MAXB], int out_ids[HP_MAXB][256]
+       HP_MAXB = MAX_ROWS };
+constexpr size_t HP_BYTES = HP_WORDS * 8 + (size_t)HP_MAXB * 8 + (size_t)HP_MAXB * 256 * 4;
+__host__ __device__ inline int* hp_out_len(unsigned long long* hp) { return reinterpret_cast<int*>(hp + HP_WORDS); }
+__host__ __device__ inline float* hp_out_score(unsigned long long* hp) { return reinterpret_cast<float*>(hp + HP_WORDS) + HP_MAXB; }
+__host__ __device__ inline int* hp_out_ids(unsigned long long* hp) { return reinterpret_cast<int*>(hp + HP_WORDS) + 2 * HP_MAXB; }
 // after a beam step: every live beam's KV rows (all layers, positions < P - 1 + step) become a copy of its parent's
 int launch_kv_reorder(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const BeamState& bs, int B, int beam, int P, int ctx, int d);
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -162,6 +163,8 @@ struct wis_model {
   float* d_in; int64_t* d_nsamp; float* d_probs;
   float* lm_logspec = nullptr; unsigned* lm_gmax = nullptr;   // log-mel scratch of THIS replica (never shared with other callers)
   int* h_pin;      // pinned host scratch
+  unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
+  unsigned gen = 0;                          // generation of the current search (records of an earlier call's over-run step are ignored)
   hipEvent_t ev[8];
   wis_timing_t timing;
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -498,6 +501,8 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.hyp_score, (size_t)Bm * max_hyp)); WIS_RET(dalloc(m, &m->bs.hyp_len, (size_t)Bm * max_hyp));
   WIS_RET(dalloc(m, &m->bs.hyp_tok, (size_t)Bm * max_hyp * max_new));
   WIS_RET(dalloc(m, &m->bs.all_done, 4));
+  WIS_RET(dalloc(m, &m->bs.tick, 4));
+  WIS_HIP_CHECK(hipMemsetAsync(m->bs.tick, 0, 16, m->st));
   WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
   WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_SUB)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_SUB));
   WIS_RET(dalloc(m, &m->st_val, (size_t)MAX_ROWS * STAT_SUB * MAX_CAND)); WIS_RET(dalloc(m, &m->st_idx, (size_t)MAX_ROWS * STAT_SUB * MAX_CAND));
@@ -508,6 +513,12 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->d_probs, (size_t)Bm * (c.n_lang > 0 ? c.n_lang : 1)));
   WIS_RET(dalloc(m, &m->d_prof, ((size_t)c.n_dec_layers * 8 + 2) * 16));   // + sampling kernels (tap builds)
   WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 65536, hipHostMallocDefault));
+  // fine-grained (coherent) host memory mapped into the device: beam_step_kernel's system-scope stores land here while the
+  // stream is still running
+  WIS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->h_prog), HP_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(m->h_prog, 0, HP_BYTES);
+  { void* dp = nullptr; WIS_HIP_CHECK(hipHostGetDevicePointer(&dp, m->h_prog, 0)); m->bs.host = static_cast<unsigned long long*>(dp); }
+  m->bs.giveup = m->ca_epoch;
   for (int i = 0; i < 8; ++i) WIS_HIP_CHECK(hipEventCreate(&m->ev[i]));
   return WIS_OK;
 }
@@ -603,6 +614,11 @@ static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
 // (160 combiners) takes the ticket form, one utterance per replica (20 combiners each) keeps the granules.  Whatever happens, a
 // spin that runs out never fails a request: the flag is read at every host poll, the handle switches to the ticket form for good and
 // the call is run again (wis_generate / wis_detect_language / the logits taps).
+static inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
 static std::atomic<int> g_live_handles[64];
 static bool spin_allowed(const wis_model* m, int B) {
   static const bool env_share = getenv("WIS_CA_SPIN_SHARED") != nullptr;      // test switch: ignore the census (exercises the shared-GPU hazard on purpose)
@@ -768,15 +784,19 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
 static int init_beam_state(wis_model* m, int B, int beam) {
   hipStream_t st = m->st;
   const int Mrows = B * beam;
-  std::vector<float> cum(Mrows);
+  // staged in pinned memory of its own (h_pin + 2048 ..): the copies run when the stream gets there, nothing waits for them here
+  float* cum = reinterpret_cast<float*>(m->h_pin + 2048);
   for (int r = 0; r < Mrows; ++r) cum[r] = (r % beam == 0) ? 0.f : -INFINITY;
-  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, st));
+  unsigned* tk = reinterpret_cast<unsigned*>(m->h_pin + 2048 + MAX_ROWS);
+  m->gen = (m->gen % 0xFFFFu) + 1u;      // 1 .. 65535: never the 0 of a cleared record
+  tk[0] = 0; tk[1] = m->gen; tk[2] = 0; tk[3] = 0;
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, cum, (size_t)Mrows * 4, hipMemcpyHostToDevice, st));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.tick, tk, 16, hipMemcpyHostToDevice, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.step_u, 0, (size_t)B * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.done, 0, (size_t)B * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.n_hyp, 0, (size_t)B * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.all_done, 0, 16, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.out_len, 0, (size_t)B * 4, st));
-  WIS_HIP_CHECK(hipStreamSynchronize(st));   // the host vector goes out of scope
   return WIS_OK;
 }
 // decoding options -> what the sampling kernels take (CTranslate2 4.1.0 BeamSearch defaults where WIS passes none, main.py:687-693)
@@ -797,7 +817,7 @@ static SampleCfg make_sample_cfg(const wis_model* m, const wis_gen_opts_t* o, in
   return sc;
 }
 
-int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot) {
+int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot, bool wait = true) {
   const size_t n = tok.size();
   int* h = m->h_pin + 1024;
   memcpy(h, tok.data(), n * 4); memcpy(h + MAX_ROWS, pos.data(), n * 4); memcpy(h + 2 * MAX_ROWS, slot.data(), n * 4); memcpy(h + 3 * MAX_ROWS, lslot.data(), n * 4);
@@ -805,8 +825,9 @@ int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int
   WIS_HIP_CHECK(hipMemcpyAsync(m->rm.pos, h + MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
   WIS_HIP_CHECK(hipMemcpyAsync(m->rm.slot, h + 2 * MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
   WIS_HIP_CHECK(hipMemcpyAsync(m->rm.lslot, h + 3 * MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
-  // the pinned staging area is reused by the next upload: make sure the copies are done
-  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  // the pinned staging area is reused by the next upload: make sure the copies are done (wis_generate uploads once per call and
+  // drains its stream before it returns or re-enters, so it does not wait here)
+  if (wait) WIS_HIP_CHECK(hipStreamSynchronize(m->st));
   return WIS_OK;
 }
 
@@ -906,6 +927,7 @@ void wis_model_destroy(wis_model_t* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_pin) hipHostFree(m->h_pin);
+  if (m->h_prog) hipHostFree(m->h_prog);
   for (int i = 0; i < 8; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
   if (m->st) hipStreamDestroy(m->st);
   delete m;
@@ -959,6 +981,23 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   const int ctx = c.n_text_ctx;
   auto t0 = std::chrono::steady_clock::now();
 
+  // ---- decode state first: search counters and the prompt rows depend on nothing the encoder produces, and staged from pinned
+  // memory they cost the host no wait - the whole chain log-mel -> encoder -> cross-K/V -> prefill is enqueued behind them in one go
+  // (the prefill's ~230 launches are issued while the encoder runs instead of after two stream drains)
+  const int Mrows = B * beam;
+  WIS_RET(init_beam_state(m, B, beam));
+  float patience;
+  const SampleCfg sc = make_sample_cfg(m, o, beam, max_new, &patience);
+  const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
+  {
+    std::vector<int> tok(B * P), pos(B * P), slot(B * P), ls(B * P);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) { tok[b * P + i] = prompt[b * P + i]; pos[b * P + i] = i; slot[b * P + i] = b * beam; ls[b * P + i] = b * beam; }
+    WIS_RET(upload_rows(m, tok, pos, slot, ls, false));
+  }
+  const unsigned long long gen = m->gen;
+  __atomic_store_n(&m->h_prog[HP_REC], 0ull, __ATOMIC_RELAXED);      // (a record of an earlier call's over-run step may still land here: it carries that call's generation)
+  m->h_prog[HP_DONE_STEP] = 0; m->h_prog[HP_DONE_STAMP] = 0; m->h_prog[HP_STAMP0] = 0;
+
   WIS_HIP_CHECK(hipEventRecord(m->ev[0], st));
   WIS_RET(stage_input(m, input, o->input_kind, B));
   WIS_HIP_CHECK(hipEventRecord(m->ev[1], st));
@@ -967,20 +1006,10 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   WIS_RET(run_cross_kv(m, B));
   WIS_HIP_CHECK(hipEventRecord(m->ev[3], st));
 
-  // ---- decode state
-  const int Mrows = B * beam;
-  WIS_RET(init_beam_state(m, B, beam));
-  float patience;
-  const SampleCfg sc = make_sample_cfg(m, o, beam, max_new, &patience);
-  const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
-
   // ---- prefill + FIRST decode step in one pass: all P prompt tokens of an utterance are rows (b, i) at positions i in the
   // utterance's first KV slot (causal by position); the logits of the last prompt row seed the beams (CT2 forwards
   // prompt[:-1] and then feeds prompt[-1] as the first decoder input — the same arithmetic, one weight pass instead of two)
   {
-    std::vector<int> tok(B * P), pos(B * P), slot(B * P), ls(B * P);
-    for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) { tok[b * P + i] = prompt[b * P + i]; pos[b * P + i] = i; slot[b * P + i] = b * beam; ls[b * P + i] = b * beam; }
-    WIS_RET(upload_rows(m, tok, pos, slot, ls));
     WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 + 16 : nullptr));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
@@ -1015,49 +1044,93 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
       m->graphs[key] = gexec;
     }
   }
-  int sync_every = o->sync_every > 0 ? o->sync_every : 4;
   int steps = 1;            // the first step ran with the prefill pass
-  int* h_done = m->h_pin;   // pinned
-  h_done[0] = 0; h_done[1] = 0;
+  int needed = 0;           // steps after which the last utterance had finished (natural termination)
+  bool gave_up = false, from_host = false;
+  float decode_ms_dev = -1.f;
   // with the measurement convention the step count is known: fixed_new tokens + the forced EOT
   const int known = (sc.fixed_new > 0) ? std::min(max_new, sc.fixed_new + 1) : 0;
   const int limit = known ? known : max_new;
-  for (;;) {
-    if (steps < limit) {
-      const int burst = known ? limit - steps : std::min(sync_every, limit - steps);
-      for (int i = 0; i < burst; ++i) {
-        if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
-      }
-      steps += burst;
-    }
-    WIS_HIP_CHECK(hipMemcpyAsync(h_done, m->bs.all_done, 4, hipMemcpyDeviceToHost, st));
-    WIS_HIP_CHECK(hipMemcpyAsync(h_done + 1, m->ca_epoch, 4, hipMemcpyDeviceToHost, st));      // (word 0 of the epoch block: the hand-off's give-up flag)
+  auto unpack = [&](unsigned long long r, int* st_, int* dn_, int* gu_) {
+    if ((r >> 48) != gen) { *st_ = 0; *dn_ = 0; *gu_ = 0; return; }
+    *st_ = (int)((r >> 32) & 0xFFFFu); *gu_ = (int)((r >> 16) & 0xFFFFu); *dn_ = (int)(r & 0xFFFFu);
+  };
+  if (known) {
+    // every step goes out in one burst: nothing to find out from the device before the last one
+    for (; steps < limit; ++steps) { if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step()); }
+    WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
     WIS_HIP_CHECK(hipStreamSynchronize(st));
-    if (*h_done >= B || steps >= limit || h_done[1]) break;      // (h_done[1]: a hand-off gave up - no point decoding on)
+    int st_, dn_, gu_; unpack(__atomic_load_n(&m->h_prog[HP_REC], __ATOMIC_ACQUIRE), &st_, &dn_, &gu_);
+    gave_up = gu_ != 0;
+    if (!gave_up && dn_ < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, dn_, B); return WIS_E_STATE; }
+    needed = steps;
+  } else {
+    // A search that ends on EOT (every real request: the reference passes no max_length, main.py:687-693).  The host keeps `depth`
+    // steps enqueued beyond the last one it has seen complete (one running, one waiting behind it: the device never idles between
+    // steps) and reads the search's progress from the host-mapped record beam_step_kernel writes at the end of every step - no
+    // stream drain, no copy.  When the record says every utterance has finished, at most depth - 1 further steps are in the queue;
+    // they run on finished utterances (every sampling workgroup returns at its `done` test, results stay as they are) and this
+    // call does not wait for them: the results are already in host memory, the next call on the handle queues behind them.
+    const int depth = o->queue_depth > 0 ? o->queue_depth : 2;
+    auto t_last = std::chrono::steady_clock::now();
+    int seen = -1, st_ = 0, dn_ = 0, gu_ = 0;
+    for (unsigned spins = 0;; ++spins) {
+      unpack(__atomic_load_n(&m->h_prog[HP_REC], __ATOMIC_ACQUIRE), &st_, &dn_, &gu_);
+      if (dn_ >= B || gu_) break;
+      if (st_ >= limit) break;                 // (cannot happen: the max_new-th step finishes every utterance)
+      if (steps < limit && steps - st_ < depth) {
+        if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
+        ++steps;
+        continue;
+      }
+      if (st_ != seen) { seen = st_; t_last = std::chrono::steady_clock::now(); spins = 0; }
+      else if ((spins & 1023u) == 1023u) {
+        const double idle = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count();
+        if (idle > 30.0) { set_error("decode made no progress for 30 s (step %d of %d enqueued)", st_, steps); return WIS_E_HIP; }
+        if (idle > 200e-6) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }      // long steps (big batches): stop burning the core
+      }
+      cpu_relax();
+    }
+    gave_up = gu_ != 0;
+    if (!gave_up && dn_ < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, dn_, B); return WIS_E_STATE; }
+    if (!gave_up) {
+      from_host = true;
+      needed = (int)m->h_prog[HP_DONE_STEP];
+      const unsigned long long s0 = m->h_prog[HP_STAMP0], s1 = m->h_prog[HP_DONE_STAMP];
+      decode_ms_dev = s1 > s0 ? (float)((double)(s1 - s0) * 1e-5) : 0.f;      // 100 MHz constant clock; from the end of the first beam step (ev[4] is one kv_reorder later)
+    }
   }
-  WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
   // the granule hand-off's give-up flag (a combiner's bounded spin ran out: another handle's chain held the CUs its producers needed).
   // Not an error for the caller: the handle keeps to the ticket hand-off from now on and the call is run again (wis_generate).
-  if (h_done[1]) {
+  if (gave_up) {
     WIS_HIP_CHECK(hipMemsetAsync(m->ca_epoch, 0, 4, st));
     WIS_HIP_CHECK(hipStreamSynchronize(st));
     m->spin_off = true; *retry = true; ++m->handoff_retries;
     fprintf(stderr, "[wis_hip] device %d: decoder cross-attention granule hand-off timed out; this handle uses the ticket hand-off from now on, the call is repeated\n", m->device);
     return WIS_OK;
   }
-  if (*h_done < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, *h_done, B); return WIS_E_STATE; }
-  // results
-  std::vector<int32_t> ids((size_t)B * 256);
-  WIS_HIP_CHECK(hipMemcpyAsync(ids.data(), m->bs.out_ids, (size_t)B * 256 * 4, hipMemcpyDeviceToHost, st));
-  WIS_HIP_CHECK(hipMemcpyAsync(out_len, m->bs.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  std::vector<float> sc_h(B);
-  WIS_HIP_CHECK(hipMemcpyAsync(sc_h.data(), m->bs.out_score, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  WIS_HIP_CHECK(hipStreamSynchronize(st));
-  // out_ids is [B][max_new] on device too (beam_step_kernel indexes by the resolved max_new; the ALLOCATION is [max_batch][256])
-  for (int b = 0; b < B; ++b) {
-    if (out_len[b] > max_new) out_len[b] = max_new;
-    for (int t = 0; t < max_new; ++t) out_ids[(size_t)b * max_new + t] = t < out_len[b] ? ids[(size_t)b * max_new + t] : 0;
-    if (out_score) out_score[b] = sc_h[b];
+  // results: out_ids is [B][max_new] (beam_step_kernel indexes by the resolved max_new; the allocations are [.][256])
+  if (from_host) {
+    const int* hl = hp_out_len(m->h_prog); const float* hs = hp_out_score(m->h_prog); const int* hi = hp_out_ids(m->h_prog);
+    for (int b = 0; b < B; ++b) {
+      int n = hl[b];
+      if (n < 0 || n > max_new) { set_error("decode result of utterance %d has length %d outside [0, %d]", b, n, max_new); return WIS_E_STATE; }
+      out_len[b] = n;
+      for (int t = 0; t < max_new; ++t) out_ids[(size_t)b * max_new + t] = t < n ? hi[(size_t)b * max_new + t] : 0;
+      if (out_score) out_score[b] = hs[b];
+    }
+  } else {
+    std::vector<int32_t> ids((size_t)B * 256);
+    WIS_HIP_CHECK(hipMemcpyAsync(ids.data(), m->bs.out_ids, (size_t)B * 256 * 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipMemcpyAsync(out_len, m->bs.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    std::vector<float> sc_h(B);
+    WIS_HIP_CHECK(hipMemcpyAsync(sc_h.data(), m->bs.out_score, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    WIS_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+      if (out_len[b] > max_new) out_len[b] = max_new;
+      for (int t = 0; t < max_new; ++t) out_ids[(size_t)b * max_new + t] = t < out_len[b] ? ids[(size_t)b * max_new + t] : 0;
+      if (out_score) out_score[b] = sc_h[b];
+    }
   }
   auto t1 = std::chrono::steady_clock::now();
   float ms;
@@ -1065,9 +1138,10 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   hipEventElapsedTime(&ms, m->ev[1], m->ev[2]); m->timing.encoder_ms = ms;
   hipEventElapsedTime(&ms, m->ev[2], m->ev[3]); m->timing.crosskv_ms = ms;
   hipEventElapsedTime(&ms, m->ev[3], m->ev[4]); m->timing.prefill_ms = ms;
-  hipEventElapsedTime(&ms, m->ev[4], m->ev[5]); m->timing.decode_ms = ms;
+  if (from_host) m->timing.decode_ms = decode_ms_dev; else { hipEventElapsedTime(&ms, m->ev[4], m->ev[5]); m->timing.decode_ms = ms; }
   m->timing.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  m->timing.decode_steps = steps;
+  m->timing.decode_steps = steps;             // steps enqueued (the merged prefill + first step included)
+  m->timing.decode_steps_needed = needed;     // steps after which every utterance had finished: steps - needed = over-run
   return WIS_OK;
 }
 

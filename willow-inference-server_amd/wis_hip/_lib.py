@@ -40,15 +40,15 @@ class Tensor(C.Structure):
 class GenOpts(C.Structure):
     _fields_ = [("input_kind", C.c_int32), ("beam_size", C.c_int32), ("max_new_tokens", C.c_int32), ("length_penalty", C.c_float),
                 ("patience", C.c_float), ("suppress_blank", C.c_int32), ("suppress_default", C.c_int32),
-                ("fixed_new_tokens", C.c_int32), ("sync_every", C.c_int32)]
+                ("fixed_new_tokens", C.c_int32), ("queue_depth", C.c_int32)]
 
 
 class Timing(C.Structure):
     _fields_ = [("logmel_ms", C.c_float), ("encoder_ms", C.c_float), ("crosskv_ms", C.c_float), ("prefill_ms", C.c_float),
-                ("decode_ms", C.c_float), ("total_ms", C.c_float), ("decode_steps", C.c_int32), ("reserved", C.c_int32)]
+                ("decode_ms", C.c_float), ("total_ms", C.c_float), ("decode_steps", C.c_int32), ("decode_steps_needed", C.c_int32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 # every symbol include/wis_hip.h declares: (name, restype, argtypes)
