@@ -48,12 +48,17 @@ while [ $# -gt 0 ]; do
     bench[0-9]*)
       B=${step#bench}; envs=(); while [ $# -gt 0 ] && [[ $1 == *=* ]]; do envs+=("$1"); shift; done
       run_bench "$B" "${envs[@]}" ;;
-    eot) timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-roofline --natural-eot > "$O/bench_eot.json" 2> "$O/bench_eot.err"
-      python - "$O/bench_eot.json" <<'PY'
+    eot)      # eot [ENV=VAL ...]: the natural-EOT row; extra words are environment assignments (part of the output name)
+      envs=(); name="bench_eot"; while [ $# -gt 0 ] && [[ $1 == *=* ]]; do envs+=("$1"); name="${name}_${1//[^A-Za-z0-9=]/}"; shift; done
+      env "${envs[@]}" timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-roofline --natural-eot > "$O/$name.json" 2> "$O/$name.err"
+      grep "eot-trace" "$O/$name.err" | tail -24
+      python - "$O/$name.json" <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-    print("headline ms", d["p50_ms"]); print(json.dumps(d.get("natural_eot"), indent=1))
+    print(sys.argv[1].split("/")[-1], "headline ms", d["p50_ms"])
+    for k, v in (d.get("natural_eot") or {}).items():
+        print("  ", k, v if not isinstance(v, dict) else {a: b for a, b in v.items() if a.split()[0] in ("natural_eot_p50_ms", "fixed_length_same_passes_p50_ms", "natural_over_fixed", "decoder_passes_needed", "decoder_passes_enqueued", "decode_ms_natural", "decode_ms_fixed")})
 except Exception as e:
     print("bench output unreadable:", e)
 PY

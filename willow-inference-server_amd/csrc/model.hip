@@ -156,7 +156,7 @@ struct wis_model {
   unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
   bool spin_off = false;        // sticky: a combiner's bounded spin ran out once on this handle - it keeps to the ticket hand-off from then on
   int handoff_retries = 0;      // calls repeated because a combiner's spin ran out (wis_debug_handoff: expected to stay 0)
-  bool spin_now = true;         // this call's decision (spin_allowed): dec_forward passes the granule buffers only when set
+  bool spin_now = true;         // this call's decision (SpinClaim): dec_forward passes the granule buffers only when set
   f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
@@ -166,6 +166,8 @@ struct wis_model {
   unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
   unsigned gen = 0;                          // generation of the current search (records of an earlier call's over-run step are ignored)
   hipEvent_t ev[8];
+  hipStream_t st_enc = nullptr;             // wis_generate's front half (log-mel, encoder) runs here: it overlaps the previous call's over-run decode step on `st`
+  hipEvent_t ev_enc = nullptr, ev_ckv = nullptr;      // encoder output ready (st_enc -> st); cross-K/V projection done reading it (st -> the next call's st_enc)
   wis_timing_t timing;
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph;
@@ -178,7 +180,6 @@ struct wis_model {
   bool prof_on; bool prof_all;
   size_t enc_part_cap = 0;      // (utterance, head, query tile) triples the split-key encoder attention buffers were sized for
   std::atomic_flag busy = ATOMIC_FLAG_INIT;   // one compute call at a time per handle (BusyGuard)
-  bool counted = false;         // this handle is in the per-device census (g_live_handles)
 };
 
 namespace {
@@ -520,12 +521,16 @@ int alloc_buffers(wis_model* m) {
   { void* dp = nullptr; WIS_HIP_CHECK(hipHostGetDevicePointer(&dp, m->h_prog, 0)); m->bs.host = static_cast<unsigned long long*>(dp); }
   m->bs.giveup = m->ca_epoch;
   for (int i = 0; i < 8; ++i) WIS_HIP_CHECK(hipEventCreate(&m->ev[i]));
+  WIS_HIP_CHECK(hipStreamCreateWithFlags(&m->st_enc, hipStreamNonBlocking));
+  WIS_HIP_CHECK(hipEventCreateWithFlags(&m->ev_enc, hipEventDisableTiming));
+  WIS_HIP_CHECK(hipEventCreateWithFlags(&m->ev_ckv, hipEventDisableTiming));
+  WIS_HIP_CHECK(hipEventRecord(m->ev_ckv, m->st));
   return WIS_OK;
 }
 
 // ---- input -> conv1 image --------------------------------------------------------------
-int stage_input(wis_model* m, const float* input, int kind, int B) {
-  hipStream_t st = m->st;
+int stage_input(wis_model* m, const float* input, int kind, int B, hipStream_t on = nullptr) {
+  hipStream_t st = on ? on : m->st;
   if (kind == WIS_IN_PCM_HOST || kind == WIS_IN_PCM_DEV) {
     const float* dp = input;
     if (kind == WIS_IN_PCM_HOST) {
@@ -548,8 +553,8 @@ int stage_input(wis_model* m, const float* input, int kind, int B) {
 }
 
 // ---- encoder + cross K/V ---------------------------------------------------------------
-int run_encoder(wis_model* m, int B) {
-  const wis_config_t& c = m->cfg; hipStream_t st = m->st;
+int run_encoder(wis_model* m, int B, hipStream_t on = nullptr) {
+  const wis_config_t& c = m->cfg; hipStream_t st = on ? on : m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, M = B * T;
   {  // conv1: implicit im2col over the [3002][96] image, K = 288 (+32 zero-weighted columns that read into the next row)
     GemmP p; p.klen = 0; p.A = m->img; p.a_bs = (int64_t)3002 * 96; p.a_rs = 96; p.a_rpb = 3000; p.W = m->w_conv1; p.M = B * 3000; p.N = d; p.K = 320;
@@ -608,24 +613,37 @@ static int launch_ln_gemv(wis_model* m, hipStream_t st, GemvP g) {
 }
 
 // ---- granule hand-off of the cross-attention: when it may be used -------------------------------
-// Its progress argument ("at most B*H <= CA_SPIN_MAX_BH combiners spin, fewer than the chip's CUs, so a producer always finds a slot") is
-// about ONE decode chain.  Several handles on a GPU (wis_model_clone replicas, other models) run their chains concurrently, so the
-// budget is divided by the number of live handles on the device: with the server's four replicas per GPU a batch of 8 utterances
-// (160 combiners) takes the ticket form, one utterance per replica (20 combiners each) keeps the granules.  Whatever happens, a
-// spin that runs out never fails a request: the flag is read at every host poll, the handle switches to the ticket form for good and
-// the call is run again (wis_generate / wis_detect_language / the logits taps).
+// Its progress argument ("at most CA_SPIN_MAX_BH combiners spin, fewer than the chip's CUs, so a producer always finds a slot") is about
+// everything that runs on the GPU at the same time, so the budget is kept per DEVICE and claimed per CALL: a call that wants the
+// granule form adds its B x heads combiners to the device's count for its duration and takes the ticket form when that would
+// exceed the budget.  (Until round 5 the budget was divided by the handles ALIVE on the device - a server holding several model
+// sizes at four replicas each never got the granule form although at most a few of its handles decode at any time, while bench.py,
+// with one handle, always did: the published decode numbers were for a path the server did not run.)  Whatever happens, a spin
+// that runs out never fails a request: the flag travels with every step's progress record / is read after every tap pass, the handle
+// switches to the ticket form for good and the call is run again (wis_generate / wis_detect_language / the logits taps).
 static inline void cpu_relax() {
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
   __builtin_ia32_pause();
 #endif
 }
-static std::atomic<int> g_live_handles[64];
-static bool spin_allowed(const wis_model* m, int B) {
-  static const bool env_share = getenv("WIS_CA_SPIN_SHARED") != nullptr;      // test switch: ignore the census (exercises the shared-GPU hazard on purpose)
-  if (m->spin_off) return false;
-  const int live = std::max(1, g_live_handles[m->device & 63].load(std::memory_order_relaxed));
-  return env_share || B * m->cfg.n_heads * live <= CA_SPIN_MAX_BH;
-}
+static std::atomic<int> g_spin_bh[64];
+struct SpinClaim {
+  wis_model* m; int n = 0;
+  SpinClaim(wis_model* mm, int B) : m(mm) {
+    static const bool env_share = getenv("WIS_CA_SPIN_SHARED") != nullptr;      // test switch: ignore the budget (exercises the shared-GPU hazard on purpose)
+    m->spin_now = false;
+    if (m->spin_off) return;
+    if (env_share) { m->spin_now = true; return; }
+    const int need = B * m->cfg.n_heads;
+    std::atomic<int>& a = g_spin_bh[m->device & 63];
+    int cur = a.load(std::memory_order_relaxed);
+    while (cur + need <= CA_SPIN_MAX_BH)
+      if (a.compare_exchange_weak(cur, cur + need, std::memory_order_relaxed)) { n = need; m->spin_now = true; return; }
+  }
+  ~SpinClaim() { if (n) g_spin_bh[m->device & 63].fetch_sub(n, std::memory_order_relaxed); }
+  SpinClaim(const SpinClaim&) = delete;
+  SpinClaim& operator=(const SpinClaim&) = delete;
+};
 // reads and clears the give-up flag (word 0 of the epoch block); true = a combiner gave up: results of the pass are garbage
 static int spin_gave_up(wis_model* m, bool* gave_up) {
   int* h = m->h_pin + 2;
@@ -808,13 +826,25 @@ static SampleCfg make_sample_cfg(const wis_model* m, const wis_gen_opts_t* o, in
   sc.length_penalty = o->length_penalty; sc.max_hyp = MAX_HYP;
   const float patience = o->patience > 0.f ? o->patience : 1.f;
   // hypotheses an utterance can hold: the search ends once max_candidates exist and one step adds at most `beam`, so
-  // max_candidates + beam - 1 slots never overflow; a patience beyond that is clamped (MAX_HYP = 3 MAX_R: patience <= 2 at any beam)
+  // max_candidates + beam - 1 slots never overflow (MAX_HYP = 3 MAX_R: patience <= 2 at any beam; check_patience refuses more)
   sc.max_candidates = (int)lroundf((float)beam * patience); if (sc.max_candidates < 1) sc.max_candidates = 1;
-  if (sc.max_candidates > sc.max_hyp - beam + 1) sc.max_candidates = sc.max_hyp - beam + 1;
   // CT2: allow_early_exit = patience == 1 && length_penalty == 0 && coverage_penalty == 0
   sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
   *patience_out = patience;
   return sc;
+}
+
+// A patience the hypothesis storage cannot honour is an argument error, not a silently shorter search (CTranslate2 would keep
+// searching until round(beam x patience) hypotheses exist and return different ids)
+static int check_patience(int beam, float patience) {
+  const float p = patience > 0.f ? patience : 1.f;
+  const long want = lroundf((float)beam * p);
+  if (want > MAX_HYP - beam + 1) {
+    set_error("patience %.3g at beam_size %d needs %ld finished hypotheses; the engine holds %d (patience <= %.3g at this beam)", (double)p, beam, want, MAX_HYP - beam + 1,
+              (double)(MAX_HYP - beam + 1) / (double)beam);
+    return WIS_E_ARG;
+  }
+  return WIS_OK;
 }
 
 int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot, bool wait = true) {
@@ -914,14 +944,12 @@ int wis_model_create(const wis_config_t* cfg, const void* arena, size_t arena_by
   } while (0);
   if (d_arena) hipFree(d_arena);
   if (rc) { wis_model_destroy(m); return rc; }
-  g_live_handles[device & 63].fetch_add(1, std::memory_order_relaxed); m->counted = true;
   *out = m;
   return WIS_OK;
 }
 
 void wis_model_destroy(wis_model_t* m) {
   if (!m) return;
-  if (m->counted) g_live_handles[m->device & 63].fetch_sub(1, std::memory_order_relaxed);
   hipSetDevice(m->device);
   if (m->st) hipStreamSynchronize(m->st);
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
@@ -929,6 +957,9 @@ void wis_model_destroy(wis_model_t* m) {
   if (m->h_pin) hipHostFree(m->h_pin);
   if (m->h_prog) hipHostFree(m->h_prog);
   for (int i = 0; i < 8; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
+  if (m->st_enc) { hipStreamSynchronize(m->st_enc); hipStreamDestroy(m->st_enc); }
+  if (m->ev_enc) hipEventDestroy(m->ev_enc);
+  if (m->ev_ckv) hipEventDestroy(m->ev_ckv);
   if (m->st) hipStreamDestroy(m->st);
   delete m;
 }
@@ -957,7 +988,6 @@ int wis_model_clone(wis_model_t* parent, wis_model_t** out) {
     if (hipStreamSynchronize(m->st) != hipSuccess) { set_error("clone init failed"); rc = WIS_E_HIP; break; }
   } while (0);
   if (rc) { wis_model_destroy(m); return rc; }
-  g_live_handles[m->device & 63].fetch_add(1, std::memory_order_relaxed); m->counted = true;
   *out = m;
   return WIS_OK;
 }
@@ -968,10 +998,11 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
                  const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score, bool* retry) {
   *retry = false;
   WIS_HIP_CHECK(hipSetDevice(m->device));
-  m->spin_now = spin_allowed(m, B);
+  SpinClaim claim(m, B);
   const wis_config_t& c = m->cfg;
   const int beam = o->beam_size < 1 ? 1 : o->beam_size;
   WIS_RET(check_batch(m, B, beam));
+  WIS_RET(check_patience(beam, o->patience));
   if (P < 1 || P > 16 || B * P > MAX_ROWS) { set_error("prompt length %d unsupported (1..16, B*P <= %d)", P, MAX_ROWS); return WIS_E_UNSUPPORTED; }
   int max_new = o->max_new_tokens > 0 ? o->max_new_tokens : std::min(c.n_text_ctx / 2, c.n_text_ctx - P);
   if (max_new > 256) max_new = 256;
@@ -998,13 +1029,22 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   __atomic_store_n(&m->h_prog[HP_REC], 0ull, __ATOMIC_RELAXED);      // (a record of an earlier call's over-run step may still land here: it carries that call's generation)
   m->h_prog[HP_DONE_STEP] = 0; m->h_prog[HP_DONE_STAMP] = 0; m->h_prog[HP_STAMP0] = 0;
 
-  WIS_HIP_CHECK(hipEventRecord(m->ev[0], st));
-  WIS_RET(stage_input(m, input, o->input_kind, B));
-  WIS_HIP_CHECK(hipEventRecord(m->ev[1], st));
-  WIS_RET(run_encoder(m, B));
-  WIS_HIP_CHECK(hipEventRecord(m->ev[2], st));
+  // Front half on a stream of its own.  A search that ended on EOT may have left ONE over-run decode step running on `st` (below): the
+  // log-mel and the encoder of this call touch none of the decoder's buffers, so they start at once beside it instead of behind it;
+  // the cross-K/V projection (which overwrites what that step still reads) and everything after it stay on `st`.  st_enc waits for the
+  // previous call's cross-K/V projection - the last reader of the encoder's output buffer.
+  static const bool one_stream = getenv("WIS_ONE_STREAM") != nullptr;      // A/B switch
+  hipStream_t se = one_stream ? st : m->st_enc;
+  if (se != st) WIS_HIP_CHECK(hipStreamWaitEvent(se, m->ev_ckv, 0));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[0], se));
+  WIS_RET(stage_input(m, input, o->input_kind, B, se));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[1], se));
+  WIS_RET(run_encoder(m, B, se));
+  WIS_HIP_CHECK(hipEventRecord(m->ev[2], se));
+  if (se != st) { WIS_HIP_CHECK(hipEventRecord(m->ev_enc, se)); WIS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_enc, 0)); }
   WIS_RET(run_cross_kv(m, B));
   WIS_HIP_CHECK(hipEventRecord(m->ev[3], st));
+  WIS_HIP_CHECK(hipEventRecord(m->ev_ckv, st));
 
   // ---- prefill + FIRST decode step in one pass: all P prompt tokens of an utterance are rows (b, i) at positions i in the
   // utterance's first KV slot (causal by position); the logits of the last prompt row seed the beams (CT2 forwards
@@ -1074,6 +1114,10 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     const int depth = o->queue_depth > 0 ? o->queue_depth : 2;
     auto t_last = std::chrono::steady_clock::now();
     int seen = -1, st_ = 0, dn_ = 0, gu_ = 0;
+    static const bool trace = getenv("WIS_EOT_TRACE") != nullptr;      // per-step record of the pacing loop on stderr (tuning)
+    struct Tr { int step; unsigned long long dev; double host_us; int launched; };
+    std::vector<Tr> tr;
+    const auto t_loop = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
       unpack(__atomic_load_n(&m->h_prog[HP_REC], __ATOMIC_ACQUIRE), &st_, &dn_, &gu_);
       if (dn_ >= B || gu_) break;
@@ -1083,13 +1127,22 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
         ++steps;
         continue;
       }
-      if (st_ != seen) { seen = st_; t_last = std::chrono::steady_clock::now(); spins = 0; }
+      if (st_ != seen) {
+        seen = st_; t_last = std::chrono::steady_clock::now(); spins = 0;
+        if (trace) tr.push_back({st_, m->h_prog[HP_STAMP], std::chrono::duration<double, std::micro>(t_last - t_loop).count(), steps});
+      }
       else if ((spins & 1023u) == 1023u) {
         const double idle = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count();
         if (idle > 30.0) { set_error("decode made no progress for 30 s (step %d of %d enqueued)", st_, steps); return WIS_E_HIP; }
         if (idle > 200e-6) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }      // long steps (big batches): stop burning the core
       }
       cpu_relax();
+    }
+    if (trace) {
+      for (size_t i = 0; i < tr.size(); ++i)
+        fprintf(stderr, "[eot-trace] step %d seen by the host at %.1f us (device clock +%.1f us since the previous record), %d steps enqueued\n", tr[i].step, tr[i].host_us,
+                i ? (double)(tr[i].dev - tr[i - 1].dev) * 0.01 : 0.0, tr[i].launched);
+      fprintf(stderr, "[eot-trace] done seen at %.1f us: %d of %d utterances, %d steps enqueued\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop).count(), dn_, B, steps);
     }
     gave_up = gu_ != 0;
     if (!gave_up && dn_ < B) { set_error("decode did not terminate within %d steps (done %d of %d)", steps, dn_, B); return WIS_E_STATE; }
@@ -1168,6 +1221,7 @@ int wis_debug_search(wis_model_t* m, const float* logits, int n_steps, int B, co
   const wis_config_t& c = m->cfg;
   const int beam = o->beam_size < 1 ? 1 : o->beam_size;
   WIS_RET(check_batch(m, B, beam));
+  WIS_RET(check_patience(beam, o->patience));
   const int max_new = o->max_new_tokens > 0 ? std::min(o->max_new_tokens, 256) : n_steps;
   if (max_new > n_steps) { set_error("wis_debug_search: %d steps of logits for max_new_tokens %d", n_steps, max_new); return WIS_E_ARG; }
   hipStream_t st = m->st;
@@ -1244,7 +1298,7 @@ int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int 
   WIS_RET(run_cross_kv(m, B));
   std::vector<int> tok(B, m->cfg.sot);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    m->spin_now = spin_allowed(m, B);
+    SpinClaim claim(m, B);
     WIS_RET(single_row_setup(m, B, tok, 0));
     WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
     WIS_RET(launch_lang_probs(m->st, m->logits, m->n_vocab_pad, m->d_lang_ids, m->cfg.n_lang, m->d_probs, B));
@@ -1283,7 +1337,7 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B, 
     std::vector<int> tok(B);
     for (int b = 0; b < B; ++b) tok[b] = dec_in[b * T + t];
     for (int attempt = 0; attempt < 2; ++attempt) {      // (a pass whose granule hand-off gave up is repeated in the ticket form)
-      m->spin_now = spin_allowed(m, B);
+      SpinClaim claim(m, B);
       WIS_RET(single_row_setup(m, B, tok, t));
       WIS_RET(dec_forward(m, B, 1, B, true, 1, 0));
       for (int b = 0; b < B; ++b)
@@ -1316,7 +1370,7 @@ int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, in
     for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i) { const int r = b * rows + i; tok[r] = dec_in[b * T + t0 + i]; pos[r] = t0 + i; slot[r] = b; ls[r] = b; }
     for (int r = 0; r < M; ++r) if (tok[r] < 0 || tok[r] >= V) { set_error("wis_debug_logits_rows: token %d out of range", tok[r]); return WIS_E_ARG; }
     for (int attempt = 0; attempt < 2; ++attempt) {      // (a pass whose granule hand-off gave up is repeated in the ticket form)
-      m->spin_now = spin_allowed(m, B);
+      SpinClaim claim(m, B);
       WIS_RET(upload_rows(m, tok, pos, slot, ls));
       WIS_RET(dec_forward(m, M, rows, B, true, 1, 0));
       for (int b = 0; b < B; ++b) for (int i = 0; i < rows; ++i)
@@ -1335,6 +1389,7 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
   WIS_ENTER(m, "wis_debug_phase_cycles")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, beam));
+  SpinClaim claim(m, B);      // the hand-off form wis_generate would take for this batch now (and not whatever the last call left behind)
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx;
   if (pos < 0 || pos >= ctx) { set_error("bad pos"); return WIS_E_ARG; }
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
@@ -1351,7 +1406,9 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
   static const int rows[6] = {0, 2, 4, 1, 6, 7};
   for (int i = 0; i < 6; ++i)
     WIS_HIP_CHECK(hipMemcpyAsync(out + i * 16, m->d_prof + rows[i] * 16, 16 * 8, hipMemcpyDeviceToHost, m->st));
-  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  bool gave_up = false;
+  WIS_RET(spin_gave_up(m, &gave_up));      // (synchronises the stream; a raised flag is consumed here, not by the next wis_generate)
+  if (gave_up) { set_error("wis_debug_phase_cycles: the granule hand-off gave up during the tap; stamps are not valid"); return WIS_E_STATE; }
   return WIS_OK;
 }
 
@@ -1369,6 +1426,7 @@ int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, 
   WIS_ENTER(m, "wis_debug_timeline")
   WIS_HIP_CHECK(hipSetDevice(m->device));
   WIS_RET(check_batch(m, B, beam));
+  SpinClaim claim(m, B);
   const int Mrows = B * beam, ctx = m->cfg.n_text_ctx, nk = m->cfg.n_dec_layers * 8;
   if (pos < 0 || pos >= ctx || n_out < nk) { set_error("wis_debug_timeline: bad pos / out size (need %d rows)", nk); return WIS_E_ARG; }
   WIS_HIP_CHECK(hipStreamSynchronize(m->st));
@@ -1399,6 +1457,7 @@ int wis_debug_timeline(wis_model_t* m, int B, int beam, int pos, int use_graph, 
   if (gx) hipGraphExecDestroy(gx);
   if (g) hipGraphDestroy(g);
   WIS_RET(rc);
+  { bool gave_up = false; WIS_RET(spin_gave_up(m, &gave_up)); if (gave_up) { set_error("wis_debug_timeline: the granule hand-off gave up during the tap"); return WIS_E_STATE; } }
   std::vector<unsigned long long> h((size_t)nk * 16);
   WIS_HIP_CHECK(hipMemcpy(h.data(), m->d_prof, h.size() * 8, hipMemcpyDeviceToHost));
   for (int k = 0; k < nk; ++k) { out[2 * k] = h[(size_t)k * 16 + 14]; out[2 * k + 1] = h[(size_t)k * 16 + 15]; }

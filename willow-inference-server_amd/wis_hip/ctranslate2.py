@@ -181,6 +181,15 @@ MAX_DECODER_ROWS = 96      # csrc/kernels.hpp MAX_ROWS: decoder rows per device 
 MAX_BEAM = 8               # csrc/kernels.hpp MAX_R: rows per utterance (beam size)
 MAX_REPLICAS_PER_DEVICE = 4   # default ceiling for inter_threads -> replicas per GPU (measured on MI355X, bench.py "concurrent_device_batches": 118 / 152 / 165 / 173 / 160 utterances/s with 1..5 batches of 8 in flight)
 MAX_PROMPT = 16            # wis_generate: prompt tokens per utterance
+MAX_HYPOTHESES = 24        # csrc/kernels.hpp MAX_HYP: finished hypotheses an utterance's search can hold
+
+
+def _check_patience(beam_size, patience):
+    """CTranslate2 searches until round(beam_size * patience) hypotheses have finished; the engine stores MAX_HYPOTHESES - beam_size + 1.
+    A patience beyond that is a request error (it used to be clamped silently: a shorter search than CTranslate2's, other ids)."""
+    p = float(patience) if float(patience) > 0 else 1.0
+    if int(round(int(beam_size) * p)) > MAX_HYPOTHESES - int(beam_size) + 1:
+        raise ValueError(f"patience {patience} at beam_size {beam_size} is beyond the engine's hypothesis storage (patience <= {(MAX_HYPOTHESES - int(beam_size) + 1) / int(beam_size):.3g} at this beam)")
 
 
 def _capacity(max_batch, key):
@@ -345,6 +354,7 @@ class Whisper:
             raise ValueError(f"beam_size {beam_size} outside 1..{self.max_beam} (setting max_beam; engine ceiling {MAX_BEAM})")
         if not 1 <= P <= MAX_PROMPT:
             raise ValueError(f"prompt length {P} outside 1..{MAX_PROMPT}")
+        _check_patience(beam_size, patience)
         max_new = min(max_length // 2, max_length - P)
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), list(suppress_tokens) == [-1],
                int(fixed_new_tokens), int(input_kind))
@@ -369,11 +379,12 @@ class Whisper:
     def generate_from_device(self, device, mel_device_ptr, prompt, *, beam_size=5, max_length=448, length_penalty=1, patience=1,
                              suppress_blank=True, fixed_new_tokens=0, replica=None):
         """One utterance whose log-mel features ALREADY live in HBM on `device` (f32 [80][3000] at `mel_device_ptr`, e.g. an
-        audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Goes through the micro-batcher
-        with that device's replica as its affinity: concurrent windows of several streaming sessions on the same GPU coalesce
-        into one device batch like REST requests do."""
-        # `replica`: the replica the caller holds (a streaming session pins itself to the least-loaded one, acquire_replica - its windows
-        # run THERE, so the sessions of a GPU spread over its replicas and the load accounting is charged where the work is done)
+        audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Goes through the micro-batcher bound
+        to that DEVICE: any replica of the GPU can read the features, so concurrent windows of several streaming sessions on one GPU
+        coalesce into one device batch like REST requests do, whatever replica each session holds (round 4 bound a window to the
+        session's own replica: sessions pinned to different replicas of a GPU never shared a batch)."""
+        # `replica`: the replica the caller holds (a streaming session pins itself to the least-loaded one, acquire_replica: the load
+        # accounting that spreads sessions over GPUs); it only has to live on the features' device
         r = replica if replica is not None else self.replica_on(device)
         if r.device != device:
             raise ValueError(f"replica lives on device {r.device}, the features on {device}")
@@ -383,7 +394,8 @@ class Whisper:
             raise ValueError(f"beam_size {beam_size} outside 1..{self.max_beam}")
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), True, int(fixed_new_tokens),
                int(_lib.WIS_IN_MEL_DEV))
-        return self._batcher.submit(key, [(int(mel_device_ptr), [int(t) for t in prompt])], affinity=r)[0]
+        _check_patience(beam_size, patience)
+        return self._batcher.submit(key, [(int(mel_device_ptr), [int(t) for t in prompt])], affinity=("device", device))[0]
 
     def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
         """One `wis_generate` call on replica r (the caller serialises access to r)."""

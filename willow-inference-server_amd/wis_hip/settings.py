@@ -49,12 +49,13 @@ class APISettings:
     # replicas per GPU sharing one weight copy, each with its own stream / activations / KV caches: `ctranslate2_threads` (the
     # reference's inter_threads) device batches run concurrently per GPU, up to this many
     replicas_per_gpu: int = 4
-    # largest beam_size a request may ask for; the engine's ceiling is 8 (csrc/kernels.hpp MAX_R) - a larger per-request beam_size
-    # is answered with HTTP 400, not a 500.  It sizes the self-attention KV caches of EVERY replica: max_batch * max_beam slots x
-    # 448 positions x d x 2 (K, V) x layers x 2 bytes = 73 MB per slot for large-v2, i.e. 2.9 GB per replica at 8 x 5 and
-    # 4.7 GB at 8 x 8 - times replicas_per_gpu (18.8 GB per large-v2 model and GPU with four replicas at 8 x 8).  5 covers the reference's own request surface (beam 1 default, 3 for long audio,
-    # `beam_size` up to 5 in the README's benchmarks); raise it for clients that ask for more.
-    max_beam: int = 5
+    # largest beam_size a request may ask for = the engine's ceiling, 8 (csrc/kernels.hpp MAX_R): the reference hands any `beam_size`
+    # query parameter to CTranslate2 as it is (main.py:1180-1209, 685-693), so clients that send 6..8 keep working; only a beam the
+    # engine cannot decode is answered with HTTP 400 (not a 500).  The setting sizes the self-attention KV caches of EVERY replica:
+    # max_batch * max_beam slots x 448 positions x d x 2 (K, V) x layers x 2 bytes = 73 MB per slot for large-v2, i.e. 4.7 GB per
+    # replica at 8 x 8 (2.9 GB at 8 x 5) - 18.8 GB per large-v2 model and GPU with four replicas, of 288 GB.  Lower it to save memory
+    # (the effective ceiling is logged when a model is loaded).
+    max_beam: int = 8
     # measurement convention for seeded synthetic weights, which never emit EOT: decode exactly this many tokens
     # (EOT masked until then, then forced).  0 = off: the product default, natural termination
     fixed_new_tokens: int = 0

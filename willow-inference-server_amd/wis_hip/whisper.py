@@ -108,12 +108,14 @@ class WhisperModels:
                                                 "loads WhisperProcessor from the model dir, main.py:329-334); set allow_token_id_text=1 to serve "
                                                 "token ids as text")
                     self.tokenizers[size] = tok
+                max_beam = min(max(int(self.settings.max_beam), int(self.settings.beam_size), int(self.settings.long_beam_size)), ctranslate2.MAX_BEAM)
                 self._models[size] = ctranslate2.models.Whisper(path, device="cuda", compute_type=self.settings.compute_type,
                                                                 inter_threads=self.settings.ctranslate2_threads,
                                                                 device_index=self.device_index, max_batch=self.settings.max_batch,
-                                                                replicas_per_device=self.settings.replicas_per_gpu,
-                                                                max_beam=min(max(int(self.settings.max_beam), int(self.settings.beam_size),
-                                                                                 int(self.settings.long_beam_size)), ctranslate2.MAX_BEAM))
+                                                                replicas_per_device=self.settings.replicas_per_gpu, max_beam=max_beam)
+                import logging
+                logging.getLogger("wis_hip").info("whisper %s loaded: beam_size 1..%d served (max_beam), device batches of up to %d utterances, %d replica(s)",
+                                                  size, max_beam, self.settings.max_batch, len(self._models[size]._replicas))
             return self._models[size]
 
     def tokenizer_for(self, size):
