@@ -159,6 +159,17 @@ typedef struct {
 int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
                  const wis_gen_opts_t* opts, int32_t* out_ids, int32_t* out_len, float* out_score);
 
+/* ---- 8(f)3, BASELINE configs[4]: the FINAL decode of a recording that was heard while it arrived (one utterance, beam_size 1 - the
+ * reference's default, settings.py:14).  `draft`: the token ids of an earlier hypothesis for (most of) the same audio, e.g. the last
+ * interim transcript of a streaming session.  The encoder runs on the final window as in wis_generate; the draft is then verified
+ * in teacher-forced passes of 16 positions (one decoder weight stream per 16 tokens instead of one per token), the longest prefix
+ * that greedy decoding of the FINAL window reproduces is kept, and ordinary greedy steps continue behind it.  The result is the
+ * greedy decode of the final window - what wis_generate returns for it (same kernels; the multi-row passes sum in a different
+ * order than the one-row step, so a decision closer than ~1e-3 in logit can fall differently, as between any two batch shapes).
+ * accepted: draft tokens kept (may be NULL).  n_draft == 0 is wis_generate. */
+int wis_generate_draft(wis_model_t* m, const float* input, const int32_t* prompt, int P, const wis_gen_opts_t* opts,
+                       const int32_t* draft, int n_draft, int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* accepted);
+
 /* ---- a14: language detection (replaces whisper_model.detect_language(features),
  * main.py:637-643): probabilities over cfg.lang_ids, [B][n_lang]. */
 int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int B, float* lang_probs);

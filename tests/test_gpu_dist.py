@@ -35,7 +35,7 @@ def _json_line(stdout):
 
 def test_bench_distributed_branch_on_one_gpu_matches_the_plain_run():
     args = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--model", "base", "--beam", "5", "--no-extras", "--no-cpu-baseline"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", WIS_BENCH_FORCE_BATCHED="1")      # (the N > 1 line's batched leg, on the one rank there is)
     env.pop("WIS_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
@@ -49,6 +49,11 @@ def test_bench_distributed_branch_on_one_gpu_matches_the_plain_run():
     print(f"torch.distributed.run (1 rank, nccl): {d['value']} x realtime, {d['ms_per_step']} ms/step | plain: {s['value']} x realtime, {s['ms_per_step']} ms/step")
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["steps"] == 6 and d["unit"] == s["unit"] and d["metric"] == s["metric"]
     assert d["roofline"] and d["roofline"]["achieved"] > 0
+    # the leg every N > 1 run adds (BASELINE configs[3]: 8 utterances per device batch per GPU); `value` stays the one-utterance figure
+    b = d["batched"]
+    print(f"  batched leg: {b['utterances_per_s']} utterances/s ({b['per_gpu']} per GPU), {b['ms_per_device_batch']} ms per device batch of 8")
+    assert b["per_gpu"] == b["utterances_per_s"] and b["utterances_per_s"] > 1e3 / d["ms_per_step"]      # a batch of 8 beats 8 serial utterances
+    assert "batched" not in s
     # the same work on the same GPU: the two clocks agree (generously: fresh-process clock state, 6 steps)
     assert 0.6 <= d["value"] / s["value"] <= 1.6, (d["value"], s["value"])
 

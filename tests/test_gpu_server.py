@@ -4,6 +4,8 @@ import asyncio
 import os
 import threading
 
+import time
+
 import numpy as np
 import pytest
 import torch  # noqa: F401  (before libwis_hip.so)
@@ -146,6 +148,47 @@ def test_streaming_session_equals_offline(golden_dir):
     assert sess.front_windows == 5        # every window (4 eager + the tail) was decoded from incrementally computed features
     with pytest.raises(RuntimeError):
         sess.feed(long_pcm[:10])
+
+
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_streaming_speculation_beam1_final_equals_offline(golden_dir, size):
+    """BASELINE configs[4] for a recording of up to 30 s (ONE window: its encoder needs the whole audio): while the audio arrives the
+    session decodes what it has heard every 2 s (beam 1); stop() verifies the last such hypothesis against the final window 16 tokens
+    per decoder pass (wis_generate_draft) and only decodes token by token behind the accepted prefix.  The answer must be the
+    offline do_whisper answer."""
+    from wis_hip import audio
+    from wis_hip.settings import APISettings
+    from wis_hip.streaming import StreamingSession
+    from wis_hip.whisper import WhisperModels, do_whisper
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.beam_size, s.long_beam_size = 1, 1          # beam 1 for every length (the reference's default long-audio beam is 3: a beam search has no single chain to verify)
+    s.stream_speculate_s = 2.0
+    models = WhisperModels(s, device_index=[0])
+    for clip, S in (("30sec", 48), ("10sec", 24)):
+        pcm, _ = audio.load_audio(os.path.join(golden_dir, "clips", clip + ".flac"))
+        off = do_whisper(pcm, size, 1, models=models, fixed_new_tokens=S)
+        sess = StreamingSession(size, 1, models=models, fixed_new_tokens=S)
+        for i in range(0, pcm.shape[0], 8000):
+            sess.feed((pcm[i:i + 8000] * 32768.0).astype("<i2").tobytes(), 2)
+            if sess._spec_job is not None:
+                sess._spec_job.result()           # real time: an interim decode (tens of ms) is long done before the next 2 s of audio exist
+        runs = sess.spec_runs
+        t0 = time.perf_counter()
+        fin = sess.stop()
+        dt = 1e3 * (time.perf_counter() - t0)
+        print(f"{size} {clip}: {runs} interim decodes while the audio arrived; stop() -> result {dt:.1f} ms (offline call {off[2]:.1f} ms), the final decode kept "
+              f"{sess.accepted_draft_tokens} of the last hypothesis' {S} tokens; identical to offline: {fin.tokens == off.tokens}")
+        assert runs >= pcm.shape[0] // (2 * 16000) - 1
+        assert sess.accepted_draft_tokens is not None
+        assert fin.tokens == off.tokens and fin[1] == off[1]
+        # speculation off: the same answer, no draft
+        sess = StreamingSession(size, 1, models=models, fixed_new_tokens=S, speculate_every_s=0)
+        for i in range(0, pcm.shape[0], 8000):
+            sess.feed(pcm[i:i + 8000])
+        fin0 = sess.stop()
+        assert fin0.tokens == off.tokens and sess.accepted_draft_tokens is None and sess.spec_runs == 0
+    models.get(size).close()
 
 
 def test_logmel_is_reentrant_across_threads(golden_dir):

@@ -72,15 +72,22 @@ static void md5_final(md5_t* m, uint8_t out[16]) {
 // ----------------------------------------------------------------------------------------
 // bit reader (MSB first)
 typedef struct { const uint8_t* p; size_t n; size_t pos; /* bit position */ int err; } br_t;
+// the next 57+ bits of the stream, left-aligned in a 64-bit word (bits past the end of the buffer read as zero; br_bits / br_unary
+// flag the overrun): one unaligned 8-byte load and a byte swap instead of a loop over single bits - the container decode is the
+// largest host-side cost of a short request (tools/host_ceiling.py)
+static inline uint64_t br_peek(const br_t* b) {
+  const size_t byte = b->pos >> 3;
+  uint64_t w;
+  if (byte + 8 <= b->n) { memcpy(&w, b->p + byte, 8); w = __builtin_bswap64(w); }
+  else { w = 0; for (size_t i = 0; i < 8; ++i) w = (w << 8) | (byte + i < b->n ? b->p[byte + i] : 0u); }
+  return w << (b->pos & 7);
+}
 static inline uint32_t br_bits(br_t* b, int n) {  // n in 0..32
-  uint64_t v = 0;
-  for (int i = 0; i < n; ++i) {
-    size_t byte = b->pos >> 3;
-    if (byte >= b->n) { b->err = 1; return 0; }
-    v = (v << 1) | ((b->p[byte] >> (7 - (b->pos & 7))) & 1u);
-    ++b->pos;
-  }
-  return (uint32_t)v;
+  if (n == 0) return 0;
+  if (b->pos + (size_t)n > b->n * 8) { b->err = 1; b->pos = b->n * 8; return 0; }
+  const uint32_t v = (uint32_t)(br_peek(b) >> (64 - n));
+  b->pos += (size_t)n;
+  return v;
 }
 static inline int32_t br_sbits(br_t* b, int n) {
   if (n == 0) return 0;
@@ -91,21 +98,36 @@ static inline int32_t br_sbits(br_t* b, int n) {
 static inline uint32_t br_unary(br_t* b) {  // count zeros before a one
   uint32_t q = 0;
   for (;;) {
-    size_t byte = b->pos >> 3;
-    if (byte >= b->n) { b->err = 1; return 0; }
-    int bit = (b->p[byte] >> (7 - (b->pos & 7))) & 1; ++b->pos;
-    if (bit) return q;
-    ++q;
+    if (b->pos >= b->n * 8) { b->err = 1; return 0; }
+    const uint64_t w = br_peek(b) | ((uint64_t)1 << 7);      // 57 valid bits per peek: a stop bit below them bounds the count
+    const int z = __builtin_clzll(w);
+    if (z < 56) {
+      if (b->pos + (size_t)z + 1 > b->n * 8) { b->err = 1; b->pos = b->n * 8; return 0; }
+      b->pos += (size_t)z + 1;
+      return q + (uint32_t)z;
+    }
+    q += 56; b->pos += 56;
+  }
+}
+// CRC-8 (poly 0x07) and CRC-16 (poly 0x8005) of the frame headers / frames, byte-wise by table
+static uint8_t CRC8_T[256];
+static uint16_t CRC16_T[256];
+__attribute__((constructor)) static void crc_tables(void) {
+  for (int i = 0; i < 256; ++i) {
+    uint8_t c = (uint8_t)i; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1));
+    CRC8_T[i] = c;
+    uint16_t d = (uint16_t)(i << 8); for (int k = 0; k < 8; ++k) d = (uint16_t)((d & 0x8000) ? (d << 1) ^ 0x8005 : (d << 1));
+    CRC16_T[i] = d;
   }
 }
 static uint8_t crc8(const uint8_t* p, size_t n) {
   uint8_t c = 0;
-  for (size_t i = 0; i < n; ++i) { c ^= p[i]; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1)); }
+  for (size_t i = 0; i < n; ++i) c = CRC8_T[c ^ p[i]];
   return c;
 }
 static uint16_t crc16(const uint8_t* p, size_t n) {
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) { c ^= (uint16_t)(p[i] << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1)); }
+  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ CRC16_T[(c >> 8) ^ p[i]]);
   return c;
 }
 

@@ -1687,6 +1687,28 @@ int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_al
   return WIS_OK;
 }
 
+// Greedy pick of teacher-forced rows (wis_generate_draft: the final decode of a streamed recording verifies the last interim hypothesis
+// in a few multi-row passes instead of one pass per token).  One wave per logits row over what logit_stats_kernel left for it: the
+// log-softmax normaliser from the 64 sub-chunk (max, sum-exp) pairs and the best candidate of the 64 sub-chunk winners, in
+// beam_step_kernel's arithmetic and order (score = logit - lse, ties to the lower token id) - the token beam_step would take at k = 1.
+__global__ __launch_bounds__(64) void greedy_pick_kernel(const float* __restrict__ st_max, const float* __restrict__ st_sum, const float* __restrict__ st_val,
+                                                         const int* __restrict__ st_idx, int n_cand, int V, int* __restrict__ tok_out, float* __restrict__ lp_out) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const float smx = st_max[m * STAT_SUB + lane], ssm = st_sum[m * STAT_SUB + lane];
+  const float v = st_val[((size_t)m * STAT_SUB + lane) * n_cand];
+  const int ix = st_idx[((size_t)m * STAT_SUB + lane) * n_cand];
+  const float M_ = wave_max(smx);
+  const float S = wave_sum(smx > -INFINITY ? ssm * __expf(smx - M_) : 0.f);
+  const float lse = M_ + logf(S);
+  const int tk = ix > V - 1 ? V - 1 : ix;
+  const u64 best = wave_max_key(sel_key(v > -INFINITY ? v - lse : -INFINITY, tk));
+  if (lane == 0) { tok_out[m] = key_index(best); lp_out[m] = key_value(best); }
+}
+int launch_greedy_pick(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx, int rows, const SampleCfg& cfg, int* tok_out, float* lp_out) {
+  hipLaunchKernelGGL(greedy_pick_kernel, dim3(rows), dim3(64), 0, st, st_max, st_sum, st_val, st_idx, cfg.n_cand, cfg.n_vocab, tok_out, lp_out);
+  return WIS_OK;
+}
+
 // =======================================================================================
 // beam search bookkeeping (CTranslate2 4.1.0 BeamSearch::search semantics).  grid B, block 256 (four waves per
 // utterance).  Everything the step needs from memory - the candidate pool (k rows x 64 sub-chunks x n_cand), the row statistics,

@@ -165,6 +165,8 @@ __host__ __device__ inline int* hp_out_ids(unsigned long long* hp) { return rein
 int launch_kv_reorder(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const BeamState& bs, int B, int beam, int P, int ctx, int d);
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof = nullptr);
+// teacher-forced rows: the token a k = 1 beam step would take from each row's statistics, and its log-probability
+int launch_greedy_pick(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx, int rows, const SampleCfg& cfg, int* tok_out, float* lp_out);
 // language detection: softmax over lang_ids of the row's logits
 int launch_lang_probs(hipStream_t st, const float* logits, int ld, const int* lang_ids, int n_lang, float* probs, int B);
 

@@ -161,6 +161,7 @@ struct wis_model {
   RowMeta rm; BeamState bs;
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
+  int* vstep = nullptr; int* pick_tok = nullptr; float* pick_lp = nullptr;      // wis_generate_draft: per-row step index, picked token / log-probability of the teacher-forced rows
   float* lm_logspec = nullptr; unsigned* lm_gmax = nullptr;   // log-mel scratch of THIS replica (never shared with other callers)
   int* h_pin;      // pinned host scratch
   unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
@@ -503,6 +504,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.hyp_tok, (size_t)Bm * max_hyp * max_new));
   WIS_RET(dalloc(m, &m->bs.all_done, 4));
   WIS_RET(dalloc(m, &m->bs.tick, 4));
+  WIS_RET(dalloc(m, &m->vstep, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_lp, MAX_ROWS));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.tick, 0, 16, m->st));
   WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
   WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_SUB)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_SUB));
@@ -994,9 +996,12 @@ int wis_model_clone(wis_model_t* parent, wis_model_t** out) {
 
 }  // extern "C" (reopened below: the generate driver is a static helper)
 
+// draft / n_draft / accepted: wis_generate_draft (one utterance, beam 1): the tokens of an earlier hypothesis to verify first
 static int generate_impl(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
-                 const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score, bool* retry) {
+                 const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score, bool* retry,
+                 const int32_t* draft = nullptr, int n_draft = 0, int* accepted = nullptr) {
   *retry = false;
+  if (accepted) *accepted = 0;
   WIS_HIP_CHECK(hipSetDevice(m->device));
   SpinClaim claim(m, B);
   const wis_config_t& c = m->cfg;
@@ -1020,7 +1025,10 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   float patience;
   const SampleCfg sc = make_sample_cfg(m, o, beam, max_new, &patience);
   const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
-  {
+  const bool drafting = draft != nullptr && n_draft > 0;
+  if (drafting && (B != 1 || beam != 1)) { set_error("wis_generate_draft: one utterance, beam_size 1 (got B = %d, beam_size %d)", B, beam); return WIS_E_UNSUPPORTED; }
+  if (drafting) for (int i = 0; i < n_draft; ++i) if (draft[i] < 0 || draft[i] >= c.n_vocab) { set_error("draft token %d out of range", draft[i]); return WIS_E_ARG; }
+  if (!drafting) {
     std::vector<int> tok(B * P), pos(B * P), slot(B * P), ls(B * P);
     for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) { tok[b * P + i] = prompt[b * P + i]; pos[b * P + i] = i; slot[b * P + i] = b * beam; ls[b * P + i] = b * beam; }
     WIS_RET(upload_rows(m, tok, pos, slot, ls, false));
@@ -1049,11 +1057,75 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   // ---- prefill + FIRST decode step in one pass: all P prompt tokens of an utterance are rows (b, i) at positions i in the
   // utterance's first KV slot (causal by position); the logits of the last prompt row seed the beams (CT2 forwards
   // prompt[:-1] and then feeds prompt[-1] as the first decoder input — the same arithmetic, one weight pass instead of two)
-  {
+  int steps = 1;            // decoder passes done: the first step runs with the prefill pass
+  bool spec_done = false;   // the draft verification already met the end of the utterance
+  std::vector<int> spec_gen; float spec_cum = 0.f; int spec_len = 0;
+  if (!drafting) {
     WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 + 16 : nullptr));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
+  } else {
+    // ---- verify the draft: the prompt and the draft tokens go through the decoder as teacher-forced rows, 16 positions per pass
+    // (causal by position inside the utterance's KV slot, like the merged prompt pass); row i's logits are what a greedy step fed
+    // seq[i] after seq[0..i-1] sees, so as long as every earlier draft token equalled the greedy pick, row P-1+g yields generated
+    // token g.  The first disagreement ends the verification WITH the right token for that index (its prefix was right); the K / V
+    // rows of the accepted prefix are in the cache, and the ordinary step loop continues from there.  Per pass one weight stream
+    // for up to 16 tokens instead of one per token.
+    const int nd = std::min(n_draft, max_new - 1);
+    std::vector<int> seq(P + nd);
+    for (int i = 0; i < P; ++i) seq[i] = prompt[i];
+    for (int i = 0; i < nd; ++i) seq[P + i] = draft[i];
+    const int R = 16;
+    bool stop = false; int n_acc = 0;
+    for (int t0 = 0; t0 < P + nd && !stop; t0 += R) {
+      const int rows = std::min(R, P + nd - t0);
+      const int f = std::max(P - 1 - t0, 0), nv = rows - f;      // rows f .. rows-1 of this pass predict generated tokens
+      std::vector<int> tok(rows), pos(rows), slot(rows, 0), ls(rows, 0);
+      for (int i = 0; i < rows; ++i) { tok[i] = seq[t0 + i]; pos[i] = t0 + i; }
+      WIS_RET(upload_rows(m, tok, pos, slot, ls));
+      WIS_RET(dec_forward(m, rows, rows, 1, nv > 0, 1, 0));
+      if (nv <= 0) continue;
+      int* hv = m->h_pin + 4096;
+      for (int i = 0; i < nv; ++i) hv[i] = t0 + f + i - (P - 1);      // the step index of each verified row (first-step / EOT masks of logit_stats_kernel)
+      WIS_HIP_CHECK(hipMemcpyAsync(m->vstep, hv, (size_t)nv * 4, hipMemcpyHostToDevice, st));
+      WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->vstep, m->st_max, m->st_sum, m->st_val, m->st_idx, nv, sc, 1, 0, f));
+      WIS_RET(launch_greedy_pick(st, m->st_max, m->st_sum, m->st_val, m->st_idx, nv, sc, m->pick_tok, m->pick_lp));
+      int* ht = m->h_pin + 4096 + MAX_ROWS; float* hl = reinterpret_cast<float*>(m->h_pin + 4096 + 2 * MAX_ROWS);
+      WIS_HIP_CHECK(hipMemcpyAsync(ht, m->pick_tok, (size_t)nv * 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(hl, m->pick_lp, (size_t)nv * 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipStreamSynchronize(st));
+      for (int i = 0; i < nv && !stop; ++i) {
+        const int g = hv[i];
+        spec_cum = hl[i] + spec_cum;                       // beam_step_kernel: (logit - lse) + cum
+        spec_gen.push_back(ht[i]);
+        const bool eos = ht[i] == c.eot, is_last = g + 1 >= max_new;
+        if (eos || is_last) { spec_done = true; spec_len = eos ? g : g + 1; stop = true; }
+        else if (g < nd && ht[i] == draft[g]) ++n_acc;
+        else stop = true;                                  // first disagreement (or the row behind the last draft token): ht[i] is generated token g
+      }
+    }
+    if (accepted) *accepted = n_acc;
+    steps = (int)spec_gen.size();
+    if (steps < 1) { set_error("wis_generate_draft: verification produced no token"); return WIS_E_STATE; }
+    if (!spec_done) {
+      // the search state a run of `steps` ordinary steps would have left: history, cumulative score, next input row, counters
+      int* hs = m->h_pin + 4096;
+      for (int t = 0; t < steps; ++t) hs[t] = spec_gen[t];
+      WIS_HIP_CHECK(hipMemcpyAsync(m->bs.alive, hs, (size_t)steps * 4, hipMemcpyHostToDevice, st));
+      int* hw = m->h_pin + 4096 + 512;
+      hw[0] = steps; hw[1] = spec_gen.back(); hw[2] = P - 1 + steps; hw[3] = 0;
+      memcpy(hw + 4, &spec_cum, 4);
+      WIS_HIP_CHECK(hipMemcpyAsync(m->bs.step_u, hw, 4, hipMemcpyHostToDevice, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(m->rm.tok, hw + 1, 4, hipMemcpyHostToDevice, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(m->rm.pos, hw + 2, 4, hipMemcpyHostToDevice, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(m->rm.slot, hw + 3, 4, hipMemcpyHostToDevice, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(m->rm.lslot, hw + 3, 4, hipMemcpyHostToDevice, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(m->bs.cum, hw + 4, 4, hipMemcpyHostToDevice, st));
+      unsigned* tk = reinterpret_cast<unsigned*>(hw + 8);
+      tk[0] = (unsigned)steps; tk[1] = m->gen; tk[2] = 0; tk[3] = 0;      // the progress record counts passes: `steps` of them are done
+      WIS_HIP_CHECK(hipMemcpyAsync(m->bs.tick, tk, 16, hipMemcpyHostToDevice, st));
+    }
   }
   WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
 
@@ -1084,7 +1156,6 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
       m->graphs[key] = gexec;
     }
   }
-  int steps = 1;            // the first step ran with the prefill pass
   int needed = 0;           // steps after which the last utterance had finished (natural termination)
   bool gave_up = false, from_host = false;
   float decode_ms_dev = -1.f;
@@ -1095,7 +1166,11 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     if ((r >> 48) != gen) { *st_ = 0; *dn_ = 0; *gu_ = 0; return; }
     *st_ = (int)((r >> 32) & 0xFFFFu); *gu_ = (int)((r >> 16) & 0xFFFFu); *dn_ = (int)(r & 0xFFFFu);
   };
-  if (known) {
+  const int base_done = drafting ? steps : 0;      // passes the draft verification stands for: done before the first progress record of this call
+  const auto t_dec0 = std::chrono::steady_clock::now();
+  if (spec_done) {
+    needed = steps;
+  } else if (known) {
     // every step goes out in one burst: nothing to find out from the device before the last one
     for (; steps < limit; ++steps) { if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step()); }
     WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
@@ -1120,11 +1195,14 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     const auto t_loop = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
       unpack(__atomic_load_n(&m->h_prog[HP_REC], __ATOMIC_ACQUIRE), &st_, &dn_, &gu_);
+      if (st_ < base_done) st_ = base_done;
       if (dn_ >= B || gu_) break;
       if (st_ >= limit) break;                 // (cannot happen: the max_new-th step finishes every utterance)
       if (steps < limit && steps - st_ < depth) {
+        const auto tl0 = std::chrono::steady_clock::now();
         if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
         ++steps;
+        if (trace) tr.push_back({-steps, 0ull, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count(), steps});      // (negative step: a launch, host_us = its duration)
         continue;
       }
       if (st_ != seen) {
@@ -1139,9 +1217,13 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
       cpu_relax();
     }
     if (trace) {
-      for (size_t i = 0; i < tr.size(); ++i)
+      unsigned long long prev_dev = 0;
+      for (size_t i = 0; i < tr.size(); ++i) {
+        if (tr[i].step < 0) { fprintf(stderr, "[eot-trace]   launch of step %d took the host %.1f us\n", -tr[i].step, tr[i].host_us); continue; }
         fprintf(stderr, "[eot-trace] step %d seen by the host at %.1f us (device clock +%.1f us since the previous record), %d steps enqueued\n", tr[i].step, tr[i].host_us,
-                i ? (double)(tr[i].dev - tr[i - 1].dev) * 0.01 : 0.0, tr[i].launched);
+                prev_dev ? (double)(tr[i].dev - prev_dev) * 0.01 : 0.0, tr[i].launched);
+        prev_dev = tr[i].dev;
+      }
       fprintf(stderr, "[eot-trace] done seen at %.1f us: %d of %d utterances, %d steps enqueued\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop).count(), dn_, B, steps);
     }
     gave_up = gu_ != 0;
@@ -1151,6 +1233,7 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
       needed = (int)m->h_prog[HP_DONE_STEP];
       const unsigned long long s0 = m->h_prog[HP_STAMP0], s1 = m->h_prog[HP_DONE_STAMP];
       decode_ms_dev = s1 > s0 ? (float)((double)(s1 - s0) * 1e-5) : 0.f;      // 100 MHz constant clock; from the end of the first beam step (ev[4] is one kv_reorder later)
+      if (drafting) decode_ms_dev = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_dec0).count();      // (no first beam step of its own: host clock)
     }
   }
   // the granule hand-off's give-up flag (a combiner's bounded spin ran out: another handle's chain held the CUs its producers needed).
@@ -1163,7 +1246,14 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     return WIS_OK;
   }
   // results: out_ids is [B][max_new] (beam_step_kernel indexes by the resolved max_new; the allocations are [.][256])
-  if (from_host) {
+  if (spec_done) {      // the verification rows already contained the end of the utterance: beam_step_kernel's finalisation, on the host
+    float sfin = spec_cum;
+    if (sc.length_penalty != 0.f) sfin /= powf((float)spec_len, sc.length_penalty);
+    out_len[0] = spec_len;
+    for (int t = 0; t < max_new; ++t) out_ids[t] = t < spec_len ? spec_gen[t] : 0;
+    if (out_score) out_score[0] = sfin;
+    from_host = true; decode_ms_dev = 0.f;
+  } else if (from_host) {
     const int* hl = hp_out_len(m->h_prog); const float* hs = hp_out_score(m->h_prog); const int* hi = hp_out_ids(m->h_prog);
     for (int b = 0; b < B; ++b) {
       int n = hl[b];
@@ -1210,6 +1300,21 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
     WIS_RET(generate_impl(m, input, B, prompt, P, o, out_ids, out_len, out_score, &retry));
     if (retry) { set_error("wis_generate: hand-off flag raised without the granule path"); return WIS_E_STATE; }
   }
+  return WIS_OK;
+}
+
+int wis_generate_draft(wis_model_t* m, const float* input, const int32_t* prompt, int P, const wis_gen_opts_t* o,
+                       const int32_t* draft, int n_draft, int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* accepted) {
+  if (!m || !input || !prompt || !o || !out_ids || !out_len || (n_draft > 0 && !draft) || n_draft < 0) { set_error("wis_generate_draft: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_generate_draft")
+  bool retry = false;
+  int acc = 0;
+  WIS_RET(generate_impl(m, input, 1, prompt, P, o, out_ids, out_len, out_score, &retry, draft, n_draft, &acc));
+  if (retry) {
+    WIS_RET(generate_impl(m, input, 1, prompt, P, o, out_ids, out_len, out_score, &retry, draft, n_draft, &acc));
+    if (retry) { set_error("wis_generate_draft: hand-off flag raised without the granule path"); return WIS_E_STATE; }
+  }
+  if (accepted) *accepted = acc;
   return WIS_OK;
 }
 

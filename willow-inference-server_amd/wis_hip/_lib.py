@@ -74,6 +74,8 @@ SYMBOLS = [
     ("wis_model_device_bytes", _sz, [_vp]),
     ("wis_model_clone", _i, [_vp, C.POINTER(_vp)]),
     ("wis_generate", _i, [_vp, _vp, _i, C.POINTER(C.c_int32), _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),
+    ("wis_generate_draft", _i, [_vp, _vp, C.POINTER(C.c_int32), _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp,
+                                C.POINTER(C.c_int32)]),
     ("wis_detect_language", _i, [_vp, _vp, _i, _i, _fp]),
     ("wis_debug_encode", _i, [_vp, _vp, _i, _i, _fp]),
     ("wis_debug_logits", _i, [_vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _fp]),

@@ -162,15 +162,25 @@ def create_replicas(a, arena, index, devices, max_batch=8, max_beam=5, **cfgkw):
     return handles
 
 
-def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=None):
-    """mel: host ndarray [B, ...] - or, with device_ptr, just the batch size B of features already resident on r.device."""
+def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=None, draft=None):
+    """mel: host ndarray [B, ...] - or, with device_ptr, just the batch size B of features already resident on r.device.
+    draft: token ids of an earlier hypothesis (one utterance, beam 1): wis_generate_draft verifies them before decoding on."""
     B = int(mel) if device_ptr is not None else mel.shape[0]
     o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
     pr = np.ascontiguousarray(np.asarray(prompts, np.int32).reshape(B, P))
     ids = np.zeros((B, max_new), np.int32)
     lens = np.zeros(B, np.int32)
     scores = np.zeros(B, np.float32)
-    _lib.check(_lib.load().wis_generate(r.handle, C.c_void_p(device_ptr) if device_ptr is not None else _lib.ptr(mel), B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
+    src = C.c_void_p(device_ptr) if device_ptr is not None else _lib.ptr(mel)
+    if draft:
+        d = np.ascontiguousarray(np.asarray(draft, np.int32))
+        acc = C.c_int32(0)
+        _lib.check(_lib.load().wis_generate_draft(r.handle, src, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o), d.ctypes.data_as(C.POINTER(C.c_int32)), int(d.shape[0]),
+                                                  ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)), scores.ctypes.data_as(C.POINTER(C.c_float)), C.byref(acc)))
+        res = WhisperGenerationResult([ids[0, :lens[0]].tolist()], [float(scores[0])])
+        res.accepted_draft_tokens = int(acc.value)
+        return [res]
+    _lib.check(_lib.load().wis_generate(r.handle, src, B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
                                         ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
                                         scores.ctypes.data_as(C.POINTER(C.c_float))))
     return [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
@@ -203,7 +213,8 @@ _MEL_BYTES = 80 * 3000 * 4
 
 
 def _run_batch(replica, key, rows):
-    P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind = key
+    P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind = key[:9]
+    draft = key[9] if len(key) > 9 else None          # (a drafted utterance has a key of its own: it never shares a device batch)
     prompts = [p for _, p in rows]
     if kind == _lib.WIS_IN_MEL_DEV:
         # features that already live in this replica's HBM (streaming sessions: audio.MelStream.finish): one utterance goes in
@@ -218,10 +229,12 @@ def _run_batch(replica, key, rows):
                 for i, (src, _) in enumerate(rows):
                     _lib.check(lib.wis_dev_copy_peer(replica.device, C.c_void_p(replica.stage.ptr.value + i * _MEL_BYTES), replica.device, C.c_void_p(int(src)), _MEL_BYTES))
                 ptr = replica.stage.ptr.value
-            return _generate_chunk(replica, len(rows), prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=ptr)
+            return _generate_chunk(replica, len(rows), prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=ptr,
+                                   draft=draft[1] if draft and len(rows) == 1 else None)
     mel = np.ascontiguousarray(np.stack([m for m, _ in rows]))
     with replica.lock:
-        return _generate_chunk(replica, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind)
+        return _generate_chunk(replica, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind,
+                               draft=draft[1] if draft and len(rows) == 1 else None)
 
 
 class Whisper:
@@ -339,7 +352,9 @@ class Whisper:
     def generate(self, features, prompts, *, asynchronous=False, beam_size=5, patience=1, num_hypotheses=1, length_penalty=1,
                  repetition_penalty=1, no_repeat_ngram_size=0, max_length=448, return_scores=False, return_no_speech_prob=False,
                  max_initial_timestamp_index=50, suppress_blank=True, suppress_tokens=(-1,), sampling_topk=1,
-                 sampling_temperature=1, fixed_new_tokens=0, input_kind=_lib.WIS_IN_MEL_HOST):
+                 sampling_temperature=1, fixed_new_tokens=0, input_kind=_lib.WIS_IN_MEL_HOST, draft_tokens=None):
+        """`draft_tokens` (one utterance, beam_size 1): the ids of an earlier hypothesis for this audio - wis_generate_draft verifies them in
+        multi-row passes and decodes on behind the accepted prefix; the result is the greedy decode of THESE features either way."""
         if num_hypotheses != 1 or repetition_penalty != 1 or no_repeat_ngram_size != 0 or sampling_topk != 1:
             raise NotImplementedError("only the decoding options WIS uses are implemented (defaults of CTranslate2 4.1.0)")
         mel = self._features(features, input_kind)
@@ -358,6 +373,8 @@ class Whisper:
         max_new = min(max_length // 2, max_length - P)
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), list(suppress_tokens) == [-1],
                int(fixed_new_tokens), int(input_kind))
+        if draft_tokens is not None and len(draft_tokens) and B == 1 and int(beam_size) == 1:
+            key = key + ((object(), tuple(int(t) for t in draft_tokens)),)
         rows = [(np.ascontiguousarray(mel[b]), [int(t) for t in prompts[b]]) for b in range(B)]
         return self._batcher.submit(key, rows)
 
@@ -377,7 +394,7 @@ class Whisper:
         raise ValueError(f"no replica on device {device}")
 
     def generate_from_device(self, device, mel_device_ptr, prompt, *, beam_size=5, max_length=448, length_penalty=1, patience=1,
-                             suppress_blank=True, fixed_new_tokens=0, replica=None):
+                             suppress_blank=True, fixed_new_tokens=0, replica=None, draft_tokens=None):
         """One utterance whose log-mel features ALREADY live in HBM on `device` (f32 [80][3000] at `mel_device_ptr`, e.g. an
         audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Goes through the micro-batcher bound
         to that DEVICE: any replica of the GPU can read the features, so concurrent windows of several streaming sessions on one GPU
@@ -395,6 +412,8 @@ class Whisper:
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), True, int(fixed_new_tokens),
                int(_lib.WIS_IN_MEL_DEV))
         _check_patience(beam_size, patience)
+        if draft_tokens is not None and len(draft_tokens) and int(beam_size) == 1:
+            key = key + ((object(), tuple(int(t) for t in draft_tokens)),)
         return self._batcher.submit(key, [(int(mel_device_ptr), [int(t) for t in prompt])], affinity=("device", device))[0]
 
     def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):

@@ -56,6 +56,11 @@ class APISettings:
     # replica at 8 x 8 (2.9 GB at 8 x 5) - 18.8 GB per large-v2 model and GPU with four replicas, of 288 GB.  Lower it to save memory
     # (the effective ceiling is logged when a model is loaded).
     max_beam: int = 8
+    # streaming sessions of up to 30 s (BASELINE configs[4]): while the audio arrives, decode what has been heard every this many seconds
+    # of new audio (beam 1 only - the default beam_size - and only when the language is known without detection); stop() then verifies
+    # the last such hypothesis against the FINAL window in multi-row passes (wis_generate_draft) instead of decoding token by token.
+    # 0 = off.  The answer is the greedy decode of the final window either way.
+    stream_speculate_s: float = 2.0
     # measurement convention for seeded synthetic weights, which never emit EOT: decode exactly this many tokens
     # (EOT masked until then, then forced).  0 = off: the product default, natural termination
     fixed_new_tokens: int = 0

@@ -77,7 +77,7 @@ class _IncrementalFront:
 
 class StreamingSession:
     def __init__(self, model, beam_size=None, task="transcribe", detect_language=False, force_language=None, models=None,
-                 fixed_new_tokens=0, incremental=True):
+                 fixed_new_tokens=0, incremental=True, speculate_every_s=None):
         self.models = models or default_models()
         s = self.models.settings
         self.model_name, self.task = model, task
@@ -93,6 +93,11 @@ class StreamingSession:
         self._windows = {}            # (start, length) -> Future[list[int]]   window token ids, computed eagerly
         self._language_job = None     # Future: language of the chunked recording (from window 0), resolved exactly once
         self._closed = False
+        # speculative interim decodes of a recording that is still short enough for ONE window (<= 30 s): see _maybe_speculate
+        self._spec_every = float(s.stream_speculate_s if speculate_every_s is None else speculate_every_s)
+        self._spec_n, self._spec_job, self._spec_latest = 0, None, None      # samples covered when the last one was scheduled; its Future; (samples, tokens)
+        self.spec_runs = 0            # interim decodes done while the audio arrived (stats / tests)
+        self.accepted_draft_tokens = None     # tokens of the last interim hypothesis the final decode kept (None: no draft was used)
         self.eager_windows = 0        # windows transcribed before stop() (stats / tests)
         self.front_windows = 0        # windows whose features came from the incremental front-end
         # the session's GPU: the least-loaded replica now, held (counted in its load) until close()
@@ -123,6 +128,7 @@ class StreamingSession:
             if front is not None:
                 front.feed(x, self.models.settings.support_chunking)
             self._schedule_complete_windows()
+            self._maybe_speculate()
 
     @property
     def buffered_ms(self):
@@ -147,7 +153,39 @@ class StreamingSession:
             raise ValueError(f"unsupported language {language!r}")
         return language
 
-    def _window_tokens(self, piece, beam, language, stream=None):
+    def _final_beam(self, n_samples):
+        s = self.models.settings
+        return s.long_beam_size if int(n_samples / audio.SAMPLE_RATE * 1000) >= s.long_beam_size_threshold else self.beam_size
+
+    def _maybe_speculate(self):
+        """Called with the lock held.  A recording of up to 30 s is ONE window whose encoder needs the whole audio, so nothing of the
+        FINAL answer can be computed early - but its decode, 80-95 % of the time to the answer, can be PREPARED: every `_spec_every`
+        seconds of new audio the audio so far is decoded (greedy; on whatever replica is free) and the hypothesis kept.  stop()
+        hands the latest one to the final decode as a draft (wis_generate_draft): the final window's encoder runs, the draft is
+        verified against it 16 tokens per decoder pass, and token-by-token decoding only resumes where the two part - typically
+        the last words.  Only for beam 1 (the reference's default; a beam search has no single chain to verify) and a language
+        that needs no detection on the final audio."""
+        if getattr(self, "_spec_every", 0) <= 0 or self._n > 30 * audio.SAMPLE_RATE or self._n - self._spec_n < self._spec_every * audio.SAMPLE_RATE:
+            return
+        if (self.detect_language and not self.force_language) or self._final_beam(self._n) != 1:
+            return
+        if self._spec_job is not None and not self._spec_job.done():
+            return
+        pcm, n = self._audio().copy(), self._n
+        self._spec_n = n
+        prev = self._spec_latest[1] if self._spec_latest else None
+        self._spec_job = self._pool.submit(self._speculate, pcm, n, prev)
+
+    def _speculate(self, pcm, n, prev):
+        language = self.force_language or self.models.settings.language
+        ids = self._window_tokens(pcm, 1, language, draft=prev)      # (the previous hypothesis is the draft of this one)
+        with self._lock:
+            if self._spec_latest is None or n > self._spec_latest[0]:
+                self._spec_latest = (n, list(ids))
+            self.spec_runs += 1
+        return ids
+
+    def _window_tokens(self, piece, beam, language, stream=None, draft=None):
         """`language`: a code, or a Future resolving to one (the session-wide language job of window 0: every eager window
         waits for THAT result, so a later window can never decide the language - do_whisper always detects on window 0).
         `stream`: the window's MelStream (its samples are all fed): finish it and decode from the features in HBM."""
@@ -157,14 +195,16 @@ class StreamingSession:
             try:
                 stream.finish(to_host=False)
                 r = self._whisper.generate_from_device(stream.device, stream.device_ptr, self._prompt(language), beam_size=beam,
-                                                       fixed_new_tokens=self.fixed_new_tokens, replica=self._replica)
+                                                       fixed_new_tokens=self.fixed_new_tokens, replica=self._replica, draft_tokens=draft)
                 self.front_windows += 1
+                self._last_accepted = getattr(r, "accepted_draft_tokens", None)
                 return r.sequences_ids[0]
             finally:
                 stream.close()
         x = np.ascontiguousarray(audio.pad_or_trim(piece)[None], np.float32)
         r = self._whisper.generate(ctranslate2.StorageView.from_array(x), [self._prompt(language)], beam_size=beam,
-                                   return_scores=False, fixed_new_tokens=self.fixed_new_tokens, input_kind=ctranslate2._lib.WIS_IN_PCM_HOST)
+                                   return_scores=False, fixed_new_tokens=self.fixed_new_tokens, input_kind=ctranslate2._lib.WIS_IN_PCM_HOST, draft_tokens=draft)
+        self._last_accepted = getattr(r[0], "accepted_draft_tokens", None)
         return r[0].sequences_ids[0]
 
     def _schedule_complete_windows(self):
@@ -220,7 +260,18 @@ class StreamingSession:
             st = None                              # (longer) call detects again on its own first window
             if final and front is not None and front.short is not None and front.n == pcm.shape[0]:
                 st, front.short = front.short, None
-            tokens = self._window_tokens(pcm, beam, language, st) if st is not None else self._window_tokens(pcm, beam, language)
+            draft = None
+            if final and beam == 1:
+                with self._lock:
+                    latest = getattr(self, "_spec_latest", None)
+                    draft = latest[1] if latest else None
+            self._last_accepted = None
+            if st is not None or draft is not None:
+                tokens = self._window_tokens(pcm, beam, language, st, draft=draft)
+            else:
+                tokens = self._window_tokens(pcm, beam, language)
+            if final and draft is not None:
+                self.accepted_draft_tokens = self._last_accepted
         text = tokenizer.decode(tokens).strip()
         ms = (time.perf_counter() - t0) * 1000
         out = WhisperResult((language, text, ms, None, math.floor(duration_ms / ms) if ms > 0 else 0, duration_ms))
