@@ -8,6 +8,7 @@
 #   bench<N> [ENV=VAL ...]   bench.py at N utterances per device batch (no extras, no CPU baseline); extra words are
 #                   environment assignments for that run and become part of the output name
 #   eot             bench.py --natural-eot: the search that ends on EOT against the fixed-length call of the same number of passes
+#   stream          bench.py's streaming rows alone (large-v2, 30sec.flac)
 #   benchfull       the default bench.py line (what the driver runs)
 #   prof<N> [ENV=VAL ...]   rocprofv3 --kernel-trace --stats of the eager bench at N utterances per device batch -> kernel_stats_b*.txt (+ by-grid table)
 #   frag2 [iters]   tools/bin/frag2_lab in its three flag variants (as the library / -fno-slp-vectorize / accumulators in AGPRs): the two-n-tile
@@ -63,6 +64,19 @@ except Exception as e:
     print("bench output unreadable:", e)
 PY
       ;;
+    stream)   # bench.py's streaming rows alone (BASELINE configs[4]): large-v2, 30sec.flac, beam 3 / beam 1 with speculation
+      timeout 900 python - > "$O/stream.json" 2> "$O/stream.err" <<'PY'
+import json, os, sys
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "willow-inference-server_amd")]
+import bench
+from wis_hip import _lib, ctranslate2 as ct2, weights as W
+lib = _lib.load(); _lib.require_gpu()
+a = W.arch("large"); w = W.synthetic_weights("large", seed=1234)
+arena, index = W.build_arena(w)
+h = ct2.create_handle(a, arena, index, 0, max_batch=8, max_beam=5)
+print(json.dumps(bench.streaming_bench(h, a, 0, os.path.join("tests", "golden", "clips", "30sec.flac"))))
+PY
+      python -c "import json,sys; d=json.load(open('$O/stream.json')); print({k:v for k,v in d.items() if k!='noise_64s'})" || tail -5 "$O/stream.err" ;;
     benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; tail -c 600 "$O/bench_default.json" ;;
     prof[0-9]*)
       B=${step#prof}; while [ $# -gt 0 ] && [[ $1 == *=* ]]; do export "$1"; B="$B"; PSUF="${PSUF}_${1//[^A-Za-z0-9=]/}"; shift; done
