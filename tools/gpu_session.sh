@@ -64,6 +64,11 @@ except Exception as e:
     print("bench output unreadable:", e)
 PY
       ;;
+    phases)   # tap build (lib/libwis_hip_taps.so: python willow-inference-server_amd/build.py --variant taps -DWIS_TAPS=1): phase stamps of layer 0's skinny GEMMs
+      for b in 1 8; do WIS_LIB_PATH=$R/willow-inference-server_amd/lib/libwis_hip_taps.so timeout 300 python tools/phase_cycles.py large $b --md > "$O/phases_b$b.txt" 2>&1; cat "$O/phases_b$b.txt" | head -60; done ;;
+    encstress)   # encstress [rounds]: tools/enc_stress.py (bitwise repeatability of encoder + generate under 4-replica concurrency)
+      RN=100; if [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; then RN=$1; shift; fi
+      timeout 900 python tools/enc_stress.py $RN > "$O/enc_stress_$RN.txt" 2>&1; echo "rc=$?" >> "$O/enc_stress_$RN.txt"; tail -5 "$O/enc_stress_$RN.txt" ;;
     stream)   # bench.py's streaming rows alone (BASELINE configs[4]): large-v2, 30sec.flac, beam 3 / beam 1 with speculation
       timeout 900 python - > "$O/stream.json" 2> "$O/stream.err" <<'PY'
 import json, os, sys

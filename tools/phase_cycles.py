@@ -19,9 +19,19 @@ arena, index = W.build_arena(w)
 h = ct2.create_handle(a, arena, index, 0, max_batch=B, max_beam=5)
 out = np.zeros((6, 16), np.uint64)
 names = ["gemv QKV (LN)", "gemv out-proj", "cross-attn", "self-attn", "gemv FFN1 (LN)", "gemv FFN2"]
+# gemv_body's stamps (csrc/dec_kernels.hip): one wave of workgroup 0
+PH = ["requests issued (activation rows + first weight fragments)", "activation rows arrived, cast to f16, staged in LDS", "staging barrier",
+      "weight stream consumed (MFMA loop)", "epilogue operands + cross-wave reduction barrier", "epilogue, stores issued"]
+md = "--md" in sys.argv
 for pos in (10,):
     _lib.check(lib.wis_debug_phase_cycles(h, B, 5, pos, out.ctypes.data_as(C.POINTER(C.c_uint64))))
     for i, n in enumerate(names):
         st = [int(v) for v in out[i][:14] if v]
         if st:
-            print(f"{n:16s} pos {pos}: total {st[-1] - st[0]:6d} cyc; phases {[st[j + 1] - st[j] for j in range(len(st) - 1)]}")
+            ph = [st[j + 1] - st[j] for j in range(len(st) - 1)]
+            print(f"{n:16s} pos {pos}: total {st[-1] - st[0]:6d} cyc; phases {ph}")
+            if md and n.startswith("gemv") and len(ph) == len(PH):
+                print(f"\n| {n}: phase (one wave of workgroup 0, decoder layer 0, {B} x beam 5 rows) | s_memtime ticks | share |\n|---|---|---|")
+                for name, c in zip(PH, ph):
+                    print(f"| {name} | {c} | {100.0 * c / max(1, st[-1] - st[0]):.0f} % |")
+                print(f"| total | {st[-1] - st[0]} | |\n")
