@@ -28,6 +28,28 @@ def test_abi_exports_every_declared_symbol(lib):
     assert lib.wis_version() == 1
 
 
+def test_library_exports_only_the_c_abi_and_passes_the_isa_lint(lib):
+    """(round-4 review items 2b / 8) nothing but the wis_* C symbols leaves libwis_hip.so (csrc/exports.map: no C++ helper, no kernel stub
+    can collide with another HIP library in the process), and the built code objects obey the packed-f32 / scratch rule that build()
+    enforces (tools/isa_lint.py) - checked here on the artefacts the tests run on."""
+    import glob
+    import importlib.util
+    import subprocess
+    from wis_hip import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names and all(n.startswith("wis_") for n in names), [n for n in names if not n.startswith("wis_")][:5]
+    assert set(names) == {name for name, _, _ in _lib.SYMBOLS}
+    spec = importlib.util.spec_from_file_location("wis_isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    objs = sorted(glob.glob(os.path.join(ROOT, "willow-inference-server_amd", "build", "*.hip.o")))
+    assert len(objs) == 4
+    bad, rows = mod.lint(objs)
+    assert len(rows) > 150 and not bad and not [r for r in rows if r[6]]
+    assert sum(1 for r in rows if r[4]) > 100          # (the scan really saw the MFMA kernels)
+
+
 @pytest.mark.parametrize("clip,md5,n", [("3sec", "ad790df21d4d9d223d3f34227b5cfedd", 61440),
                                         ("10sec", "c5b99673d012d9a8f5d19dd68874a121", 171008),
                                         ("30sec", "3a541ad6463fe6e884e5995212b518fa", 467968)])

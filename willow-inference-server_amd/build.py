@@ -36,8 +36,8 @@ C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
 # 240 000 without, same registers, same occupancy, same chip - tools/frag_stress.hip, tools/frag2_lab.hip).
 # Scalar f32 code is also what the guide recommends beside MFMAs (packed f32 is "an anti-lever" there).  The flag alone does not
 # remove every packed op (sums on ext-vector types still lower to v_pk_add_f32: the encoder epilogues add component-wise, add4), so
-# the rule is ENFORCED on the built code objects: tools/isa_lint.py, run by build() below - no kernel with MFMAs that can run three
-# or more waves per SIMD may contain v_pk_{add,mul,fma}_f32, and no kernel may use scratch (a spill inside the 8-phase GEMM loop
+# the rule is ENFORCED on the built code objects: tools/isa_lint.py, run by build() below - no kernel with MFMAs may contain
+# v_pk_{add,mul,fma}_f32 (today no kernel of the library contains one at all), and no kernel may use scratch (a spill inside the 8-phase GEMM loop
 # would move its hand-counted vmcnt waits).
 SOURCE_FLAGS = {}
 
