@@ -466,19 +466,29 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   if (tid == 0) tl_end(p.prof);
 #undef WIS_ROW_OF
 }
+// Kernel arguments: what the kernel needs BEFORE its first vector load (activation / weight base addresses, the shape) leads the
+// argument list as plain scalars, the rest follows as the struct.  With -amdgpu-kernarg-preload-count (build.py) the command
+// processor delivers the leading 16 dwords in SGPRs at wave launch, so the activation and weight requests go out without waiting
+// for a scalar load of the kernarg segment (an HBM round trip: the step's 1.6 GB weight stream leaves nothing of it in the
+// caches between replays); hipcc preloads only scalar / pointer arguments, never a by-value struct (kernarg_preload_length 0).
+#define WIS_GV_LEAD(q) (q).x, (q).x2, (q).Wp, (q).M, (q).N, (q).K, (q).xsplit
+#define WIS_GV_LEAD_DECL(s) const void* s##x, const void* s##x2, const f16* s##Wp, int s##M, int s##N, int s##K, int s##xsplit
+#define WIS_GV_LEAD_APPLY(q, s) (q).x = s##x; (q).x2 = s##x2; (q).Wp = s##Wp; (q).M = s##M; (q).N = s##N; (q).K = s##K; (q).xsplit = s##xsplit
 template <int MB, int MODE, int SC, int RM, bool W8>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvP p, int KC) {
+__global__ __launch_bounds__(256) void gemv_kernel(WIS_GV_LEAD_DECL(l_), int KC, GemvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  WIS_GV_LEAD_APPLY(p, l_);
   gemv_body<MB, MODE, SC, RM, W8>(p, KC, blockIdx.x, smem);
 }
 // Two skinny GEMMs in ONE launch (workgroups [0, nA) run problem A, the rest problem B; both f16-activation, single-chunk,
 // <= 16 rows): the decoder's attention output projection together with the cross-attention query projection folded THROUGH it
 // (model.hip fused_out_cq): one dependent stage instead of two.
 template <int SCA, int SCB>
-__global__ __launch_bounds__(256) void gemv_dual_kernel(GemvP pa, GemvP pb, int nA) {
+__global__ __launch_bounds__(256) void gemv_dual_kernel(int nA, int M, const void* ax, const f16* aWp, int aN, int aK, const void* bx, const void* bx2, const f16* bWp, int bN, int bK, int bxsplit,
+                                                        GemvP pa, GemvP pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x < nA) gemv_body<1, 2, SCA, 1, false>(pa, pa.K, blockIdx.x, smem);
-  else gemv_body<1, 2, SCB, 1, false>(pb, pb.K, (int)blockIdx.x - nA, smem);
+  if ((int)blockIdx.x < nA) { pa.x = ax; pa.x2 = nullptr; pa.Wp = aWp; pa.M = M; pa.N = aN; pa.K = aK; gemv_body<1, 2, SCA, 1, false>(pa, aK, blockIdx.x, smem); }
+  else { pb.x = bx; pb.x2 = bx2; pb.Wp = bWp; pb.M = M; pb.N = bN; pb.K = bK; pb.xsplit = bxsplit; gemv_body<1, 2, SCB, 1, false>(pb, bK, (int)blockIdx.x - nA, smem); }
 }
 // per-device launch state of the skinny GEMM (several replica worker threads may launch on different GPUs at once): the dynamic-LDS
 // ceiling of each device, queried once, and the lock under which the per-instantiation attribute is raised
@@ -495,7 +505,7 @@ static size_t gemv_lds_limit(int dev) {
   return v;
 }
 int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
-  if (pa.M != pb.M || pa.M < 1 || pa.M > 16 || pa.wscale || pb.wscale || (pa.flags & (GV_LN | GV_QKV)) || (pb.flags & (GV_LN | GV_QKV))) { set_error("gemv_dual: unsupported pair"); return WIS_E_UNSUPPORTED; }
+  if (pa.M != pb.M || pa.M < 1 || pa.M > 16 || pa.x2 || pa.wscale || pb.wscale || (pa.flags & (GV_LN | GV_QKV)) || (pb.flags & (GV_LN | GV_QKV))) { set_error("gemv_dual: unsupported pair"); return WIS_E_UNSUPPORTED; }
   if (pa.M * (pa.K / 8) > 13 * 256 || pb.M * (pb.K / 8) > 13 * 256 || pa.K % 128 || pb.K % 128) { set_error("gemv_dual: rows do not fit the register staging (M=%d K=%d/%d)", pa.M, pa.K, pb.K); return WIS_E_UNSUPPORTED; }
   const int sa = pa.K / 128, sb = pb.K / 128;
   const size_t aux = (size_t)4 * 64 * 16 + MAX_ROWS * 8 + 4 * 16 * 4 + 16;
@@ -505,11 +515,11 @@ int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
   const int nA = cdiv(pa.N, 16), nB = cdiv(pb.N, 16);
   dim3 grid(nA + nB), block(256);
   GemvP a = pa, b = pb; a.rows = 16; b.rows = 16;
-  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, a, b, nA);
-  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, a, b, nA);
-  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, a, b, nA);
-  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, a, b, nA);
-  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, a, b, nA);
+  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
+  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
+  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
+  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
+  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
   else { set_error("gemv_dual: K=%d/%d not instantiated", pa.K, pb.K); return WIS_E_UNSUPPORTED; }
   return WIS_OK;
 }
@@ -559,7 +569,7 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap) != hipSuccess) { \
           set_error("gemv: cannot raise the dynamic LDS limit to %zu bytes", lds_cap); return WIS_E_HIP; } \
         big_ok.fetch_or(1ull << (cur_dev & 63), std::memory_order_release); } } \
-    hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), grid, block, lds, st, pp, KC); } while (0)
+    hipLaunchKernelGGL((gemv_kernel<MBv, MODEv, SCv, RMv, W8v>), grid, block, lds, st, WIS_GV_LEAD(pp), KC, pp); } while (0)
 #define WIS_GV(MBv, MODEv, SCv, RMv) do { if (p.wscale) WIS_GV1(MBv, MODEv, SCv, RMv, true); else WIS_GV1(MBv, MODEv, SCv, RMv, false); } while (0)
 #define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \
                                                       case 8: WIS_GV(MBv, MODEv, 8, RMv); break; case 10: WIS_GV(MBv, MODEv, 10, RMv); break; default: WIS_GV(MBv, MODEv, 0, RMv); } } while (0)
@@ -784,7 +794,8 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
 }
 
 template <int MB, int PF, bool W8>
-__global__ __launch_bounds__(256) void gemv_frag_kernel(GemvP p) {
+__global__ __launch_bounds__(256) void gemv_frag_kernel(WIS_GV_LEAD_DECL(l_), GemvP p) {
+  WIS_GV_LEAD_APPLY(p, l_);
   gemv_frag_body<MB, PF, W8>(p, blockIdx.x, gridDim.y, blockIdx.y);
 }
 // Up to three skinny GEMMs of one row count in ONE launch (f16 weights, no K split): workgroups [0, n0) run problem 0, the next n1
@@ -807,7 +818,8 @@ __global__ __launch_bounds__(256) void gemv_frag3_kernel(GemvP3 ps) {
 // kernel's time is those CUs' 328 KB.  Two tiles per workgroup: 160 workgroups x (82 + 123) KB, one round.  Every activation
 // fragment feeds two MFMAs.  No residual form, no K split (those projections have 80 n-tiles).
 template <int MB, int PF, bool W8>
-__global__ __launch_bounds__(256) void gemv_frag2_kernel(GemvP p) {
+__global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), GemvP p) {
+  WIS_GV_LEAD_APPLY(p, l_);
   typedef typename WFrag<W8>::T WT;
   constexpr int EPN = (MB + 3) / 4;
   __shared__ __attribute__((aligned(16))) float red[4 * MB * 2 * 64 * 4];
@@ -984,8 +996,8 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   static const int env_nb = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 2;
   if (env_nb == 2 && (p.flags & GV_LN) && !(p.flags & GV_RESID) && ks == 1 && (npad / 16) % 2 == 0 && npad / 16 > 256) {
     dim3 g2(npad / 32), blk(256);
-#define WIS_GF2(MBv, PFv) do { if (p.wscale) hipLaunchKernelGGL((gemv_frag2_kernel<MBv, PFv, true>), g2, blk, 0, st, p); \
-                               else hipLaunchKernelGGL((gemv_frag2_kernel<MBv, PFv, false>), g2, blk, 0, st, p); } while (0)
+#define WIS_GF2(MBv, PFv) do { if (p.wscale) hipLaunchKernelGGL((gemv_frag2_kernel<MBv, PFv, true>), g2, blk, 0, st, WIS_GV_LEAD(p), p); \
+                               else hipLaunchKernelGGL((gemv_frag2_kernel<MBv, PFv, false>), g2, blk, 0, st, WIS_GV_LEAD(p), p); } while (0)
     switch (p.xmb) {
       case 1: WIS_GF2(1, 6); break;
       case 2: WIS_GF2(2, 6); break;
@@ -1003,8 +1015,8 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   // up to three row blocks: the whole wave stream (ten k-steps) or eight k-steps in flight; four to six row blocks (49-96 rows):
   // a six-deep ring, so that weight + activation fragments stay inside the register file ((MB + 1) x 4 VGPRs per k-step)
 #define WIS_GF(MBv, PFA, PFB) do { \
-    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, true>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, true>), grid, block, 0, st, p); } \
-    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, false>), grid, block, 0, st, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, false>), grid, block, 0, st, p); } } while (0)
+    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, true>), grid, block, 0, st, WIS_GV_LEAD(p), p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, true>), grid, block, 0, st, WIS_GV_LEAD(p), p); } \
+    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, false>), grid, block, 0, st, WIS_GV_LEAD(p), p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, false>), grid, block, 0, st, WIS_GV_LEAD(p), p); } } while (0)
   switch (p.xmb) {
     case 1: WIS_GF(1, 10, 8); break;
     case 2: WIS_GF(2, 10, 8); break;
