@@ -188,7 +188,7 @@ int main(int argc, char** argv) {
   GemvP g; memset(&g, 0, sizeof(g));
   g.x = xf; g.Wp = Wp; g.bias = bias; g.csum = csum; g.stat_in = stat; g.M = M; g.N = N; g.K = K; g.flags = GV_LN | GV_OUT_F32; g.xmb = MB; g.rows = 16;
   g.y = yref;
-  hipLaunchKernelGGL((gemv_frag_kernel<5, 6, false>), dim3(N / 16), dim3(256), 0, st, WIS_GV_LEAD(g), g);
+  hipLaunchKernelGGL((gemv_frag_kernel<5, 6, false>), dim3(N / 16), dim3(256), 0, st, g.x, g.Wp, g.M, g.N, g.K, g.wks, g.wk0, 1, g);
   CK(hipStreamSynchronize(st));
   g.y = y;
   std::vector<Rec> hrec(4096);
@@ -321,7 +321,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 4; ++i) { CK(hipStreamCreate(&ss[i])); CK(hipMalloc(&ys[i], ny * 4)); }
     unsigned bad = 0; const int rounds = iters;
     for (int it = 0; it < rounds; ++it) {
-      for (int i = 0; i < 4; ++i) { GemvP gi = g; gi.y = ys[i]; hipLaunchKernelGGL((gemv_frag_kernel<5, 6, false>), dim3(N / 16), dim3(256), 0, ss[i], WIS_GV_LEAD(gi), gi); }
+      for (int i = 0; i < 4; ++i) { GemvP gi = g; gi.y = ys[i]; hipLaunchKernelGGL((gemv_frag_kernel<5, 6, false>), dim3(N / 16), dim3(256), 0, ss[i], gi.x, gi.Wp, gi.M, gi.N, gi.K, gi.wks, gi.wk0, 1, gi); }
       for (int i = 0; i < 4; ++i) CK(hipStreamSynchronize(ss[i]));
       for (int i = 0; i < 4; ++i) bad += check("f1 x4 streams", ys[i], yref, ny, it, bad < 3) ? 1 : 0;
     }

@@ -484,11 +484,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(WIS_GV_LEAD_DECL(l_), int KC,
 // <= 16 rows): the decoder's attention output projection together with the cross-attention query projection folded THROUGH it
 // (model.hip fused_out_cq): one dependent stage instead of two.
 template <int SCA, int SCB>
-__global__ __launch_bounds__(256) void gemv_dual_kernel(int nA, int M, const void* ax, const f16* aWp, int aN, int aK, const void* bx, const void* bx2, const f16* bWp, int bN, int bK, int bxsplit,
+__global__ __launch_bounds__(256) void gemv_dual_kernel(int nA, int M, const void* ax, const f16* aWp, const void* bx, const void* bx2, const f16* bWp, int bxsplit,
                                                         GemvP pa, GemvP pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x < nA) { pa.x = ax; pa.x2 = nullptr; pa.Wp = aWp; pa.M = M; pa.N = aN; pa.K = aK; gemv_body<1, 2, SCA, 1, false>(pa, aK, blockIdx.x, smem); }
-  else { pb.x = bx; pb.x2 = bx2; pb.Wp = bWp; pb.M = M; pb.N = bN; pb.K = bK; pb.xsplit = bxsplit; gemv_body<1, 2, SCB, 1, false>(pb, bK, (int)blockIdx.x - nA, smem); }
+  // (K of either problem is the instantiation's: SC k-steps of 32 per wave, four waves)
+  if ((int)blockIdx.x < nA) { pa.x = ax; pa.x2 = nullptr; pa.Wp = aWp; pa.M = M; pa.K = SCA * 128; gemv_body<1, 2, SCA, 1, false>(pa, SCA * 128, blockIdx.x, smem); }
+  else { pb.x = bx; pb.x2 = bx2; pb.Wp = bWp; pb.M = M; pb.K = SCB * 128; pb.xsplit = bxsplit; gemv_body<1, 2, SCB, 1, false>(pb, SCB * 128, (int)blockIdx.x - nA, smem); }
 }
 // per-device launch state of the skinny GEMM (several replica worker threads may launch on different GPUs at once): the dynamic-LDS
 // ceiling of each device, queried once, and the lock under which the per-instantiation attribute is raised
@@ -515,11 +516,11 @@ int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
   const int nA = cdiv(pa.N, 16), nB = cdiv(pb.N, 16);
   dim3 grid(nA + nB), block(256);
   GemvP a = pa, b = pb; a.rows = 16; b.rows = 16;
-  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
-  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
-  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
-  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
-  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, nA, a.M, a.x, a.Wp, a.N, a.K, b.x, b.x2, b.Wp, b.N, b.K, b.xsplit, a, b);
+  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
+  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
+  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
+  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
+  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
   else { set_error("gemv_dual: K=%d/%d not instantiated", pa.K, pb.K); return WIS_E_UNSUPPORTED; }
   return WIS_OK;
 }
@@ -794,9 +795,9 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
 }
 
 template <int MB, int PF, bool W8>
-__global__ __launch_bounds__(256) void gemv_frag_kernel(WIS_GV_LEAD_DECL(l_), GemvP p) {
-  WIS_GV_LEAD_APPLY(p, l_);
-  gemv_frag_body<MB, PF, W8>(p, blockIdx.x, gridDim.y, blockIdx.y);
+__global__ __launch_bounds__(256) void gemv_frag_kernel(const void* l_x, const f16* l_Wp, int l_M, int l_N, int l_K, int l_wks, int l_wk0, int KS, GemvP p) {
+  p.x = l_x; p.Wp = l_Wp; p.M = l_M; p.N = l_N; p.K = l_K; p.wks = l_wks; p.wk0 = l_wk0;      // (KS = gridDim.y, passed: the hidden grid-size arguments are a kernarg load too)
+  gemv_frag_body<MB, PF, W8>(p, blockIdx.x, KS, blockIdx.y);
 }
 // Up to three skinny GEMMs of one row count in ONE launch (f16 weights, no K split): workgroups [0, n0) run problem 0, the next n1
 // problem 1, the rest problem 2 - a dependent stage less per decoder layer at 9-96 rows (model.hip dec_forward_frag): the self-attention
@@ -1015,8 +1016,8 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   // up to three row blocks: the whole wave stream (ten k-steps) or eight k-steps in flight; four to six row blocks (49-96 rows):
   // a six-deep ring, so that weight + activation fragments stay inside the register file ((MB + 1) x 4 VGPRs per k-step)
 #define WIS_GF(MBv, PFA, PFB) do { \
-    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, true>), grid, block, 0, st, WIS_GV_LEAD(p), p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, true>), grid, block, 0, st, WIS_GV_LEAD(p), p); } \
-    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, false>), grid, block, 0, st, WIS_GV_LEAD(p), p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, false>), grid, block, 0, st, WIS_GV_LEAD(p), p); } } while (0)
+    if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, true>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, true>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); } \
+    else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, false>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, false>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); } } while (0)
   switch (p.xmb) {
     case 1: WIS_GF(1, 10, 8); break;
     case 2: WIS_GF(2, 10, 8); break;
@@ -1101,10 +1102,11 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 // products and the position reductions are DPP ops, longer histories continue with an online softmax.
 // Logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul (decode rows own their slot, prefill rows share
 // the utterance's first slot).
+// (argument order: everything the first round of loads needs - q, the caches, the row table, the shape - sits in the first 14
+// dwords, which -amdgpu-kernarg-preload-count delivers in SGPRs at wave launch; `out` and the taps are only read at the end)
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
-                                                           const int* __restrict__ pos,
-                                                           f16* __restrict__ out, int d, int ctx, int rpu, int sstride, int rmul,
-                                                           unsigned long long* prof, int out_mb) {
+                                                           const int* __restrict__ pos, int d, int ctx, int rpu, int sstride, int rmul,
+                                                           f16* __restrict__ out, unsigned long long* prof, int out_mb) {
   __shared__ float red[4][64];
   const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, pl = lane >> 3, c = lane & 7;
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
@@ -1196,7 +1198,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof, int out_mb) {
   if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, out, d, ctx, rpu, sstride, rmul, prof, out_mb);
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb);
   return WIS_OK;
 }
 
@@ -1248,11 +1250,16 @@ constexpr unsigned CA_SPIN_LIMIT = 1u << 17;      // sweeps before the combiner 
 // dec_forward_frag) and the statistics come from the per-16-column (sum, M2) partials the out-projection's residual epilogue left
 // (xres = [B*R][d/16][2]; merged like gemv_frag_kernel merges them) - 80 pairs per row instead of 1280 floats.
 template <int TPW, int CM, int FOLD, bool SPIN>
+// (argument order as in dec_self_attn_kernel: the first 14 dwords - q, K, V^T, the folded query's rows / second half, the epoch block and
+// the packed shape - are preloaded into SGPRs, so the kernel's first round of requests (q, the statistics' rows, the K fragments) does
+// not wait for a kernarg fetch; what needs the later arguments - column sums / bias of the folded query, V^T's pitch - is requested behind them)
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
-                                                             f16* __restrict__ out, float* part, unsigned* counters,
-                                                             int R, int H, int d, int T, int Tpad, int C, int CL, unsigned long long* prof, int out_mb,
-                                                             const float* __restrict__ xres, const float* __restrict__ qcs, const float* __restrict__ qb,
-                                                             gran_t* gran, unsigned* epoch, const float* __restrict__ q2) {
+                                                             const float* __restrict__ xres, const float* __restrict__ q2, unsigned* epoch, int RHCC, int dT,
+                                                             int Tpad, f16* __restrict__ out, float* part, unsigned* counters,
+                                                             unsigned long long* prof, int out_mb,
+                                                             const float* __restrict__ qcs, const float* __restrict__ qb, gran_t* gran) {
+  // rows | heads << 8 | chunk length << 14 | chunks << 24, d | T << 16: six pointers + two words = the 14 preloaded dwords
+  const int R = RHCC & 0xFF, H = (RHCC >> 8) & 0x3F, CL = (RHCC >> 14) & 0x3FF, C = (RHCC >> 24) & 0xFF, d = dT & 0xFFFF, T = (dT >> 16) & 0xFFFF;
   __shared__ float ssc[16][257];
   __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
   __shared__ float smax[16][16];
@@ -1302,11 +1309,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       for (int i = 0; i < NXS; ++i) { const int c4 = lane + 64 * i; xs4[j][i] = xr[c4 < d4 ? c4 : d4 - 1]; }      // unconditional (clamped; masked in the sums): no exec-masked branch between the loads
     }
   }
-  if (FOLD) {
-    const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
-    cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
-    bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
-  }
+  // (K fragments: addressed from preloaded arguments only, so they go out before the first wait for a scalar kernarg load)
   const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
   u32x4 kf[TPW][2];
 #pragma unroll
@@ -1314,6 +1317,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     int key = klo + 16 * (wave + 4 * i) + l15; if (key > T - 1) key = T - 1;      // clamped; masked below
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
+  }
+  if (FOLD) {
+    const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
+    cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
+    bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
   }
   constexpr int NSTEP = 2 * TPW;                      // 32-key P.V steps per chunk; V^T is zero padded up to Tpad >= chunks * CL
   const f16* vb = vt + ((size_t)(b * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
@@ -1588,14 +1596,15 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
   if (xres && (!qcs || !qb || R > 8 || d > (xres_is_stat ? 2048 : 1280))) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280 (2048 from partials)"); return WIS_E_ARG; }
   if (xres_is_stat && (!xres || !q2)) { set_error("dec_cross_attn: the batched fold needs the row partials and the second half of q_raw"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
+  if (H > 63 || d > 65535 || T > 65535) { set_error("dec_cross_attn: H=%d d=%d T=%d beyond the packed shape arguments", H, d, T); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)
   if ((CL != 128 && CL != 256) || CL * chunks > Tpad) { set_error("dec_cross_attn: %d chunks of %d keys unsupported (Tpad %d)", chunks, CL, Tpad); return WIS_E_UNSUPPORTED; }
   const int used = cdiv(T, CL);                      // chunks that actually hold keys
   static const int env_spin = getenv("WIS_CA_SPIN") ? atoi(getenv("WIS_CA_SPIN")) : 1;      // 0: always the ticket form (A/B switch)
   // granule hand-off: small grids only (fewer spinning combiners than CUs), the default 256-key chunking, <= 8 rows per utterance
   const bool spin = env_spin && gran && epoch && B * H <= CA_SPIN_MAX_BH && CL == 256 && used >= 2 && used <= 6 && R <= 8;
-#define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, out, part, counters, \
-                                                  R, H, d, T, Tpad, used, CL, prof, out_mb, xres, qcs, qb, gran, epoch, q2)
+#define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, xres, q2, epoch, \
+                                                  (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), Tpad, out, part, counters, prof, out_mb, qcs, qb, gran)
   if (xres_is_stat) {
     if (spin) WIS_CA(4, 6, 2, true); else if (CL <= 128) WIS_CA(2, 16, 2, false); else if (used <= 6) WIS_CA(4, 6, 2, false); else WIS_CA(4, 16, 2, false);
   }
