@@ -27,8 +27,16 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (zero-initialisation and hand-over to the softmax arithmetic, ~20 % of the loop's vector-ALU time); in VGPR form the first MFMA
 # of a tile takes the inline constant 0 as its C operand and the softmax reads the result registers directly.  No kernel spills.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
+             "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize",
+             "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("WIS_EXTRA_HIPFLAGS", "").split()
 C_FLAGS = ["-O2", "-fPIC", "-std=c11", "-I" + os.path.join(ROOT, "include")]
+# -amdgpu-kernarg-preload-count=16 (r5): the command processor hands the first kernel arguments to a wave in SGPRs at launch instead of
+# the wave fetching them from the kernarg segment - one HBM round trip (the decode step's 1.6 GB weight stream leaves nothing cached between
+# graph replays) in front of the first address computation of EVERY one of the step's 229 kernels.  hipcc preloads only leading scalar /
+# pointer arguments (a by-value struct gets kernarg_preload_length 0 - which is why round 1 measured "no change" for this flag: the skinny
+# GEMMs took one struct), so the decoder kernels now list what their first round of loads needs as leading scalars, at most 14 dwords
+# (csrc/dec_kernels.hip WIS_GV_LEAD, dec_self_attn_kernel, dec_cross_attn_kernel).  Same box, same call: decode step 1.402 -> 1.342 ms at
+# one utterance (-4.2 %), 2.215 -> 2.146 ms at eight (-3.1 %), whole utterance 29.47 -> 28.42 ms.
 # -fno-slp-vectorize, every HIP source: hipcc's SLP pass turns adjacent scalar f32 adds / multiplies (epilogue arithmetic on float4
 # values) into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), and the two-n-tile skinny GEMM's
 # 3-waves-per-SIMD instantiation (168 VGPRs) returned WRONG low halves of those packed results in lanes 48-63 in about half of its
