@@ -26,6 +26,16 @@
 
 namespace wis {
 
+// GEMM kernels take the GemmP fields as leading SCALAR arguments (rebuilt into the struct inside): hipcc's kernarg preload
+// (-amdgpu-kernarg-preload-count, build.py) hands scalars / pointers to the wave in SGPRs at launch but never a by-value struct, and the
+// first DMA / fragment addresses need A, W, the shape and the row mapping before anything else.  12 + 2 dwords fit the preload window;
+// n_phase (an epilogue quantity) is the first one outside it.
+#define WIS_GP_DECL(s) const f16* s##A, int64_t s##a_bs, int s##a_rs, int s##a_rpb, const f16* s##W, int s##M, int s##N, int s##K, int s##klen, int s##n_span, int s##n_period, int s##n_phase
+#define WIS_GP_ARGS(q) (q).A, (q).a_bs, (q).a_rs, (q).a_rpb, (q).W, (q).M, (q).N, (q).K, (q).klen, (q).n_span, (q).n_period, (q).n_phase
+#define WIS_GP_MAKE(p, s) GemmP p; p.A = s##A; p.a_bs = s##a_bs; p.a_rs = s##a_rs; p.a_rpb = s##a_rpb; p.W = s##W; p.M = s##M; p.N = s##N; p.K = s##K; p.klen = s##klen; \
+                          p.n_span = s##n_span; p.n_period = s##n_period; p.n_phase = s##n_phase
+
+
 // =======================================================================================
 // LayerNorm: fp32 [M][d] -> f16 [M][d]; one 64-lane wave per row, two-pass in registers.
 #define WIS_PIN4(r) asm volatile("" :: "v"((r).x), "v"((r).y), "v"((r).z), "v"((r).w))
@@ -191,7 +201,8 @@ __device__ __forceinline__ void epilogue_32(const Epi& epi, const f32x16 (&acc)[
 }
 
 template <class Epi, int BM_, int BN_, int WM_, int WN_>
-__global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi epi) {
+__global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(WIS_GP_DECL(g_), Epi epi) {
+  WIS_GP_MAKE(p, g_);
   constexpr int T = 64 * WM_ * WN_;            // threads
   constexpr int TM = BM_ / WM_, TN = BN_ / WN_;   // wave tile
   constexpr int MI = TM / 32, NI = TN / 32;    // 32x32 MFMA sub-tiles per wave
@@ -298,7 +309,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_f16_kernel(GemmP p, Epi e
 // Same MFMA order per output element as gemm_f16_kernel: bit-identical results.  tools/gemm_lab.hip, weights streamed from HBM,
 // M = 1500: QKV 29.8 -> 27.6 us, FFN1 32.4 -> 30.3 us against the 128 x 128 tile.
 template <class Epi>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p, Epi epi) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(WIS_GP_DECL(g_), Epi epi) {
+  WIS_GP_MAKE(p, g_);
   constexpr int BM_ = 256, BN_ = 128;
   __shared__ __attribute__((aligned(16))) f16 sA[2][BM_ * LSTR];
   __shared__ __attribute__((aligned(16))) f16 sW[2][BN_ * LSTR];
@@ -404,7 +416,8 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // lane): the transposed V images of the QKV and cross-K/V projections, whose plain layout would scatter single 2-byte stores.  A launch is
 // either all plain or all transposed tiles (GemmP::n_span / n_period / n_phase select its output columns).
 template <class Epi, bool TR>
-__global__ __launch_bounds__(512) void gemm_8p_kernel(GemmP p, Epi epi) {
+__global__ __launch_bounds__(512) void gemm_8p_kernel(WIS_GP_DECL(g_), Epi epi) {
+  WIS_GP_MAKE(p, g_);
   constexpr int BM_ = 256, BN_ = 256, HALF = 128 * 64, BUF = 4 * HALF;
   __shared__ __attribute__((aligned(1024))) f16 smem[2 * BUF];      // ONE LDS object (a second one makes hipcc drain vmcnt before fragment reads)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -794,7 +807,7 @@ static void launch_8p_part(hipStream_t st, const GemmP& q, const Epi& epi) {
   if (!n_cu) { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256; n_cu = v & ~7; }
   dim3 g8((q.N / 256) * cdiv(q.M, 256), 1, q.klen > 0 ? q.K / q.klen : 1);
   if (persist && (int)g8.x > n_cu) g8.x = n_cu;
-  hipLaunchKernelGGL((gemm_8p_kernel<Epi, TR>), g8, dim3(512), 0, st, q, epi);
+  hipLaunchKernelGGL((gemm_8p_kernel<Epi, TR>), g8, dim3(512), 0, st, WIS_GP_ARGS(q), epi);
 }
 // Functors with a transposed part (Epi::HAS_T: the V images) get TWO launches - their plain columns, then their transposed columns with
 // swapped MFMA operands; Epi::split describes the two column sets.
@@ -857,10 +870,10 @@ static int launch_gemm_t(hipStream_t st, const GemmP& p, const Epi& epi) {
     const int rc = launch_gemm_8pn(st, p, epi);
     if (rc <= 0) return rc;
   }
-  if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, p, epi);
-  else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, p, epi);
-  else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
-  else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, p, epi);
+  if (bm == 256 && bn == 256) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 256, 256, 2, 4>), grid, dim3(512), 0, st, WIS_GP_ARGS(p), epi);
+  else if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<Epi>), grid, dim3(512), 0, st, WIS_GP_ARGS(p), epi);
+  else if (bm == 64) hipLaunchKernelGGL((gemm_f16_kernel<Epi, 64, 128, 2, 2>), grid, dim3(256), 0, st, WIS_GP_ARGS(p), epi);
+  else hipLaunchKernelGGL((gemm_f16_kernel<Epi, 128, 128, 2, 2>), grid, dim3(256), 0, st, WIS_GP_ARGS(p), epi);
   return WIS_OK;
 }
 // f32x4 sums of the epilogues, component by component and pinned in VGPRs: `a + b` on the vector type compiles to v_pk_add_f32, which the
@@ -1244,8 +1257,8 @@ int launch_gemm_splitk_resid(hipStream_t st, const GemmP& p0, int splits, float*
   const int64_t zs = (int64_t)p.M * p.N;
   EpiPartial e{scratch, p.N, zs};
   // (the 128 x 256 8-phase tile measured no better here: 33.2 vs 32.5 us for the four K slices of FFN2)
-  if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, p, e);
-  else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, p, e);
+  if (gemm_pp_fits(p, splits)) hipLaunchKernelGGL((gemm_pp_kernel<EpiPartial>), dim3((p.N / 128) * cdiv(p.M, 256), 1, splits), dim3(512), 0, st, WIS_GP_ARGS(p), e);
+  else hipLaunchKernelGGL((gemm_f16_kernel<EpiPartial, 128, 128, 2, 2>), dim3((p.N / 128) * cdiv(p.M, 128), 1, splits), dim3(256), 0, st, WIS_GP_ARGS(p), e);
   if (Y) {
     if (!ln_gamma || !ln_beta || p.N > 2048 || (splits != 2 && splits != 4)) { set_error("splitk: fused LayerNorm needs gamma, beta, N <= 2048 and 2 or 4 splits"); return WIS_E_ARG; }
     if (splits == 2) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2>), dim3(cdiv(p.M, 4)), dim3(256), 0, st, scratch, zs, bias, resid, X, ln_gamma, ln_beta, Y, p.M, p.N);
