@@ -95,6 +95,7 @@ def cpu_baseline(size, weights, pcm, beam, fixed_new, audio_ms):
     enc_s, dec_s = t2e - t0, t3 - t2
     total = enc_s + dec_s
     return {"value": round(audio_ms / 1000.0 / total, 4), "unit": "x realtime", "cores": max(enc_t, best_t), "kind": "port",
+            "logmel_timed": mel_src,          # which log-mel ran on the host: the reference's own module only where /root/reference exists (not on the GPU box)
             "sample": (f"torch-fp32 oracle (KV-cached), the whole utterance measured: log-mel {1e3 * (t1 - t0):.0f} ms [{mel_src}] + encoder {1e3 * (t2e - t1):.0f} ms on {enc_t} host "
                        f"threads (best of 16/32/64/{cores} on a probe GEMM) + cross-KV, prefill and all {fixed_new + 1} beam-{beam} steps {1e3 * dec_s:.0f} ms on {best_t} threads "
                        f"(best of 8/16/32/{cores} on one step), {len(ids)} tokens = {total:.2f} s per utterance. Stand-in for the CT2 int8 CPU path (not installable offline); "
