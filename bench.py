@@ -543,7 +543,7 @@ def main():
         per_launch_us = 1e3 * ms.value / (passes * nl.value)
         achieved = nb.value / nl.value / (per_launch_us * 1e-6) / 1e9
         traffic = None
-        for name in ("r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
+        for name in ("r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -609,7 +609,7 @@ def main():
                                           "frac_of_hbm_peak": round(sb / (tm["decode_ms"] / sd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                     if Bc == 8:
                         try:      # HBM traffic of the step's two byte-heavy kernels from the --pmc passes (profiles/r03_pmc_decode.json)
-                            b8 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_decode.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_decode.json")) else "r03_pmc_decode.json")))["batch_8"]
+                            b8 = json.load(open(next(pp for pp in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json")) if os.path.exists(pp))))["batch_8"]
                             row["decode_step"]["traffic_over_algorithmic"] = {"skinny_gemm (gemv_frag_kernel)": b8["skinny_gemm_traffic_over_algorithmic"],
                                                                               "cross_attention": b8["per_kernel"]["dec_cross_attn_kernel 245760"]["traffic_over_algorithmic"]}
                         except Exception:
