@@ -44,6 +44,17 @@ def kernel_stats(tag):
         st, gr = read(f"{G}/{tag}/kernel_stats_b{B}.txt"), read(f"{G}/{tag}/kernels_by_grid_b{B}.txt")
         if not st:
             continue
+
+        def readable(txt):      # (symbols the trace tool cut before demangling: decode what is there)
+            out = []
+            for ln in txt.split("\n"):
+                m = re.match(r"(_ZN3wis\S+)(\s+)(.*)", ln)
+                if m:
+                    nm = short(m.group(1))
+                    ln = ("wis::" + nm).ljust(len(m.group(1)) + len(m.group(2))) + m.group(3)
+                out.append(ln)
+            return "\n".join(out)
+        st, gr = readable(st), (readable(gr) if gr else gr)
         out = (f"# rocprofv3 --kernel-trace --stats, round {int(RND[1:])}, Whisper large-v2 beam 5, 3.84 s clip, {what}\n\n"
                f"Command (GPU box, `bash tools/gpu_session.sh prof{B}`): `WIS_NO_GRAPH=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --batch {B} --no-cpu-baseline --no-extras`\n"
                "(eager launches: rocprofv3 cannot follow a HIP-graph capture; 7 generate calls + the roofline tap's passes over the decoder weight stream + the one-time weight conversion kernels).\n"
@@ -72,9 +83,26 @@ def parse_pmc(path):
 
 
 def short(name):
+    """demangled short form; the trace tools cut long symbols before they demangle them, so integer / bool template arguments of a mangled
+    (possibly truncated) name are decoded here: _ZN3wis11gemv_kernelILi1ELi2ELi0ELi1ELb0EEEv... -> gemv_kernel<1, 2, 0, 1, false>"""
     name = name.replace("wis::", "")
-    m = re.match(r"_ZN3wis\d+([a-z_0-9]+?)(?:I|E)", name)
-    return m.group(1) if m else name
+    m = re.match(r"_ZN3wis(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    if rest.startswith("I"):
+        args, i = [], 1
+        while i < len(rest):
+            a = re.match(r"Li(\d+)E|Lb([01])E", rest[i:])
+            if not a:
+                break
+            args.append(a.group(1) if a.group(1) is not None else ("true" if a.group(2) == "1" else "false"))
+            i += a.end()
+        if args and rest[i:i + 1] == "E" and base.startswith("gemv"):
+            return f"{base}<{', '.join(args)}>"
+    return base
 
 
 def pmc_decode(tag):
