@@ -96,11 +96,19 @@ def short(name):
         args, i = [], 1
         while i < len(rest):
             a = re.match(r"Li(\d+)E|Lb([01])E", rest[i:])
-            if not a:
-                break
-            args.append(a.group(1) if a.group(1) is not None else ("true" if a.group(2) == "1" else "false"))
-            i += a.end()
-        if args and rest[i:i + 1] == "E" and base.startswith("gemv"):
+            if a:
+                args.append(a.group(1) if a.group(1) is not None else ("true" if a.group(2) == "1" else "false"))
+                i += a.end()
+                continue
+            a = re.match(r"NS_(\d+)", rest[i:])        # a type of namespace wis: NS_<len><name>E
+            if a:
+                ln = int(a.group(1)); st = i + a.end()
+                args.append(rest[st:st + ln]); i = st + ln
+                if rest[i:i + 1] == "E":
+                    i += 1
+                continue
+            break
+        if args and rest[i:i + 1] == "E":
             return f"{base}<{', '.join(args)}>"
     return base
 
@@ -118,6 +126,8 @@ def pmc_decode(tag):
         rows, tot_t, tot_a = {}, 0.0, 0.0
         for (name, grid), cs in f.items():
             key = f"{short(name)} {grid}"
+            if key not in ALG and not short(name).startswith("gemv"):      # (the attention kernels are listed without their template arguments)
+                key = f"{short(name).split('<')[0]} {grid}"
             alg = ALG.get(key)
             if alg is None or "FETCH_SIZE" not in cs:
                 continue
