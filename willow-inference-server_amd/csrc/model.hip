@@ -874,10 +874,11 @@ int check_batch(wis_model* m, int B, int beam) {
 // replica from one worker thread).  A second thread entering the same handle is refused with WIS_E_STATE instead of silently
 // corrupting the first call's state - SURVEY 8(b) asks for thread safety at the boundary: concurrency comes from replicas and the
 // micro-batcher, never from two calls inside one replica.
+static std::atomic<int> g_active_calls[64];      // compute calls running per device (all handles): generate_impl's stream choice
 struct BusyGuard {
   wis_model* m; bool ok;
-  explicit BusyGuard(wis_model* mm) : m(mm), ok(!mm->busy.test_and_set(std::memory_order_acquire)) {}
-  ~BusyGuard() { if (ok) m->busy.clear(std::memory_order_release); }
+  explicit BusyGuard(wis_model* mm) : m(mm), ok(!mm->busy.test_and_set(std::memory_order_acquire)) { if (ok) g_active_calls[m->device & 63].fetch_add(1, std::memory_order_relaxed); }
+  ~BusyGuard() { if (ok) { g_active_calls[m->device & 63].fetch_sub(1, std::memory_order_relaxed); m->busy.clear(std::memory_order_release); } }
 };
 #define WIS_ENTER(m, what)                                                                                      \
   BusyGuard _busy(m);                                                                                           \
@@ -1041,8 +1042,15 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   // log-mel and the encoder of this call touch none of the decoder's buffers, so they start at once beside it instead of behind it;
   // the cross-K/V projection (which overwrites what that step still reads) and everything after it stay on `st`.  st_enc waits for the
   // previous call's cross-K/V projection - the last reader of the encoder's output buffer.
+  // ... but only while this is the ONLY call running on the GPU.  HIP streams share a handful of hardware queues (four by default): with
+  // several replicas decoding at once a second stream per handle puts one replica's encoder and another's decode chain into the same
+  // queue, and the chain waits behind 100 us GEMMs - measured, 8 utterances per batch, 2 / 3 / 4 batches in flight: 130 / 151 / 145
+  // utterances/s with the second stream against 165 / 178 / 165 without.  Under that load the over-run step costs next to nothing anyway
+  // (the GPU is shared; the step is a thin chain).
   static const bool one_stream = getenv("WIS_ONE_STREAM") != nullptr;      // A/B switch
-  hipStream_t se = one_stream ? st : m->st_enc;
+  static const bool two_streams = getenv("WIS_TWO_STREAMS") != nullptr;    // A/B switch: the second stream whatever else runs
+  const bool alone = g_active_calls[m->device & 63].load(std::memory_order_relaxed) <= 1;
+  hipStream_t se = (one_stream || !(alone || two_streams)) ? st : m->st_enc;
   if (se != st) WIS_HIP_CHECK(hipStreamWaitEvent(se, m->ev_ckv, 0));
   WIS_HIP_CHECK(hipEventRecord(m->ev[0], se));
   WIS_RET(stage_input(m, input, o->input_kind, B, se));
