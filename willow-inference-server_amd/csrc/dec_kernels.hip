@@ -421,6 +421,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     const int m = ep_m, n = ep_n;
+    float4 rsum = make_float4(0.f, 0.f, 0.f, 0.f);      // the residual row values this lane stored (statistics partials below)
     if (ep_ok) {
       if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
       if (fast) {   // y = rs * (W' x - mu * c) [+ b' below]
@@ -451,6 +452,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
         const size_t o = (size_t)m * p.N + n;
         if (p.flags & GV_RESID) {
           const float4 r = make_float4(ep_res.x + s.x, ep_res.y + s.y, ep_res.z + s.z, ep_res.w + s.w);
+          rsum = r;
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = r;
           if (p.y16) { const f16x4 h = {(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w}; *reinterpret_cast<f16x4*>(p.y16 + o) = h; }   // f16 copy: next layer's folded cross-Q input
         } else if (p.flags & GV_OUT_F32) {
@@ -460,6 +462,18 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
           *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + o) = h;
         }
       }
+    }
+    // LayerNorm partials of the rows this launch produces (GV_RESID with stat_out: the out-projection in front of the folded cross-attention
+    // query): per (row, 16-column tile) the pair (sum, M2 about the tile mean), as gemv_frag_kernel's residual epilogue leaves them - the
+    // four lanes of a row (kq = 0..3) hold four columns each; whole waves take part in the shuffles.  The consumer merges d / 16 pairs per
+    // row instead of re-reading and re-summing the whole rows in every one of its workgroups.
+    if ((p.flags & GV_RESID) && p.stat_out) {
+      float t1 = ep_ok ? (rsum.x + rsum.y) + (rsum.z + rsum.w) : 0.f;
+      t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+      float t2 = 0.f;
+      if (ep_ok) { const float ml = t1 * 0.0625f, a_ = rsum.x - ml, b_ = rsum.y - ml, c_ = rsum.z - ml, e_ = rsum.w - ml; t2 = (a_ * a_ + b_ * b_) + (c_ * c_ + e_ * e_); }
+      t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+      if ((lane >> 4) == 0 && m < M && rows * nt < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt) * 2) = make_float2(t1, t2);
     }
   }
   stamp(pf, 6);
@@ -1290,8 +1304,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   float4 qc0, qc1, qc2, qc3; float2 pt[2][2];
   const int d4 = d >> 2, ntile = d >> 4;
   if (FOLD == 2) {
-    const float* qp2 = q2 + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
-    qc0 = *reinterpret_cast<const float4*>(qp2); qc1 = *reinterpret_cast<const float4*>(qp2 + 4); qc2 = *reinterpret_cast<const float4*>(qp2 + 32); qc3 = *reinterpret_cast<const float4*>(qp2 + 36);
+    qc0 = qc1 = qc2 = qc3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q2) {      // (uniform: the batched step's second half of q_raw; the one-utterance step's dual launch leaves the whole of it in q)
+      const float* qp2 = q2 + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
+      qc0 = *reinterpret_cast<const float4*>(qp2); qc1 = *reinterpret_cast<const float4*>(qp2 + 4); qc2 = *reinterpret_cast<const float4*>(qp2 + 32); qc3 = *reinterpret_cast<const float4*>(qp2 + 36);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {      // wave w merges the partials of rows w and w + 4: lane = tile (and tile + 64; d <= 2048)
       const int r = wave + 4 * j;
@@ -1329,7 +1346,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // (batched fold: the V fragments are requested BEHIND the query prologue - its column sums, biases, second q half and partials
   // are dead by then, so the kernel stays near the 88 registers of the plain form (five workgroups per CU: the 960 workgroups of an
   // 8-utterance batch in one round) instead of 153 (three per CU); V is not needed before the softmax)
-  if (FOLD != 2) {
+  constexpr bool VLATE = FOLD == 2 && !SPIN;      // (small grids - the granule hand-off's - have CUs to spare: V goes out with everything else)
+  if (!VLATE) {
 #pragma unroll
     for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
   }
@@ -1384,7 +1402,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     qb0 = make_float4(rs * (qb0.x - mu * cs2.x) + bq2.x, rs * (qb0.y - mu * cs2.y) + bq2.y, rs * (qb0.z - mu * cs2.z) + bq2.z, rs * (qb0.w - mu * cs2.w) + bq2.w);
     qb1 = make_float4(rs * (qb1.x - mu * cs3.x) + bq3.x, rs * (qb1.y - mu * cs3.y) + bq3.y, rs * (qb1.z - mu * cs3.z) + bq3.z, rs * (qb1.w - mu * cs3.w) + bq3.w);
   }
-  if (FOLD == 2) {
+  if (VLATE) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
@@ -1594,7 +1612,7 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
                           const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch, const float* q2, int xres_is_stat) {
   if (xres && (!qcs || !qb || R > 8 || d > (xres_is_stat ? 2048 : 1280))) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280 (2048 from partials)"); return WIS_E_ARG; }
-  if (xres_is_stat && (!xres || !q2)) { set_error("dec_cross_attn: the batched fold needs the row partials and the second half of q_raw"); return WIS_E_ARG; }
+  if (xres_is_stat && !xres) { set_error("dec_cross_attn: the fold from partials needs the row partials"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
   if (H > 63 || d > 65535 || T > 65535) { set_error("dec_cross_attn: H=%d d=%d T=%d beyond the packed shape arguments", H, d, T); return WIS_E_UNSUPPORTED; }
   const int CL = cdiv(cdiv(T, chunks), 32) * 32;     // chunk length: multiple of 32 keys (16-byte aligned V^T fragments)

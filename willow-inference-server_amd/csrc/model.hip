@@ -758,9 +758,16 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
       // cross-attention kernel applies the LayerNorm statistics of x1 (rs, mu) and b' to q_raw
       GemvP ga; memset(&ga, 0, sizeof(ga));
       ga.x = m->dao; ga.Wp = w.p_out; ga.bias = w.b_out; ga.y = m->dx; ga.M = M; ga.N = d; ga.K = d; ga.flags = GV_RESID; ga.prof = pr ? pr + 32 : nullptr;
+      // (r5) the out-projection leaves LayerNorm partials of x1 (80 pairs per row); the cross-attention's prologue merges them instead of
+      // every one of its 120 workgroups re-reading and re-summing the five 1280-float rows (WIS_B1_STAT_ROWS=1: the round-2..4 form, A/B)
+      static const bool stat_rows = getenv("WIS_B1_STAT_ROWS") != nullptr;
+      if (!stat_rows) ga.stat_out = m->dstat;
       GemvP gb; memset(&gb, 0, sizeof(gb));
       gb.x = m->dxh; gb.x2 = m->dao; gb.xsplit = d; gb.Wp = w.p_cqo; gb.bias = w.b_cqo; gb.y = m->dq; gb.M = M; gb.N = d; gb.K = 2 * d; gb.flags = GV_OUT_F32;
       WIS_RET(launch_gemv_dual(st, ga, gb));
+      if (!stat_rows) WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
+                                                    m->dstat, w.c_cq, w.b_cq, m->spin_now ? m->ca_gran : nullptr, m->ca_epoch, nullptr, 1));
+      else
       WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
                                     m->dx, w.c_cq, w.b_cq, m->spin_now ? m->ca_gran : nullptr, m->ca_epoch));
     } else {
