@@ -289,10 +289,23 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   const bool ep_ok = ep_act && ep_m < M && ep_n < p.N && 4 * (lane >> 4) < rows;
   float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
   int ep_slot = 0, ep_pos = 0;
+  // GV_LNP (f16 rows + per-16-column (sum, M2) partials of the rows in stat_in): mean / rstd merged Chan-style about the first
+  // tile's mean by the four lanes of a row, a quarter of the K / 16 pairs each - gemv_frag_body's form.  The consumer then needs
+  // neither the fp32 rows (a third of the load instructions of a LayerNorm-folded launch were those) nor a pass over them.
+  const bool lnp = fastx && (p.flags & GV_LNP);
+  constexpr int LNQ = 20;                     // pairs per lane: K / 64 <= 20 (K <= 1280); larger K takes the loop form
+  float2 lnp_pr[LNQ]; float lnp_c = 0.f;
 #define WIS_EP_LOADS()                                                                                              \
+  if (lnp && ep_act) {                                                                                              \
+    const int mm = ep_m < M ? ep_m : M - 1, nq = K >> 6;                                                            \
+    const float2* row = reinterpret_cast<const float2*>(p.stat_in) + (size_t)mm * (K >> 4);                         \
+    const float2* sp = row + (size_t)(lane >> 4) * nq;                                                              \
+    lnp_c = row[0].x * 0.0625f;                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < LNQ; ++i) lnp_pr[i] = sp[i < nq ? i : nq - 1];                            \
+  }                                                                                                                 \
   if (ep_ok) {                                                                                                      \
     if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);                                          \
-    if (fast) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);                                              \
+    if (fast || lnp) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);                                       \
     if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);                                              \
     if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }                    \
     else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n); \
@@ -422,8 +435,21 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
     }
     const int m = ep_m, n = ep_n;
     float4 rsum = make_float4(0.f, 0.f, 0.f, 0.f);      // the residual row values this lane stored (statistics partials below)
+    float lnp_mu = 0.f, lnp_rs = 1.f;
+    if (lnp) {      // whole wave: ((q0 + q1) + (q2 + q3)) of the row's four quarter sums on every lane
+      const int nq = K >> 6;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < LNQ; ++i) if (i < nq) { const float dm = lnp_pr[i].x * 0.0625f - lnp_c; t1 += dm; t2 += lnp_pr[i].y + 16.0f * dm * dm; }
+      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      const float invK = 1.0f / (float)K, dmu = t1 * 16.0f * invK;
+      lnp_mu = lnp_c + dmu;
+      lnp_rs = 1.0f / sqrtf(fmaxf(t2 * invK - dmu * dmu, 0.f) + 1e-5f);
+    }
     if (ep_ok) {
       if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
+      if (lnp) { s.x = lnp_rs * (s.x - lnp_mu * ep_cs.x); s.y = lnp_rs * (s.y - lnp_mu * ep_cs.y); s.z = lnp_rs * (s.z - lnp_mu * ep_cs.z); s.w = lnp_rs * (s.w - lnp_mu * ep_cs.w); }
       if (fast) {   // y = rs * (W' x - mu * c) [+ b' below]
         const int r = m < RMAX ? m : RMAX - 1;
         const float invK = 1.0f / (float)K;
@@ -567,6 +593,10 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
     // folded LayerNorm: raw fp32 rows in registers - at most 8 rows of at most 2048 columns; callers split larger row counts
     // into layernorm_kernel (no affine) + the f16-activation path (model.hip: launch_ln_gemv)
     if (p.M > 8 || p.K > 2048 || KC != p.K || !p.csum) { set_error("gemv: fused LayerNorm needs M <= 8, K <= 2048 and the folded column sums (M=%d K=%d)", p.M, p.K); return WIS_E_UNSUPPORTED; }
+  }
+  if (p.flags & GV_LNP) {
+    if ((p.flags & GV_LN) || p.M > 16 || p.K > 1280 || p.K % 64 || KC != p.K || !p.csum || !p.stat_in || p.M * (p.K / 8) > 13 * 256) {
+      set_error("gemv: the LayerNorm fold from partials needs f16 rows, column sums, partials, M <= 16, K <= 1280 (M=%d K=%d)", p.M, p.K); return WIS_E_UNSUPPORTED; }
   }
   if (MB == 1) {
     if (KC == p.K) {
@@ -1104,8 +1134,37 @@ __global__ void dec_embed_kernel(const f16* __restrict__ emb, const f16* __restr
     if (xh) xh[(size_t)m * d + i] = (f16)v;          // f16 copy of the layer input (fused out-proj + cross-Q stage)
   }
 }
-int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh) {
-  hipLaunchKernelGGL(dec_embed_kernel, dim3(M), dim3(256), 0, st, emb, pos_emb, tok, pos, x, xh, d);
+// the same with the rows' LayerNorm partials (GV_LNP consumers): thread = one 16-column tile of row m
+__global__ void dec_embed_stat_kernel(const f16* __restrict__ emb, const f16* __restrict__ pos_emb, const int* __restrict__ tok,
+                                      const int* __restrict__ pos, float* __restrict__ x, f16* __restrict__ xh, float* __restrict__ stat, int d) {
+  const int m = blockIdx.x, t = threadIdx.x, nt = d >> 4;
+  if (t >= nt) return;
+  const f16x8* e = reinterpret_cast<const f16x8*>(emb + (size_t)tok[m] * d + 16 * t);
+  const f16x8* pe = reinterpret_cast<const f16x8*>(pos_emb + (size_t)pos[m] * d + 16 * t);
+  const f16x8 e0 = e[0], e1 = e[1], p0 = pe[0], p1 = pe[1];
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = (float)e0[i] + (float)p0[i]; v[8 + i] = (float)e1[i] + (float)p1[i]; }
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1 += v[i];
+  const float ml = s1 * 0.0625f;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const float a = v[i] - ml; s2 += a * a; }
+  float4* xo = reinterpret_cast<float4*>(x + (size_t)m * d + 16 * t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xo[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  f16x8 h0, h1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { h0[i] = (f16)v[i]; h1[i] = (f16)v[8 + i]; }
+  f16x8* ho = reinterpret_cast<f16x8*>(xh + (size_t)m * d + 16 * t);
+  ho[0] = h0; ho[1] = h1;
+  *reinterpret_cast<float2*>(stat + ((size_t)m * nt + t) * 2) = make_float2(s1, s2);
+}
+int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh, float* stat) {
+  if (stat && xh && d % 16 == 0 && d / 16 <= 256) hipLaunchKernelGGL(dec_embed_stat_kernel, dim3(M), dim3(((d / 16 + 63) / 64) * 64), 0, st, emb, pos_emb, tok, pos, x, xh, stat, d);
+  else hipLaunchKernelGGL(dec_embed_kernel, dim3(M), dim3(256), 0, st, emb, pos_emb, tok, pos, x, xh, d);
   return WIS_OK;
 }
 

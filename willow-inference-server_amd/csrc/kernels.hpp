@@ -52,7 +52,8 @@ struct RowMeta {
 };
 
 // skinny GEMM (decoder): y = epi(LN?(x) . Wp^T + b), Wp packed in MFMA 16x16x32 A-fragment order
-enum { GV_GELU = 1, GV_RESID = 2, GV_OUT_F32 = 4, GV_LN = 8, GV_QKV = 16 };
+enum { GV_GELU = 1, GV_RESID = 2, GV_OUT_F32 = 4, GV_LN = 8, GV_QKV = 16,
+       GV_LNP = 32 };      // LayerNorm-folded projection on f16 rows whose statistics arrive as per-16-column (sum, M2) partials in stat_in (<= 16 rows)
 struct GemvP {
   const void* x;                 // f32 [M][K] (raw, un-normalised) when GV_LN else f16 [M][K]
   const float* gamma; const float* beta;   // only used by the split path (model.hip launch_ln_gemv); the kernel never reads them
@@ -106,7 +107,7 @@ int launch_pack_gemv8(hipStream_t st, const f16* W, unsigned char* Wp, float* sc
 int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int K, int n_scale, float scale, int rows = 16);
 int gemv_rows_for(int N, int K);     // tile height used for an [N][K] decoder matrix
 
-int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh = nullptr);
+int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh = nullptr, float* stat = nullptr);
 // logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
 // out_mb: 0 = out is row-major f16 [M][d]; > 0 = fragment image with that many 16-row blocks (batched decode)
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,

@@ -740,7 +740,13 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
   // fused out-proj + cross-Q stage (load_weights: cq_fold): f16 decoder weights, <= 8 rows (the LayerNorm-fused row counts)
   const bool fold = m->cq_fold && M <= 8;
-  WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr));
+  // (r5) LayerNorm-folded projections on f16 rows + row partials (GV_LNP) instead of on the fp32 rows (GV_LN): whoever produces residual rows
+  // (the embedding, the cross-attention output projection, FFN2) leaves their f16 copy and per-16-column (sum, M2) pairs, the consuming
+  // projection (QKV, FFN1, the vocabulary) loads 12.8 KB of f16 + 80 pairs per row where it loaded 25.6 KB of fp32 and summed them in
+  // every one of its 240-3242 workgroups - a third of a launch's load instructions were those.  WIS_B1_LN_ROWS=1: the fp32-row form (A/B).
+  static const bool ln_rows = getenv("WIS_B1_LN_ROWS") != nullptr;
+  const bool lnp = fold && !ln_rows && d <= 1280 && d % 64 == 0;
+  WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr, lnp ? m->dstat : nullptr));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
     // stamp rows of this layer's 8 kernels: QKV, self-attn, out, cross-Q, cross-attn, cross-out, FFN1, FFN2
@@ -750,6 +756,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.x = m->dx; g.csum = w.c_qkv; g.Wp = w.p_qkv; g.wscale = w.s_qkv; g.bias = w.b_qkv; g.M = M; g.N = 3 * d; g.K = d;
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
+    if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_QKV; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
@@ -785,22 +792,26 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     }
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
+    if (lnp) { g.y16 = m->dln; g.stat_out = m->dstat; }      // FFN1's input: f16 rows (dln is free at <= 8 rows) + partials
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.csum = w.c_f1; g.Wp = w.p_f1; g.wscale = w.s_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
+    if (lnp) { g.x = m->dln; g.stat_in = m->dstat; g.flags = GV_LNP | GV_GELU; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
     g.x = m->dh; g.Wp = w.p_f2; g.wscale = w.s_f2; g.bias = w.b_f2; g.y = m->dx; g.M = M; g.N = d; g.K = 4 * d; g.flags = GV_RESID; g.prof = pr ? pr + 112 : nullptr;
     g.y16 = fold ? m->dxh : nullptr;             // the next layer's x0 in f16
+    if (lnp) g.stat_out = m->dstat;              // ... and its LayerNorm partials (next layer's QKV / the vocabulary projection)
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
   if (want_logits) {
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = m->dx; g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
+    if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_OUT_F32; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
@@ -1593,6 +1604,8 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;
   const bool frag = M > 8 && !no_frag;          // the route dec_forward takes at this row count
   const int MBf = cdiv(M, 16);
+  static const bool ln_rows = getenv("WIS_B1_LN_ROWS") != nullptr;
+  const bool lnp = !frag && M <= 8 && m->cq_fold && !ln_rows && d <= 1280 && d % 64 == 0;      // dec_forward's choice at this row count
   auto pass = [&](bool count) -> int {
     for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
       const DecLayerW& w = m->dec[l];
@@ -1606,7 +1619,11 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
         g.y = m->logits; g.M = M; g.N = t.N; g.K = t.K; g.flags = (t.ln ? GV_LN : 0) | GV_OUT_F32;
         g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
         if (frag) { g.x = t.K == d ? (const void*)m->dxf : (const void*)m->dhxf; g.xmb = MBf; g.stat_in = m->dstat; WIS_RET(launch_gemv_frag(st, g)); }
-        else { g.x = t.ln ? (const void*)m->dx : (const void*)m->dh; WIS_RET(launch_ln_gemv(m, st, g)); }   // (more than 8 rows, round-1 route: LayerNorm runs as its own launch)
+        else {
+          g.x = t.ln ? (const void*)m->dx : (const void*)m->dh;
+          if (t.ln && lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_OUT_F32; }      // the form dec_forward launches (f16 rows + partials)
+          WIS_RET(launch_ln_gemv(m, st, g));   // (more than 8 rows, round-1 route: LayerNorm runs as its own launch)
+        }
         if (count) { ++launches; bytes += (double)t.N * t.K * (m->w8 ? 1 : 2); }
       }
     }
@@ -1614,7 +1631,11 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
     g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     g.rows = gemv_rows_for(m->cfg.n_vocab, g.K);
     if (frag) { g.x = m->dxf; g.xmb = MBf; g.stat_in = m->dstat; WIS_RET(launch_gemv_frag(st, g)); }
-    else { g.x = m->dx; WIS_RET(launch_ln_gemv(m, st, g)); }
+    else {
+      g.x = m->dx;
+      if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_OUT_F32; }
+      WIS_RET(launch_ln_gemv(m, st, g));
+    }
     if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * (m->w8 ? 1 : 2); }
     return WIS_OK;
   };
@@ -1625,6 +1646,10 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   }
   WIS_HIP_CHECK(hipMemsetAsync(m->dx, 0, (size_t)MAX_ROWS * d * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->dh, 0, (size_t)MAX_ROWS * 4 * d * 2, st));
+  if (lnp) {
+    WIS_HIP_CHECK(hipMemsetAsync(m->dxh, 0, (size_t)MAX_ROWS * d * 2, st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->dstat, 0, (size_t)MAX_ROWS * (d / 16) * 2 * 4, st));
+  }
   WIS_RET(pass(true));   // warm-up pass (also counts launches / bytes)
   // the timed passes run the way the product runs these kernels: captured once into a HIP graph and replayed (wis_generate replays
   // its decode step as a graph); WIS_NO_GRAPH=1 (profilers that cannot follow a capture) falls back to eager launches
