@@ -740,11 +740,13 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
   // fused out-proj + cross-Q stage (load_weights: cq_fold): f16 decoder weights, <= 8 rows (the LayerNorm-fused row counts)
   const bool fold = m->cq_fold && M <= 8;
-  // (r5) LayerNorm-folded projections on f16 rows + row partials (GV_LNP) instead of on the fp32 rows (GV_LN): whoever produces residual rows
-  // (the embedding, the cross-attention output projection, FFN2) leaves their f16 copy and per-16-column (sum, M2) pairs, the consuming
-  // projection (QKV, FFN1, the vocabulary) loads 12.8 KB of f16 + 80 pairs per row where it loaded 25.6 KB of fp32 and summed them in
-  // every one of its 240-3242 workgroups - a third of a launch's load instructions were those.  WIS_B1_LN_ROWS=1: the fp32-row form (A/B).
-  static const bool ln_rows = getenv("WIS_B1_LN_ROWS") != nullptr;
+  // (r5, measured and left OFF) LayerNorm-folded projections on f16 rows + row partials (GV_LNP) instead of on the fp32 rows (GV_LN): whoever
+  // produces residual rows (the embedding, the cross-attention output projection, FFN2) leaves their f16 copy and per-16-column (sum, M2)
+  // pairs, the consuming projection (QKV, FFN1, the vocabulary) loads 12.8 KB of f16 + 80 pairs per row where it loads 25.6 KB of fp32 and
+  // sums them in every workgroup.  Fewer load instructions per launch - and slower: same call, decode step 1.357 against 1.345 ms.  The
+  // fp32-row form reduces its statistics in all four waves in the shadow of the weight stream; the partial form merges them in the one
+  // epilogue wave BEHIND the reduction barrier, i.e. on the critical tail, and the producers' epilogues grow too.  WIS_B1_LNP=1 selects it.
+  static const bool ln_rows = getenv("WIS_B1_LNP") == nullptr;
   const bool lnp = fold && !ln_rows && d <= 1280 && d % 64 == 0;
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr, lnp ? m->dstat : nullptr));
   for (int l = 0; l < c.n_dec_layers; ++l) {
@@ -1604,7 +1606,7 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;
   const bool frag = M > 8 && !no_frag;          // the route dec_forward takes at this row count
   const int MBf = cdiv(M, 16);
-  static const bool ln_rows = getenv("WIS_B1_LN_ROWS") != nullptr;
+  static const bool ln_rows = getenv("WIS_B1_LNP") == nullptr;
   const bool lnp = !frag && M <= 8 && m->cq_fold && !ln_rows && d <= 1280 && d % 64 == 0;      // dec_forward's choice at this row count
   auto pass = [&](bool count) -> int {
     for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
