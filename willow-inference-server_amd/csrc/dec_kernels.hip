@@ -1358,11 +1358,12 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // to the rows the out-projection has produced SINCE (xres = x1, fp32 [B*R][d]).  Every workgroup reduces its utterance's R
   // rows itself (R x d floats from L2, requested together with K and V) and finishes q = rs (q_raw - mu c) + b'.
   // wave w reduces rows w and w + 4 of the utterance (R <= 8): 5 float4 per lane and row cover d <= 1280
+  constexpr bool PSTAT = FOLD >= 2;
   constexpr int NXS = FOLD == 1 ? 5 : 1;
   float4 xs4[2][NXS]; float4 cs0, cs1, cs2, cs3, bq0, bq1, bq2, bq3;
   float4 qc0, qc1, qc2, qc3; float2 pt[2][2];
   const int d4 = d >> 2, ntile = d >> 4;
-  if (FOLD == 2) {
+  if (PSTAT) {
     qc0 = qc1 = qc2 = qc3 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q2) {      // (uniform: the batched step's second half of q_raw; the one-utterance step's dual launch leaves the whole of it in q)
       const float* qp2 = q2 + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
@@ -1405,7 +1406,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // (batched fold: the V fragments are requested BEHIND the query prologue - its column sums, biases, second q half and partials
   // are dead by then, so the kernel stays near the 88 registers of the plain form (five workgroups per CU: the 960 workgroups of an
   // 8-utterance batch in one round) instead of 153 (three per CU); V is not needed before the softmax)
-  constexpr bool VLATE = FOLD == 2 && !SPIN;      // (small grids - the granule hand-off's - have CUs to spare: V goes out with everything else)
+  // FOLD 2 / 3: statistics from row partials; 2 requests V BEHIND the prologue (large grids: registers decide how many workgroups a CU
+  // holds), 3 with everything else (the one-utterance step's 120 workgroups have CUs to spare)
+  constexpr bool VLATE = FOLD == 2;
   if (!VLATE) {
 #pragma unroll
     for (int sidx = 0; sidx < NSTEP; ++sidx) vf[sidx] = *reinterpret_cast<const u32x4*>(vb + 32 * sidx);
@@ -1423,7 +1426,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     for (int j = 0; j < 2; ++j) {
       const int r = wave + 4 * j;
       float a1 = 0.f, a2 = 0.f;
-      if (FOLD == 2) {
+      if (PSTAT) {
         // Chan merge of the (sum, M2 about the tile mean) pairs about c0 = the first tile's mean (gemv_frag_kernel's one-pass form):
         //   mu = c0 + mean_t (m_t - c0),   var = (sum_t (M2_t + 16 (m_t - c0)^2)) / d - (mu - c0)^2
         const float c0 = readlane_f(pt[j][0].x, 0) * 0.0625f;
@@ -1452,7 +1455,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float mu = srow[rq][0], rs = srow[rq][1];
-    if (FOLD == 2) {      // the two halves of q_raw
+    if (PSTAT) {      // the two halves of q_raw (when there are two)
       qa0 = make_float4(qa0.x + qc0.x, qa0.y + qc0.y, qa0.z + qc0.z, qa0.w + qc0.w); qa1 = make_float4(qa1.x + qc1.x, qa1.y + qc1.y, qa1.z + qc1.z, qa1.w + qc1.w);
       qb0 = make_float4(qb0.x + qc2.x, qb0.y + qc2.y, qb0.z + qc2.z, qb0.w + qc2.w); qb1 = make_float4(qb1.x + qc3.x, qb1.y + qc3.y, qb1.z + qc3.z, qb1.w + qc3.w);
     }
@@ -1683,7 +1686,9 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
 #define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, xres, q2, epoch, \
                                                   (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), Tpad, out, part, counters, prof, out_mb, qcs, qb, gran)
   if (xres_is_stat) {
-    if (spin) WIS_CA(4, 6, 2, true); else if (CL <= 128) WIS_CA(2, 16, 2, false); else if (used <= 6) WIS_CA(4, 6, 2, false); else WIS_CA(4, 16, 2, false);
+    const bool small = (long)B * H * used <= 256;      // at most one workgroup per CU: V is requested up front (FOLD 3)
+    if (spin) { if (small) WIS_CA(4, 6, 3, true); else WIS_CA(4, 6, 2, true); }
+    else if (CL <= 128) WIS_CA(2, 16, 2, false); else if (used <= 6) { if (small) WIS_CA(4, 6, 3, false); else WIS_CA(4, 6, 2, false); } else WIS_CA(4, 16, 2, false);
   }
   else if (spin) { if (xres) WIS_CA(4, 6, 1, true); else WIS_CA(4, 6, 0, true); }
   else if (xres) { if (CL <= 128) WIS_CA(2, 16, 1, false); else if (used <= 6) WIS_CA(4, 6, 1, false); else WIS_CA(4, 16, 1, false); }
