@@ -111,6 +111,19 @@ __device__ __forceinline__ void wave_argbest(float& v, int& idx) {
 #define WIS_TAPS 0
 #endif
 // shader-clock stamp of workgroup 0 for the phase profiler
+// A float at a workgroup-uniform address through the scalar data cache, REQUESTED here and waited for by the caller
+// (uniform_load_wait() before the first use).  Written as inline asm on purpose: hipcc sinks an ordinary scalar load to its first use
+// and waits for it there - five dependent scalar round trips in the middle of gemv_body instead of five requests that travel with the
+// kernel's first vector loads - and it does not count asm-issued loads in its own s_waitcnt bookkeeping.  The scalar cache is
+// invalidated at kernel start like the vector L1, so rows written by the previous launch are seen.
+__device__ __forceinline__ float uniform_load_issue_f32(const float* p) {
+  const unsigned long long a = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long long>(p))) |
+                               ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long long>(p) >> 32)) << 32);
+  float v;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ void uniform_load_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
 #if WIS_TAPS
   if (prof) prof[i] = __builtin_amdgcn_s_memtime();

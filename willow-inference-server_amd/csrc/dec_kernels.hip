@@ -244,7 +244,13 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
       }
     }
 #pragma unroll
+    // (the shifts are uniform over the workgroup: fetched through the SCALAR cache - as vector loads they were five of a wave's 25 requests
+    // on the CU's address path, the unit the start of these kernels is bound by)
+#ifdef WIS_CSHIFT_VLOAD      // (A/B build: the round-2..4 form, one vector load per row)
     for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; cshift[r] = reinterpret_cast<const float*>(p.x)[(size_t)rr * K]; }
+#else
+    for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; cshift[r] = uniform_load_issue_f32(reinterpret_cast<const float*>(p.x) + (size_t)rr * K); }
+#endif
   }
   // f16 activations (attention / FFN hidden output of the previous kernel): same idea, up to 13 x 16 B per thread
   // (MB >= 2: up to 48 rows x 1280 columns per chunk = 30 x 16 B per thread; K larger than the chunk is walked chunk by
@@ -315,6 +321,9 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   stamp(pf, 1);
   float sa[RMAX], sb[RMAX];
   if (fast) {
+#ifndef WIS_CSHIFT_VLOAD
+    uniform_load_wait();      // the rows' shifts (requested with the activation rows, long landed)
+#endif
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const int rr = r < M ? r : M - 1;       // clamped rows rewrite row M-1 with identical values (benign)
