@@ -117,8 +117,10 @@ __device__ __forceinline__ void wave_argbest(float& v, int& idx) {
 // kernel's first vector loads - and it does not count asm-issued loads in its own s_waitcnt bookkeeping.  The scalar cache is
 // invalidated at kernel start like the vector L1, so rows written by the previous launch are seen.
 __device__ __forceinline__ float uniform_load_issue_f32(const float* p) {
-  const unsigned long long a = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long long>(p))) |
-                               ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long long>(p) >> 32)) << 32);
+  // (the builtin returns int: both halves go through `unsigned` before they are widened, or a low word with bit 31 set sign-extends into the high one)
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<unsigned long long>(p)));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<unsigned long long>(p) >> 32));
+  const unsigned long long a = (unsigned long long)lo | ((unsigned long long)hi << 32);
   float v;
   asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(a) : "memory");
   return v;
