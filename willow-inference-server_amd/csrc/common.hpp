@@ -125,6 +125,14 @@ __device__ __forceinline__ float uniform_load_issue_f32(const float* p) {
   asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(a) : "memory");
   return v;
 }
+__device__ __forceinline__ unsigned uniform_load_issue_u32(const void* p) {      // (the dword at a 4-byte aligned uniform address)
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<unsigned long long>(p)));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<unsigned long long>(p) >> 32));
+  const unsigned long long a = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  unsigned v;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(a) : "memory");
+  return v;
+}
 __device__ __forceinline__ void uniform_load_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
 #if WIS_TAPS

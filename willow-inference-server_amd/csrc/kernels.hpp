@@ -53,7 +53,8 @@ struct RowMeta {
 
 // skinny GEMM (decoder): y = epi(LN?(x) . Wp^T + b), Wp packed in MFMA 16x16x32 A-fragment order
 enum { GV_GELU = 1, GV_RESID = 2, GV_OUT_F32 = 4, GV_LN = 8, GV_QKV = 16,
-       GV_LNP = 32 };      // LayerNorm-folded projection on f16 rows whose statistics arrive as per-16-column (sum, M2) partials in stat_in (<= 16 rows)
+       GV_LNP = 32,
+       GV_LN16 = 64 };     // LayerNorm-folded projection on f16 rows, statistics taken from those rows in the kernel (<= 8 rows)      // LayerNorm-folded projection on f16 rows whose statistics arrive as per-16-column (sum, M2) partials in stat_in (<= 16 rows)
 struct GemvP {
   const void* x;                 // f32 [M][K] (raw, un-normalised) when GV_LN else f16 [M][K]
   const float* gamma; const float* beta;   // only used by the split path (model.hip launch_ln_gemv); the kernel never reads them

@@ -740,14 +740,16 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
   // fused out-proj + cross-Q stage (load_weights: cq_fold): f16 decoder weights, <= 8 rows (the LayerNorm-fused row counts)
   const bool fold = m->cq_fold && M <= 8;
-  // (r5, measured and left OFF) LayerNorm-folded projections on f16 rows + row partials (GV_LNP) instead of on the fp32 rows (GV_LN): whoever
-  // produces residual rows (the embedding, the cross-attention output projection, FFN2) leaves their f16 copy and per-16-column (sum, M2)
-  // pairs, the consuming projection (QKV, FFN1, the vocabulary) loads 12.8 KB of f16 + 80 pairs per row where it loads 25.6 KB of fp32 and
-  // sums them in every workgroup.  Fewer load instructions per launch - and slower: same call, decode step 1.357 against 1.345 ms.  The
-  // fp32-row form reduces its statistics in all four waves in the shadow of the weight stream; the partial form merges them in the one
-  // epilogue wave BEHIND the reduction barrier, i.e. on the critical tail, and the producers' epilogues grow too.  WIS_B1_LNP=1 selects it.
-  static const bool ln_rows = getenv("WIS_B1_LNP") == nullptr;
-  const bool lnp = fold && !ln_rows && d <= 1280 && d % 64 == 0;
+  // (r5) what the LayerNorm-folded projections (QKV, FFN1, the vocabulary) read - WIS_B1_LN = rows | f16 | partials:
+  //   rows      the fp32 rows (25.6 KB per workgroup at five rows), statistics in all four waves behind the weight stream: rounds 2-4
+  //   f16       (default) the f16 copy of the rows (GV_LN16: 12.8 KB) that whoever produces residual rows leaves next to them (embedding, cross-
+  //             attention output projection, FFN2), statistics from those same values, still in all four waves - a third of a launch's
+  //             requests through the CU's address path gone, nothing added to its tail
+  //   partials  f16 rows + per-16-column (sum, M2) pairs from the producers' epilogues (GV_LNP): fewer requests still, but the merge sits in
+  //             the one epilogue wave BEHIND the reduction barrier - measured slower than `rows` (1.357 against 1.345 ms per step)
+  static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 2 : (!strcmp(e, "rows") ? 0 : (!strcmp(e, "partials") ? 1 : 2)); }();
+  const bool ln_ok = fold && d % 64 == 0 && M * (d / 8) <= 13 * 256;
+  const bool lnp = ln_ok && ln_form == 1 && d <= 1280, ln16 = ln_ok && ln_form == 2 && d <= 2048;
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr, lnp ? m->dstat : nullptr));
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
@@ -759,6 +761,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.flags = GV_LN | GV_QKV; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
     if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_QKV; }
+    if (ln16) { g.x = m->dxh; g.flags = GV_LN16 | GV_QKV; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
@@ -795,12 +798,14 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     memset(&g, 0, sizeof(g));
     g.x = m->dao; g.Wp = w.p_cout; g.wscale = w.s_cout; g.bias = w.b_cout; g.y = m->dx; g.M = M; g.N = d; g.K = d; g.flags = GV_RESID; g.prof = pr ? pr + 80 : nullptr;
     if (lnp) { g.y16 = m->dln; g.stat_out = m->dstat; }      // FFN1's input: f16 rows (dln is free at <= 8 rows) + partials
+    if (ln16) g.y16 = m->dln;
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     // FFN
     memset(&g, 0, sizeof(g));
     g.x = m->dx; g.csum = w.c_f1; g.Wp = w.p_f1; g.wscale = w.s_f1; g.bias = w.b_f1; g.y = m->dh; g.M = M; g.N = 4 * d; g.K = d; g.flags = GV_LN | GV_GELU; g.prof = pr ? pr + 96 : nullptr;
     if (lnp) { g.x = m->dln; g.stat_in = m->dstat; g.flags = GV_LNP | GV_GELU; }
+    if (ln16) { g.x = m->dln; g.flags = GV_LN16 | GV_GELU; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
     memset(&g, 0, sizeof(g));
@@ -814,6 +819,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     GemvP g; memset(&g, 0, sizeof(g));
     g.x = m->dx; g.csum = m->c_proj; g.bias = m->b_proj; g.Wp = m->p_proj; g.wscale = m->s_proj; g.y = m->logits; g.M = M; g.N = m->n_vocab_pad; g.K = d; g.flags = GV_LN | GV_OUT_F32;
     if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_OUT_F32; }
+    if (ln16) { g.x = m->dxh; g.flags = GV_LN16 | GV_OUT_F32; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     WIS_RET(launch_ln_gemv(m, st, g));
   }
@@ -1606,8 +1612,9 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;
   const bool frag = M > 8 && !no_frag;          // the route dec_forward takes at this row count
   const int MBf = cdiv(M, 16);
-  static const bool ln_rows = getenv("WIS_B1_LNP") == nullptr;
-  const bool lnp = !frag && M <= 8 && m->cq_fold && !ln_rows && d <= 1280 && d % 64 == 0;      // dec_forward's choice at this row count
+  static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 2 : (!strcmp(e, "rows") ? 0 : (!strcmp(e, "partials") ? 1 : 2)); }();
+  const bool ln_ok = !frag && M <= 8 && m->cq_fold && d % 64 == 0 && M * (d / 8) <= 13 * 256;      // dec_forward's choice at this row count
+  const bool lnp = ln_ok && ln_form == 1 && d <= 1280, ln16 = ln_ok && ln_form == 2 && d <= 2048;
   auto pass = [&](bool count) -> int {
     for (int l = 0; l < m->cfg.n_dec_layers; ++l) {
       const DecLayerW& w = m->dec[l];
@@ -1624,6 +1631,7 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
         else {
           g.x = t.ln ? (const void*)m->dx : (const void*)m->dh;
           if (t.ln && lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_OUT_F32; }      // the form dec_forward launches (f16 rows + partials)
+          if (t.ln && ln16) { g.x = m->dxh; g.flags = GV_LN16 | GV_OUT_F32; }
           WIS_RET(launch_ln_gemv(m, st, g));   // (more than 8 rows, round-1 route: LayerNorm runs as its own launch)
         }
         if (count) { ++launches; bytes += (double)t.N * t.K * (m->w8 ? 1 : 2); }
@@ -1636,6 +1644,7 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
     else {
       g.x = m->dx;
       if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_OUT_F32; }
+      if (ln16) { g.x = m->dxh; g.flags = GV_LN16 | GV_OUT_F32; }
       WIS_RET(launch_ln_gemv(m, st, g));
     }
     if (count) { ++launches; bytes += (double)m->n_vocab_pad * d * (m->w8 ? 1 : 2); }
@@ -1648,7 +1657,7 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   }
   WIS_HIP_CHECK(hipMemsetAsync(m->dx, 0, (size_t)MAX_ROWS * d * 4, st));
   WIS_HIP_CHECK(hipMemsetAsync(m->dh, 0, (size_t)MAX_ROWS * 4 * d * 2, st));
-  if (lnp) {
+  if (lnp || ln16) {
     WIS_HIP_CHECK(hipMemsetAsync(m->dxh, 0, (size_t)MAX_ROWS * d * 2, st));
     WIS_HIP_CHECK(hipMemsetAsync(m->dstat, 0, (size_t)MAX_ROWS * (d / 16) * 2 * 4, st));
   }
