@@ -747,7 +747,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   //             requests through the CU's address path gone, nothing added to its tail
   //   partials  f16 rows + per-16-column (sum, M2) pairs from the producers' epilogues (GV_LNP): fewer requests still, but the merge sits in
   //             the one epilogue wave BEHIND the reduction barrier - measured slower than `rows` (1.357 against 1.345 ms per step)
-  static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 2 : (!strcmp(e, "rows") ? 0 : (!strcmp(e, "partials") ? 1 : 2)); }();
+  static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 0 : (!strcmp(e, "f16") ? 2 : (!strcmp(e, "partials") ? 1 : 0)); }();
   const bool ln_ok = fold && d % 64 == 0 && M * (d / 8) <= 13 * 256;
   const bool lnp = ln_ok && ln_form == 1 && d <= 1280, ln16 = ln_ok && ln_form == 2 && d <= 2048;
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr, lnp ? m->dstat : nullptr));
@@ -1612,7 +1612,7 @@ int wis_bench_weight_stream(wis_model_t* m, int M, int passes, float* total_ms, 
   static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;
   const bool frag = M > 8 && !no_frag;          // the route dec_forward takes at this row count
   const int MBf = cdiv(M, 16);
-  static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 2 : (!strcmp(e, "rows") ? 0 : (!strcmp(e, "partials") ? 1 : 2)); }();
+  static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 0 : (!strcmp(e, "f16") ? 2 : (!strcmp(e, "partials") ? 1 : 0)); }();
   const bool ln_ok = !frag && M <= 8 && m->cq_fold && d % 64 == 0 && M * (d / 8) <= 13 * 256;      // dec_forward's choice at this row count
   const bool lnp = ln_ok && ln_form == 1 && d <= 1280, ln16 = ln_ok && ln_form == 2 && d <= 2048;
   auto pass = [&](bool count) -> int {
