@@ -226,14 +226,28 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   // LayerNorm-folded path (MODE 1; host-selected, M <= 8, K <= 2048): the raw fp32 rows live in registers, thread owns float4
   // columns k4 = tid, tid + 256 of every row; they are cast to f16 and staged at once, the statistics (single shifted pass,
   // c = x[r][0]: var = E[(x-c)^2] - E[x-c]^2) are reduced AFTER the MFMA loop and meet the accumulators in the epilogue.
-  constexpr bool fast = MODE == 1;
+  // MODE 3 (r5, GV_LN16): the same on the F16 copy of the rows that whoever produces residual rows leaves next to them (12.8 KB per
+  // workgroup instead of 25.6 KB): thread t < K / 8 owns the 16-byte chunk t of every row - five requests per thread in 2.5 waves where
+  // the fp32 form issues ten in four -, stages it as it is, and takes the statistics from those same values (the ones the MFMAs consume).
+  constexpr bool fast = MODE == 1 || MODE == 3;
+  constexpr bool x16 = MODE == 3;
   constexpr int RMAX = fast ? RM : 1;        // RM in {3, 5, 8}: smallest that holds M (rows >= M are clamped duplicates)
   f32x4 xv[RMAX][2];      // (vector type, not HIP's float4 struct: hipcc split each struct load into an overlapping dwordx2 + dwordx3 pair)
+  u32x4 xv16[RMAX];
+  unsigned c16raw[RMAX];      // (whichever set the instantiation does not use is never materialised)
   float cshift[RMAX];
   unsigned long long* pf = (nt == 0 && tid == 0) ? p.prof : nullptr;
   if (tid == 0) tl_begin(p.prof);
   stamp(pf, 0);
-  if (fast) {
+  if (x16) {
+    const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
+    const int k8n16 = K >> 3, t8 = tid < k8n16 ? tid : k8n16 - 1;      // (clamped address: threads >= K / 8 load a valid chunk and drop it)
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; xv16[r] = x8[(size_t)rr * k8n16 + t8]; }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) { const int rr = r < M ? r : M - 1; c16raw[r] = uniform_load_issue_u32(reinterpret_cast<const f16*>(p.x) + (size_t)rr * K); }
+  }
+  if (fast && !x16) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -281,15 +295,6 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
       for (int i = 0; i < NXH; ++i) { const int idx = tid + 256 * i; if (idx < nx) { const int row = WIS_ROW_OF(idx); xh[i] = x8[(size_t)row * k8n + (idx - row * c8)]; } }
     }
   }
-  // GV_LN16 (r5): the LayerNorm-folded projection on the f16 copy of the rows (12.8 KB per workgroup instead of 25.6 KB of fp32: a third of
-  // the fp32 form's requests were those), statistics taken from the SAME f16 values the MFMAs consume, in all four waves while the weight
-  // stream is in flight (shifted by each row's first element, as the fp32 form; reduced behind the MFMA loop, applied in the epilogue)
-  const bool ln16 = fastx && MB == 1 && (p.flags & GV_LN16);
-  unsigned c16raw[8]; float c16[8], sa16[8], sb16[8];
-  if (ln16) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { const int rr = r < M ? r : M - 1; c16raw[r] = uniform_load_issue_u32(reinterpret_cast<const f16*>(p.x) + (size_t)rr * K); }
-  }
   // weight prefetch for chunk 0 (independent of x)
   WT wf[GV_PF];
   {
@@ -320,7 +325,7 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   }                                                                                                                 \
   if (ep_ok) {                                                                                                      \
     if (p.bias) ep_bias = *reinterpret_cast<const float4*>(p.bias + ep_n);                                          \
-    if (fast || lnp || ln16) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);                                       \
+    if (fast || lnp) ep_cs = *reinterpret_cast<const float4*>(p.csum + ep_n);                                       \
     if (W8) ep_sc = *reinterpret_cast<const float4*>(p.wscale + ep_n);                                              \
     if (p.flags & GV_QKV) { if (ep_n >= p.d) { ep_slot = p.slot[ep_m]; ep_pos = p.pos[ep_m]; } }                    \
     else if (p.flags & GV_RESID) ep_res = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.y) + (size_t)ep_m * p.N + ep_n); \
@@ -329,6 +334,22 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   if (ep_early) { WIS_EP_LOADS() }
   stamp(pf, 1);
   float sa[RMAX], sb[RMAX];
+  if (x16) {
+    uniform_load_wait();
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int rr = r < M ? r : M - 1;
+      cshift[r] = (float)__builtin_bit_cast(f16, (unsigned short)(c16raw[r] & 0xFFFFu));
+      sa[r] = 0.f; sb[r] = 0.f;
+      if (tid < (K >> 3)) {
+        *reinterpret_cast<u32x4*>(xs + (size_t)rr * xstr + tid * 8) = xv16[r];
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&xv16[r]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = (float)h[e] - cshift[r]; sa[r] += v; sb[r] += v * v; }
+      }
+    }
+    stamp(pf, 2);
+  } else
   if (fast) {
 #ifndef WIS_CSHIFT_VLOAD
     uniform_load_wait();      // the rows' shifts (requested with the activation rows, long landed)
@@ -350,29 +371,10 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
     }
     stamp(pf, 2);
   } else if (fastx) {
-    if (ln16) {
-      uniform_load_wait();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { c16[r] = (float)__builtin_bit_cast(f16, (unsigned short)(c16raw[r] & 0xFFFFu)); sa16[r] = 0.f; sb16[r] = 0.f; }
-    }
 #pragma unroll
     for (int i = 0; i < NXH; ++i) {
       const int idx = tid + 256 * i;
-      if (idx < nx) {
-        const int row = WIS_ROW_OF(idx), k8 = idx - row * c8;
-        *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i];
-        if (ln16) {
-          float cc = c16[0];
-#pragma unroll
-          for (int q = 1; q < 8; ++q) cc = row == q ? c16[q] : cc;
-          const f16x8 h = *reinterpret_cast<const f16x8*>(&xh[i]);
-          float pa = 0.f, pb = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float v = (float)h[e] - cc; pa += v; pb += v * v; }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { sa16[q] += row == q ? pa : 0.f; sb16[q] += row == q ? pb : 0.f; }
-        }
-      }
+      if (idx < nx) { const int row = WIS_ROW_OF(idx), k8 = idx - row * c8; *reinterpret_cast<u32x4*>(xs + (size_t)row * xstr + k8 * 8) = xh[i]; }
     }
   }
 
@@ -449,15 +451,6 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   // covered by the reductions and the barrier below; requested BEFORE the activations they delayed them and cost more than they saved)
   if (!ep_early) { WIS_EP_LOADS() }
 #undef WIS_EP_LOADS
-  if (ln16) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (r < M) {
-        const float ta = wave_sum(sa16[r]), tb = wave_sum(sb16[r]);
-        if (lane == 0) { sred[wave * 16 + 2 * r] = ta; sred[wave * 16 + 2 * r + 1] = tb; }
-      }
-    }
-  }
   if (fast) {   // LayerNorm statistics of the folded form: reduced here, behind the MFMAs, published with the accumulators
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -495,18 +488,6 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
     }
     if (ep_ok) {
       if (W8) { s.x *= ep_sc.x; s.y *= ep_sc.y; s.z *= ep_sc.z; s.w *= ep_sc.w; }
-      if (ln16) {
-        const int r = m < 8 ? m : 7;
-        const float invK = 1.0f / (float)K;
-        const float A = ((sred[2 * r] + sred[16 + 2 * r]) + (sred[32 + 2 * r] + sred[48 + 2 * r])) * invK;
-        const float Bq = ((sred[2 * r + 1] + sred[17 + 2 * r]) + (sred[33 + 2 * r] + sred[49 + 2 * r])) * invK;
-        float shift = c16[0];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) shift = (r == q) ? c16[q] : shift;
-        const float mu = shift + A;
-        const float rs = 1.0f / sqrtf(fmaxf(Bq - A * A, 0.f) + 1e-5f);
-        s.x = rs * (s.x - mu * ep_cs.x); s.y = rs * (s.y - mu * ep_cs.y); s.z = rs * (s.z - mu * ep_cs.z); s.w = rs * (s.w - mu * ep_cs.w);
-      }
       if (lnp) { s.x = lnp_rs * (s.x - lnp_mu * ep_cs.x); s.y = lnp_rs * (s.y - lnp_mu * ep_cs.y); s.z = lnp_rs * (s.z - lnp_mu * ep_cs.z); s.w = lnp_rs * (s.w - lnp_mu * ep_cs.w); }
       if (fast) {   // y = rs * (W' x - mu * c) [+ b' below]
         const int r = m < RMAX ? m : RMAX - 1;
@@ -657,12 +638,13 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
       set_error("gemv: the LayerNorm fold from partials needs f16 rows, column sums, partials, M <= 16, K <= 1280 (M=%d K=%d)", p.M, p.K); return WIS_E_UNSUPPORTED; }
   }
   if (p.flags & GV_LN16) {
-    if ((p.flags & (GV_LN | GV_LNP)) || p.M > 8 || p.K > 2048 || KC != p.K || !p.csum || p.M * (p.K / 8) > 13 * 256) {
+    if ((p.flags & (GV_LN | GV_LNP)) || p.M > 8 || p.K > 2048 || p.K % 8 || KC != p.K || !p.csum || MB != 1) {
       set_error("gemv: the LayerNorm fold on f16 rows needs column sums, M <= 8, K <= 2048 (M=%d K=%d)", p.M, p.K); return WIS_E_UNSUPPORTED; }
   }
   if (MB == 1) {
     if (KC == p.K) {
       if (p.flags & GV_LN) mode = 1;
+      else if (p.flags & GV_LN16) mode = 3;
       else if (!(p.flags & GV_LN) && p.M * (p.K / 8) <= 13 * 256) mode = 2;
     }
   } else if (!(p.flags & GV_LN) && p.M * (KC / 8) <= 30 * 256) mode = 2;       // register-staged f16 chunks (single or multi chunk)
@@ -682,6 +664,7 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
                                                       case 8: WIS_GV(MBv, MODEv, 8, RMv); break; case 10: WIS_GV(MBv, MODEv, 10, RMv); break; default: WIS_GV(MBv, MODEv, 0, RMv); } } while (0)
   if (MB == 1) {
     if (mode == 1) { if (p.M <= 3) WIS_GV_SC(1, 1, 3); else if (p.M <= 5) WIS_GV_SC(1, 1, 5); else WIS_GV_SC(1, 1, 8); }
+    else if (mode == 3) { if (p.M <= 3) WIS_GV_SC(1, 3, 3); else if (p.M <= 5) WIS_GV_SC(1, 3, 5); else WIS_GV_SC(1, 3, 8); }
     else if (mode == 2) WIS_GV_SC(1, 2, 1); else WIS_GV_SC(1, 0, 1);
   }
   else if (MB == 2) { if (mode == 2) WIS_GV_SC(2, 2, 1); else WIS_GV(2, 0, 0, 1); }
