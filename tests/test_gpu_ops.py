@@ -226,6 +226,32 @@ def test_gemv(lib, M, N, K, flags):
         assert worst < 0.05 * (1 + float(np.abs(ref).max()))          # no single corrupted row hiding inside the L2 norm
 
 
+@pytest.mark.parametrize("K", [384, 512, 1024, 1280])
+def test_gemv_layernorm_on_f16_rows(lib, K):
+    """GV_LN16 (tap flag 64; WIS_B1_LN=f16 in the model): the LayerNorm-folded projection on the F16 copy of the rows - one 16-byte chunk of
+    every row per thread (K / 8 threads: 48 .. 160 of the workgroup's 256, i.e. partial waves), statistics from those f16 values.  Every
+    row count 1..8 (the three register-row instantiations), rows with a common offset, against float64 on the same f16 values."""
+    from wis_hip._lib import DevBuf, check
+    N = 1280
+    for M in range(1, 9):
+        rng = np.random.default_rng(K + M)
+        x = ((rng.standard_normal((M, K)) * 2 + 0.3 + 5.0 * (M % 3))).astype(np.float16)
+        Wt = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
+        bias = rng.standard_normal(N).astype(np.float32)
+        g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32); b = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        x64 = x.astype(np.float64)
+        mu = x64.mean(1, keepdims=True); var = x64.var(1, keepdims=True)
+        Wg = (Wt.astype(np.float32) * g).astype(np.float16).astype(np.float64)
+        ref = ((x64 - mu) / np.sqrt(var + 1e-5)) @ Wg.T + Wt.astype(np.float64) @ b.astype(np.float64) + bias
+        dx, dW, dbias, dg, db = DevBuf.from_numpy(x), DevBuf.from_numpy(Wt), DevBuf.from_numpy(bias), DevBuf.from_numpy(g), DevBuf.from_numpy(b)
+        dy = DevBuf(M * N * 4)
+        check(lib.wis_op_gemv(0, dx.ptr, dg.ptr, db.ptr, dW.ptr, dbias.ptr, dy.ptr, M, N, K, 64 | 4))
+        out = dy.to_numpy(np.float32, (M, N))
+        e = _relerr(out, ref)
+        print(f"gemv + LayerNorm on f16 rows, K{K} M{M}: rel err {e:.3e}")
+        assert e < 2e-3, (K, M, e)
+
+
 @pytest.mark.parametrize("M", [5, 40])
 def test_gemv_layernorm_rows_with_a_large_common_offset(lib, M):
     """A projection behind a LayerNorm on rows whose mean is large against their spread (|mean| = 200, std 2.4): the row

@@ -1775,9 +1775,11 @@ int wis_op_gemv(int device, const void* x, const float* gamma, const float* beta
   hipStream_t st = ctx_stream(c);
   if (flags & GV_QKV) { set_error("wis_op_gemv: flag 16 is internal"); return WIS_E_ARG; }
   const int Npad = cdiv(N, gemv_rows_for(N, K)) * gemv_rows_for(N, K);
-  const bool w8 = flags & 32, ln = flags & GV_LN;
+  // (tap flags: 32 = quantise the matrix to 8 bits per weight first - NOT GV_LNP; 64 = GV_LN16: x is the F16 copy of the rows, LayerNorm folded)
+  const bool w8 = flags & 32, ln16 = (flags & GV_LN16) != 0, ln = (flags & GV_LN) || ln16;
   flags &= ~32;
-  if (ln && (!gamma || !beta)) { set_error("wis_op_gemv: flag 8 needs gamma and beta"); return WIS_E_ARG; }
+  if (ln16 && ((flags & GV_LN) || M > 8 || w8)) { set_error("wis_op_gemv: flag 64 (LayerNorm fold on f16 rows): <= 8 rows, f16 weights, without flag 8"); return WIS_E_ARG; }
+  if (ln && (!gamma || !beta)) { set_error("wis_op_gemv: flags 8 / 64 need gamma and beta"); return WIS_E_ARG; }
   // the same preparation the model loader does: optional LayerNorm fold into a private copy of W / bias, then packing
   f16 *wp = nullptr, *wtmp = nullptr, *xn = nullptr, *xfr = nullptr; float *wsc = nullptr, *b2 = nullptr, *cs = nullptr, *stt = nullptr;
   int rc = WIS_OK;
