@@ -134,6 +134,12 @@ __device__ __forceinline__ unsigned uniform_load_issue_u32(const void* p) {     
   return v;
 }
 __device__ __forceinline__ void uniform_load_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// ... and every value requested that way passes through uniform_load_landed() behind the wait before it is used: hipcc sees no data
+// dependence between the wait and a register it believes was defined by the (long finished) asm statement, and did hoist the f16 -> f32
+// conversion of a shift above the wait - reading the SGPR before the load had written it.  Volatile asm statements keep their order
+// among themselves, and the "+s" operand makes every later use depend on this one.
+__device__ __forceinline__ void uniform_load_landed(float& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void uniform_load_landed(unsigned& v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ void stamp(unsigned long long* prof, int i) {
 #if WIS_TAPS
   if (prof) prof[i] = __builtin_amdgcn_s_memtime();

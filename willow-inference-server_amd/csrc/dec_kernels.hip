@@ -337,6 +337,8 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   if (x16) {
     uniform_load_wait();
 #pragma unroll
+    for (int r = 0; r < RMAX; ++r) uniform_load_landed(c16raw[r]);
+#pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const int rr = r < M ? r : M - 1;
       cshift[r] = (float)__builtin_bit_cast(f16, (unsigned short)(c16raw[r] & 0xFFFFu));
@@ -353,6 +355,8 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   if (fast) {
 #ifndef WIS_CSHIFT_VLOAD
     uniform_load_wait();      // the rows' shifts (requested with the activation rows, long landed)
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) uniform_load_landed(cshift[r]);
 #endif
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
