@@ -294,6 +294,91 @@ def test_streaming_session_schedule_without_gpu():
         s2.feed(pcm[:10])
 
 
+def test_streaming_speculation_schedule_without_gpu():
+    """The interim decodes of a recording that is still one window (<= 30 s) with the model replaced by a stand-in: one every
+    `speculate_every_s` of NEW audio and never two at once, each drafted by the previous hypothesis, the latest handed to the
+    final decode at stop(); none for a beam search, for a language that must be detected on the final audio, past 30 s, or with
+    the interval set to 0 - and the final answer never depends on any of it."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from wis_hip.streaming import StreamingSession
+
+    class Sess(StreamingSession):
+        def __init__(self, models, beam=1, every=2.0, detect=False, gate=None):
+            self.models = models
+            self.model_name, self.task, self.beam_size = "tiny", "transcribe", beam
+            self.detect_language, self.force_language = detect, None
+            self.fixed_new_tokens = 0
+            self._whisper = None
+            self._chunks, self._n = [], 0
+            self._lock, self._pool = threading.Lock(), ThreadPoolExecutor(max_workers=2)
+            self._windows, self._language_job, self._closed, self.eager_windows = {}, None, False, 0
+            self._spec_every, self._spec_n, self._spec_job, self._spec_latest = every, 0, None, None
+            self.spec_runs, self.accepted_draft_tokens = 0, None
+            self.calls, self.gate = [], gate
+
+        def _detect(self, first_window):
+            return "en"
+
+        def _window_tokens(self, piece, beam, language, stream=None, draft=None):
+            if self.gate is not None:
+                self.gate.wait(5)
+            ids = [int(piece.shape[0] // 16000), 7, 8]                    # "transcript": seconds heard, then two fixed ids
+            self.calls.append((piece.shape[0], beam, None if draft is None else list(draft)))
+            self._last_accepted = None if draft is None else sum(1 for a, b in zip(draft, ids) if a == b)
+            return ids
+
+    models = _FakeModels()
+    sec = np.zeros(16000, np.float32)
+
+    def settle(s):
+        if s._spec_job is not None:
+            s._spec_job.result(5)
+
+    # 7 s fed one second at a time, each interim finishing before the next second arrives: interims at 2, 4, 6 s
+    s = Sess(models)
+    for _ in range(7):
+        s.feed(sec)
+        settle(s)
+    assert s.spec_runs == 3 and [(n // 16000, b) for n, b, _ in s.calls] == [(2, 1), (4, 1), (6, 1)]
+    assert [d for _, _, d in s.calls] == [None, [2, 7, 8], [4, 7, 8]]          # each one drafted by the previous hypothesis
+    out = s.stop()
+    assert s.calls[-1] == (7 * 16000, 1, [6, 7, 8]) and out.tokens == [7, 7, 8]
+    assert s.accepted_draft_tokens == 2                                        # ids 7, 8 of the draft survived; the first did not
+
+    # a slow interim: never two in flight, the next one starts only after it finished and covers everything heard by then
+    gate = threading.Event()
+    s = Sess(models, gate=gate)
+    for _ in range(9):
+        s.feed(sec)
+    assert s.spec_runs == 0 and s._spec_job is not None and s._spec_n == 2 * 16000
+    gate.set()
+    settle(s)
+    s.feed(sec)
+    settle(s)
+    assert [(n // 16000) for n, _, _ in s.calls] == [2, 10]
+    s.close()
+
+    # no speculation: beam search, language detection on the final audio, interval 0, the long-audio beam (>= 12 s here)
+    models5 = _FakeModels()
+    for kw, m in ((dict(beam=5), models), (dict(detect=True), models), (dict(every=0.0), models)):
+        s = Sess(m, **kw)
+        for _ in range(6):
+            s.feed(sec)
+        assert s._spec_job is None and s.spec_runs == 0
+        out = s.stop()
+        assert out.tokens == [6, 7, 8] and s.accepted_draft_tokens is None and s.calls[-1][2] is None
+    s = Sess(models5)
+    thr = models5.settings.long_beam_size_threshold // 1000
+    if models5.settings.long_beam_size != 1:
+        for _ in range(thr + 4):
+            s.feed(sec)
+            settle(s)
+        assert all(n // 16000 < thr for n, _, _ in s.calls)                    # interims stop once the final call would use the long beam
+        out = s.stop()
+        assert s.calls[-1][1] == models5.settings.long_beam_size and s.calls[-1][2] is None and s.accepted_draft_tokens is None
+
+
 def _pool_batcher(n_gpus, per_gpu, log, cap=8):
     from wis_hip.batching import MicroBatcher
 
