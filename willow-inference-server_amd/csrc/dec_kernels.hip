@@ -669,7 +669,14 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   if (MB == 1) {
     if (mode == 1) { if (p.M <= 3) WIS_GV_SC(1, 1, 3); else if (p.M <= 5) WIS_GV_SC(1, 1, 5); else WIS_GV_SC(1, 1, 8); }
     else if (mode == 3) { if (p.M <= 3) WIS_GV_SC(1, 3, 3); else if (p.M <= 5) WIS_GV_SC(1, 3, 5); else WIS_GV_SC(1, 3, 8); }
-    else if (mode == 2) WIS_GV_SC(1, 2, 1); else WIS_GV_SC(1, 0, 1);
+    else if (mode == 2) {
+      // K = 4d of the one-utterance step (FFN2: 80 workgroups x 160 KiB of weights): EVERY fragment requested up front (40 per wave:
+      // 160 VGPRs, one workgroup per CU anyway) instead of a ring of 16 - the ring held 64 KiB in flight per CU, and 80 CUs x 64 KiB
+      // over the memory latency is what the stream ran at (WIS_FFN2_RING=1: the ring, for A/B)
+      static const bool ffn2_ring = getenv("WIS_FFN2_RING") && atoi(getenv("WIS_FFN2_RING")) != 0;
+      if (sck == 40 && KC == p.K && !p.wscale && !ffn2_ring) WIS_GV1(1, 2, 40, 1, false);
+      else WIS_GV_SC(1, 2, 1);
+    } else WIS_GV_SC(1, 0, 1);
   }
   else if (MB == 2) { if (mode == 2) WIS_GV_SC(2, 2, 1); else WIS_GV(2, 0, 0, 1); }
   else { if (mode == 2) WIS_GV_SC(3, 2, 1); else WIS_GV(3, 0, 0, 1); }
