@@ -180,7 +180,9 @@ def test_enc_attention(lib, B, T, H):
                                          # K = 4d over four workgroups per n-tile with the in-launch merge (two launches on one set of tickets where nothing accumulates)
                                          (40, 1280, 5120, 4), (96, 1280, 5120, 0), (24, 1024, 4096, 1),
                                          # two n-tiles per workgroup (more than 256 n-tiles behind a folded LayerNorm): int8 weights, the vocabulary shape, ragged rows
-                                         (40, 5120, 1280, 32 | 8 | 1), (80, 51872, 1280, 8 | 4), (33, 8192, 1280, 8 | 4)])
+                                         (40, 5120, 1280, 32 | 8 | 1), (80, 51872, 1280, 8 | 4), (33, 8192, 1280, 8 | 4),
+                                         # the one-utterance step's LayerNorm-folded N = 4d / 3d projections at 4-5 rows (two n-tiles per workgroup of the LDS-staged form)
+                                         (5, 5120, 1280, 8 | 4 | 1), (4, 5120, 1280, 8 | 1), (5, 3840, 1280, 8 | 4), (5, 4096, 1280, 8)])
 def test_gemv(lib, M, N, K, flags):
     from wis_hip._lib import DevBuf, check
     rng = np.random.default_rng(M * 31 + N + K)

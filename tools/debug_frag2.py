@@ -1,5 +1,5 @@
 """Round-3 reproducer of the two-n-tile skinny GEMM's wrong tiles (csrc/dec_kernels.hip gemv_frag2_kernel; cause found in round 4: SLP-packed f32
-epilogue arithmetic at three waves per SIMD on some chips - DESIGN section 4; the kernel is on by default since and this script is clean): LayerNorm-folded
+epilogue arithmetic at three waves per SIMD, on every box the SLP build ran on - DESIGN section 4; the kernel is on by default since and this script is clean): LayerNorm-folded
 projection at 80 rows x 51872 columns through wis_op_gemv, twice in one process, then neighbouring shapes; prints where the result
 leaves the fp64 reference by more than 0.05 (tile index, column within the tile, row blocks).
     WIS_FRAG_NB=2 python tools/debug_frag2.py        # DBG48=1: four launches at 48 rows instead

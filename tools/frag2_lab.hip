@@ -1,9 +1,9 @@
 // Diagnostic bench for the two-n-tile skinny GEMM (csrc/dec_kernels.hip gemv_frag2_kernel: round 3 kept it off because its
 // five-row-block instantiation - 168 VGPRs, 40 KiB LDS: three workgroups per CU - returned sporadically wrong tiles at 80 rows x
 // 51872 columns), and a first stress of the one-tile kernel.  THIS is how round 4 found the cause: built with the library's round-3
-// flags (SLP vectorisation ON: packed-f32 epilogue arithmetic) the `f2` variant below fails on some chips of the pool (12-22 of every
-// 20-40 launches; features 12 and 14 = the low halves of the v_pk_*_f32 results in lanes 48-63) and not on others; built with
-// -fno-slp-vectorize (same 168 registers, same occupancy) or with AGPR accumulators (two waves per SIMD) it is clean on the same chip.
+// flags (SLP vectorisation ON: packed-f32 epilogue arithmetic) the `f2` variant below fails on every box it was run on (12-22 of every
+// 20-40 launches; features 12 and 14 = the low halves of the v_pk_*_f32 results in lanes 48-63); built with
+// -fno-slp-vectorize (same 168 registers, same occupancy) or with AGPR accumulators (two waves per SIMD) it is clean on the same boxes.
 //
 // What it does (80 rows = 5 row blocks, K = 1280, N = 51872, deterministic pseudo-random operands generated on the device):
 //   1. reference = the shipped gemv_frag_kernel<5, 6> alone on the GPU (same MFMA order per wave and same cross-wave sum order as the

@@ -202,8 +202,12 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 #define WIS_EP_EARLY 0
 #endif
 // MODE 0: generic staging from global; 1: fast LayerNorm prologue from registers; 2: fast f16 activations from registers
-template <int MB, int MODE, int SC, int RM, bool W8>
+// NT (r5; MB = 1, single chunk, compile-time SC only): n-tiles per workgroup.  2: waves 0-1 own tile 2 nt, waves 2-3 tile 2 nt + 1, half of
+// K each (SC = K / 64 fragments per wave, all requested up front) - half as many workgroups stage the activation rows, each with twice
+// the weight bytes in flight: N = 4d of the one-utterance step is 160 workgroups (one per CU) instead of 320 on 256 CUs.
+template <int MB, int MODE, int SC, int RM, bool W8, int NT = 1>
 __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const int nt, char* smem) {
+  static_assert(NT == 1 || (NT == 2 && MB == 1 && SC > 0), "two-tile workgroups: <= 16 rows, every fragment prefetched");
   typedef typename WFrag<W8>::T WT;
   constexpr int GV_PF = SC > 0 ? SC : 16;
   constexpr int rows = 16;   // full MFMA A fragments (4/8-row tiles were measured: more workgroups only add prologue work)
@@ -216,11 +220,12 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ksteps = K / 32;
   const int S = SC > 0 ? SC : KC / 128;          // k-steps per wave per chunk
-  const int ksl0 = wave * S;                     // first chunk-local k-step of this wave
+  const int wt = NT == 2 ? wave >> 1 : 0;        // the wave's n-tile within the workgroup
+  const int ksl0 = (NT == 2 ? (wave & 1) : wave) * S;      // first chunk-local k-step of this wave
   // fragment (tile, k-step) = 4*rows 16-byte pieces: piece (kq, row) at kq*rows + row; lanes with row >= rows stay zero
   const bool wact = (lane & 15) < rows;
   const int wstep = 4 * rows;                     // pieces per k-step
-  const WT* wp4 = reinterpret_cast<const WT*>(p.Wp) + (size_t)nt * ksteps * wstep + (lane >> 4) * rows + (lane & 15);
+  const WT* wp4 = reinterpret_cast<const WT*>(p.Wp) + (size_t)(nt * NT + wt) * ksteps * wstep + (lane >> 4) * rows + (lane & 15);
   const WT wzero = WFrag<W8>::zero();
   const int k4n = K >> 2;                        // float4 per row
   // LayerNorm-folded path (MODE 1; host-selected, M <= 8, K <= 2048): the raw fp32 rows live in registers, thread owns float4
@@ -304,8 +309,8 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   }
 
   // epilogue operands (bias, folded column sums, row scales, residual, KV-cache row)
-  const bool ep_act = tid < MB * 64;
-  const int ep_m = (tid >> 6) * 16 + (lane & 15), ep_n = rows * nt + 4 * (lane >> 4);
+  const bool ep_act = tid < MB * NT * 64;        // (NT == 2: wave 0 finishes tile 2 nt, wave 1 tile 2 nt + 1)
+  const int ep_m = NT == 2 ? (lane & 15) : (tid >> 6) * 16 + (lane & 15), ep_n = rows * (nt * NT + (NT == 2 ? (tid >> 6) & 1 : 0)) + 4 * (lane >> 4);
   const bool ep_ok = ep_act && ep_m < M && ep_n < p.N && 4 * (lane >> 4) < rows;
   float4 ep_bias = make_float4(0.f, 0.f, 0.f, 0.f), ep_cs = ep_bias, ep_res = ep_bias, ep_sc = make_float4(1.f, 1.f, 1.f, 1.f);
   int ep_slot = 0, ep_pos = 0;
@@ -468,13 +473,19 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
     *reinterpret_cast<float4*>(red + ((size_t)(wave * MB + mb) * 64 + lane) * 4) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
   stamp(pf, 5);
-  if (tid < MB * 64) {
-    const int mb = tid >> 6, ln = tid & 63;
+  if (tid < MB * NT * 64) {
+    const int mb = NT == 2 ? 0 : tid >> 6, ln = tid & 63;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NT == 2) {      // the two K halves of this wave's tile
+      const int w0 = 2 * (tid >> 6);
+      const float4 t0 = *reinterpret_cast<const float4*>(red + ((size_t)w0 * 64 + ln) * 4), t1 = *reinterpret_cast<const float4*>(red + ((size_t)(w0 + 1) * 64 + ln) * 4);
+      s.x = t0.x + t1.x; s.y = t0.y + t1.y; s.z = t0.z + t1.z; s.w = t0.w + t1.w;
+    } else {
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(w * MB + mb) * 64 + ln) * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
     }
     const int m = ep_m, n = ep_n;
     float4 rsum = make_float4(0.f, 0.f, 0.f, 0.f);      // the residual row values this lane stored (statistics partials below)
@@ -542,7 +553,8 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
       float t2 = 0.f;
       if (ep_ok) { const float ml = t1 * 0.0625f, a_ = rsum.x - ml, b_ = rsum.y - ml, c_ = rsum.z - ml, e_ = rsum.w - ml; t2 = (a_ * a_ + b_ * b_) + (c_ * c_ + e_ * e_); }
       t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
-      if ((lane >> 4) == 0 && m < M && rows * nt < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + nt) * 2) = make_float2(t1, t2);
+      const int tile = nt * NT + (NT == 2 ? (tid >> 6) & 1 : 0);
+      if ((lane >> 4) == 0 && m < M && rows * tile < p.N) *reinterpret_cast<float2*>(p.stat_out + ((size_t)m * (p.N >> 4) + tile) * 2) = make_float2(t1, t2);
     }
   }
   stamp(pf, 6);
@@ -557,11 +569,11 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
 #define WIS_GV_LEAD(q) (q).x, (q).x2, (q).Wp, (q).M, (q).N, (q).K, (q).xsplit
 #define WIS_GV_LEAD_DECL(s) const void* s##x, const void* s##x2, const f16* s##Wp, int s##M, int s##N, int s##K, int s##xsplit
 #define WIS_GV_LEAD_APPLY(q, s) (q).x = s##x; (q).x2 = s##x2; (q).Wp = s##Wp; (q).M = s##M; (q).N = s##N; (q).K = s##K; (q).xsplit = s##xsplit
-template <int MB, int MODE, int SC, int RM, bool W8>
+template <int MB, int MODE, int SC, int RM, bool W8, int NT = 1>
 __global__ __launch_bounds__(256) void gemv_kernel(WIS_GV_LEAD_DECL(l_), int KC, GemvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WIS_GV_LEAD_APPLY(p, l_);
-  gemv_body<MB, MODE, SC, RM, W8>(p, KC, blockIdx.x, smem);
+  gemv_body<MB, MODE, SC, RM, W8, NT>(p, KC, blockIdx.x, smem);
 }
 // Two skinny GEMMs in ONE launch (workgroups [0, nA) run problem A, the rest problem B; both f16-activation, single-chunk,
 // <= 16 rows): the decoder's attention output projection together with the cross-attention query projection folded THROUGH it
@@ -666,6 +678,16 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 #define WIS_GV(MBv, MODEv, SCv, RMv) do { if (p.wscale) WIS_GV1(MBv, MODEv, SCv, RMv, true); else WIS_GV1(MBv, MODEv, SCv, RMv, false); } while (0)
 #define WIS_GV_SC(MBv, MODEv, RMv) do { switch (sc) { case 3: WIS_GV(MBv, MODEv, 3, RMv); break; case 4: WIS_GV(MBv, MODEv, 4, RMv); break; case 6: WIS_GV(MBv, MODEv, 6, RMv); break; \
                                                       case 8: WIS_GV(MBv, MODEv, 8, RMv); break; case 10: WIS_GV(MBv, MODEv, 10, RMv); break; default: WIS_GV(MBv, MODEv, 0, RMv); } } while (0)
+  // two n-tiles per workgroup (gemv_body NT = 2): the LayerNorm-folded projections of the one-utterance step at K = 1280, 4-5 rows, f16 weights;
+  // WIS_GV_NT2 bit 0 = N >= 4096 without the KV-cache epilogue (FFN1: 320 tiles on 256 CUs left a quarter of the CUs with two workgroups;
+  // 160 two-tile workgroups: decode step 1.268 -> 1.250 ms), bit 1 = the QKV projection (240 tiles had a CU each already: 120 fat
+  // workgroups measured SLOWER, 1.292 ms - off).  Default 1.
+  static const int nt2_mask = getenv("WIS_GV_NT2") ? atoi(getenv("WIS_GV_NT2")) : 1;
+  if (MB == 1 && mode == 1 && sc == 10 && p.M > 3 && p.M <= 5 && !p.wscale && rows == 16 && p.N % 32 == 0 && !(p.flags & GV_RESID) &&
+      (((nt2_mask & 1) && !(p.flags & GV_QKV) && p.N >= 4096) || ((nt2_mask & 2) && (p.flags & GV_QKV)))) {
+    hipLaunchKernelGGL((gemv_kernel<1, 1, 20, 5, false, 2>), dim3(p.N / 32), block, lds, st, WIS_GV_LEAD(pp), KC, pp);
+    return WIS_OK;
+  }
   if (MB == 1) {
     if (mode == 1) { if (p.M <= 3) WIS_GV_SC(1, 1, 3); else if (p.M <= 5) WIS_GV_SC(1, 1, 5); else WIS_GV_SC(1, 1, 8); }
     else if (mode == 3) { if (p.M <= 3) WIS_GV_SC(1, 3, 3); else if (p.M <= 5) WIS_GV_SC(1, 3, 5); else WIS_GV_SC(1, 3, 8); }
@@ -1087,13 +1109,15 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
   // the decode time at 8 / 16 utterances.  ON since round 4 (WIS_FRAG_NB=1 keeps one tile per workgroup: A/B switch).  Round 3 kept it
   // off for a sporadic corruption of its five-row-block instantiation (168 VGPRs: three waves per SIMD) - features 12 and 14 of a tile
   // wrong for a whole row block.  Cause, narrowed down in round 4 (tools/frag2_lab.hip, tools/frag_stress.hip): hipcc's SLP pass had
-  // turned the epilogue's f32 arithmetic into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32); on SOME chips of the pool the
+  // turned the epilogue's f32 arithmetic into packed-f32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32); the
   // LOW halves of those packed results (float4 components x and z = features 12 and 14 of the 4-feature group a lane owns) come
-  // out wrong in lanes 48-63 when three such waves share a SIMD - 14-22 of every 40 launches on a failing chip, 10 808 of 96 000
-  // with four launches in flight, none on other chips; the same source built with -fno-slp-vectorize (scalar v_add / v_fma: same 168
-  // registers, same occupancy) is clean on the failing chip (0 of 240 000 launches), as is any form with two waves per SIMD.  This
-  // file is therefore compiled without SLP vectorisation (build.py SOURCE_FLAGS), and tests/test_gpu_stress.py bit-compares 10^4
-  // launches of every shipped instantiation on four streams with the idle-GPU launch.
+  // out wrong in lanes 48-63 when three such waves share a SIMD - 14-22 of every 40 launches, 10 808 of 96 000 with four launches
+  // in flight, on EVERY box the SLP build was run on (round 4 wrote "some chips": its clean runs were of other builds; corrected in
+  // round 5); the same source built with -fno-slp-vectorize (scalar v_add / v_fma: same 168 registers, same
+  // occupancy) is clean (0 of 240 000 launches), as is any form with two waves per SIMD.  The whole library is therefore compiled
+  // without SLP vectorisation (build.py HIP_FLAGS), tools/isa_lint.py fails the build on any MFMA kernel that contains packed-f32
+  // arithmetic, and tests/test_gpu_stress.py bit-compares 10^4 launches of every shipped instantiation on four streams with the
+  // idle-GPU launch.
   static const int env_nb = getenv("WIS_FRAG_NB") ? atoi(getenv("WIS_FRAG_NB")) : 2;
   if (env_nb == 2 && (p.flags & GV_LN) && !(p.flags & GV_RESID) && ks == 1 && (npad / 16) % 2 == 0 && npad / 16 > 256) {
     dim3 g2(npad / 32), blk(256);
