@@ -1142,6 +1142,8 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
 #define WIS_GF(MBv, PFA, PFB) do { \
     if (p.wscale) { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, true>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, true>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); } \
     else { if (s10) hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFA, false>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); else hipLaunchKernelGGL((gemv_frag_kernel<MBv, PFB, false>), grid, block, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, (int)grid.y, p); } } while (0)
+  // (a twelve-deep ring for the K = 4d slices at 33-48 rows, 218 VGPRs: 2.138 vs 2.134 ms per step at 8 utterances - that kernel is bound by
+  // its activation fragments from L2, not by bytes in flight; the one-utterance FFN2, bound by exactly that, takes launch_gemv's SC = 40 form)
   switch (p.xmb) {
     case 1: WIS_GF(1, 10, 8); break;
     case 2: WIS_GF(2, 10, 8); break;
