@@ -1403,7 +1403,8 @@ constexpr unsigned CA_SPIN_LIMIT = 1u << 17;      // sweeps before the combiner 
 // FOLD: 0 = q is the finished query; 1 = folded query, statistics reduced from the rows themselves (xres = x1 fp32 [B*R][d]: the one-utterance
 // step); 2 = folded query of the BATCHED step: q_raw arrives as two halves (q + q2: W'q x0 + W'q bo and (W'q Wo) a, model.hip
 // dec_forward_frag) and the statistics come from the per-16-column (sum, M2) partials the out-projection's residual epilogue left
-// (xres = [B*R][d/16][2]; merged like gemv_frag_kernel merges them) - 80 pairs per row instead of 1280 floats.
+// (xres = [B*R][d/16][2]; merged like gemv_frag_kernel merges them) - 80 pairs per row instead of 1280 floats; 3 = the same with V requested
+// up front (small grids: the one-utterance step); 4 (r5) = 2 with the query's operands handed out through LDS AND V up front (see STG below).
 template <int TPW, int CM, int FOLD, bool SPIN>
 // (argument order as in dec_self_attn_kernel: the first 14 dwords - q, K, V^T, the folded query's rows / second half, the epoch block and
 // the packed shape - are preloaded into SGPRs, so the kernel's first round of requests (q, the statistics' rows, the K fragments) does
@@ -1431,8 +1432,23 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // ---- loads: Q (B operand, lane = (row r, k-quarter)), K fragments, V^T fragments
   const int rq = l15 < R ? l15 : R - 1;
   const float* qp = q + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
-  const float4 qa0_ = *reinterpret_cast<const float4*>(qp), qa1_ = *reinterpret_cast<const float4*>(qp + 4);
-  const float4 qb0_ = *reinterpret_cast<const float4*>(qp + 32), qb1_ = *reinterpret_cast<const float4*>(qp + 36);
+  // STG (FOLD 4, the batched fold with everything requested up front): the query rows (both halves), the folded query's column sums and
+  // its bias - (2 R + 2) x 64 floats that every wave would fetch for itself into 64 VGPRs, sixteen requests per wave - are fetched once
+  // per wave as one 16-byte piece per lane and array (clamped, unconditional) and handed out through LDS behind the prologue's barrier.
+  // What that buys is REGISTERS: the operands no longer sit in VGPRs beside the K fragments while the requests are in flight, so the V
+  // fragments can be requested up front as well and the kernel still fits four workgroups per CU.
+  constexpr bool STG = FOLD == 4;
+  float4 qa0_, qa1_, qb0_, qb1_, stq, stq2, stc;
+  qa0_ = qa1_ = qb0_ = qb1_ = stq = stq2 = stc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!STG) {
+    qa0_ = *reinterpret_cast<const float4*>(qp); qa1_ = *reinterpret_cast<const float4*>(qp + 4);
+    qb0_ = *reinterpret_cast<const float4*>(qp + 32); qb1_ = *reinterpret_cast<const float4*>(qp + 36);
+  } else {
+    const int sr = (tid >> 4) < R ? (tid >> 4) : R - 1;      // thread t < 16 R owns piece (t & 15) of row t >> 4
+    const size_t so = (size_t)(b * R + sr) * d + h * 64 + 4 * (tid & 15);
+    stq = *reinterpret_cast<const float4*>(q + so);
+    if (q2) stq2 = *reinterpret_cast<const float4*>(q2 + so);      // (uniform)
+  }
   unsigned ep_now = 0;
   if (SPIN) ep_now = __hip_atomic_load(epoch + 1 + b * H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // requested with everything else (word 0 is the flag)
   // Folded query (model.hip fused_out_cq): `q` holds q_raw = W'x0 + (W'Wo) a + W'bo of the LayerNorm-folded cross-attention query
@@ -1447,7 +1463,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   const int d4 = d >> 2, ntile = d >> 4;
   if (PSTAT) {
     qc0 = qc1 = qc2 = qc3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q2) {      // (uniform: the batched step's second half of q_raw; the one-utterance step's dual launch leaves the whole of it in q)
+    if (!STG && q2) {      // (uniform: the batched step's second half of q_raw; the one-utterance step's dual launch leaves the whole of it in q)
       const float* qp2 = q2 + (size_t)(b * R + rq) * d + h * 64 + 8 * kq;
       qc0 = *reinterpret_cast<const float4*>(qp2); qc1 = *reinterpret_cast<const float4*>(qp2 + 4); qc2 = *reinterpret_cast<const float4*>(qp2 + 32); qc3 = *reinterpret_cast<const float4*>(qp2 + 36);
     }
@@ -1477,7 +1493,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) kf[i][ks] = *reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8);
   }
-  if (FOLD) {
+  if (STG) {      // threads 0-15 of every wave: the head's 64 column sums, 16-31: its bias
+    stc = *reinterpret_cast<const float4*>(((tid & 16) ? qb : qcs) + h * 64 + 4 * (tid & 15));
+  }
+  if (FOLD && !STG) {
     const float* cp = qcs + h * 64 + 8 * kq; const float* bp = qb + h * 64 + 8 * kq;
     cs0 = *reinterpret_cast<const float4*>(cp); cs1 = *reinterpret_cast<const float4*>(cp + 4); cs2 = *reinterpret_cast<const float4*>(cp + 32); cs3 = *reinterpret_cast<const float4*>(cp + 36);
     bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
@@ -1535,9 +1554,21 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       if (lane == 0 && r < R) { const float ms = a1 / (float)d; srow[r][0] = c0 + ms; srow[r][1] = 1.0f / sqrtf(fmaxf(a2 / (float)d - ms * ms, 0.f) + 1e-5f); }
       }
     }
+    constexpr int SQP = 68;      // row pitch of the staged operands (floats): 16-byte aligned, rows four banks apart
+    __shared__ __attribute__((aligned(16))) float sq[STG ? 10 * SQP : 4];      // rows 0..7: q_raw (both halves added), 8: column sums, 9: bias
+    if (STG) {
+      if (tid < 16 * R) *reinterpret_cast<float4*>(&sq[(tid >> 4) * SQP + 4 * (tid & 15)]) = make_float4(stq.x + stq2.x, stq.y + stq2.y, stq.z + stq2.z, stq.w + stq2.w);
+      if (tid < 32) *reinterpret_cast<float4*>(&sq[(8 + (tid >> 4)) * SQP + 4 * (tid & 15)]) = stc;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float mu = srow[rq][0], rs = srow[rq][1];
-    if (PSTAT) {      // the two halves of q_raw (when there are two)
+    if (STG) {
+      const float* sqr = &sq[rq * SQP + 8 * kq]; const float* scs = &sq[8 * SQP + 8 * kq]; const float* sbq = &sq[9 * SQP + 8 * kq];
+      qa0 = *reinterpret_cast<const float4*>(sqr); qa1 = *reinterpret_cast<const float4*>(sqr + 4); qb0 = *reinterpret_cast<const float4*>(sqr + 32); qb1 = *reinterpret_cast<const float4*>(sqr + 36);
+      cs0 = *reinterpret_cast<const float4*>(scs); cs1 = *reinterpret_cast<const float4*>(scs + 4); cs2 = *reinterpret_cast<const float4*>(scs + 32); cs3 = *reinterpret_cast<const float4*>(scs + 36);
+      bq0 = *reinterpret_cast<const float4*>(sbq); bq1 = *reinterpret_cast<const float4*>(sbq + 4); bq2 = *reinterpret_cast<const float4*>(sbq + 32); bq3 = *reinterpret_cast<const float4*>(sbq + 36);
+    }
+    if (PSTAT && !STG) {      // the two halves of q_raw (when there are two; the staged form added them on the way into LDS)
       qa0 = make_float4(qa0.x + qc0.x, qa0.y + qc0.y, qa0.z + qc0.z, qa0.w + qc0.w); qa1 = make_float4(qa1.x + qc1.x, qa1.y + qc1.y, qa1.z + qc1.z, qa1.w + qc1.w);
       qb0 = make_float4(qb0.x + qc2.x, qb0.y + qc2.y, qb0.z + qc2.z, qb0.w + qc2.w); qb1 = make_float4(qb1.x + qc3.x, qb1.y + qc3.y, qb1.z + qc3.z, qb1.w + qc3.w);
     }
@@ -1769,8 +1800,12 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
                                                   (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), Tpad, out, part, counters, prof, out_mb, qcs, qb, gran)
   if (xres_is_stat) {
     const bool small = (long)B * H * used <= 256;      // at most one workgroup per CU: V is requested up front (FOLD 3)
-    if (spin) { if (small) WIS_CA(4, 6, 3, true); else WIS_CA(4, 6, 2, true); }
-    else if (CL <= 128) WIS_CA(2, 16, 2, false); else if (used <= 6) { if (small) WIS_CA(4, 6, 3, false); else WIS_CA(4, 6, 2, false); } else WIS_CA(4, 16, 2, false);
+    // FOLD 4 (large grids, <= 8 rows): the folded query's operands through LDS, V requested up front (WIS_CA_FOLD4=0: FOLD 2, V behind the prologue)
+    static const bool fold4 = !(getenv("WIS_CA_FOLD4") && atoi(getenv("WIS_CA_FOLD4")) == 0);
+    const bool f4 = fold4 && !small && R <= 8;
+    if (spin) { if (small) WIS_CA(4, 6, 3, true); else if (f4) WIS_CA(4, 6, 4, true); else WIS_CA(4, 6, 2, true); }
+    else if (CL <= 128) WIS_CA(2, 16, 2, false);
+    else if (used <= 6) { if (small) WIS_CA(4, 6, 3, false); else if (f4) WIS_CA(4, 6, 4, false); else WIS_CA(4, 6, 2, false); } else WIS_CA(4, 16, 2, false);
   }
   else if (spin) { if (xres) WIS_CA(4, 6, 1, true); else WIS_CA(4, 6, 0, true); }
   else if (xres) { if (CL <= 128) WIS_CA(2, 16, 1, false); else if (used <= 6) WIS_CA(4, 6, 1, false); else WIS_CA(4, 16, 1, false); }
