@@ -170,6 +170,22 @@ int wis_generate(wis_model_t* m, const float* input, int B, const int32_t* promp
 int wis_generate_draft(wis_model_t* m, const float* input, const int32_t* prompt, int P, const wis_gen_opts_t* opts,
                        const int32_t* draft, int n_draft, int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* accepted);
 
+/* ---- the same for a BEAM SEARCH (round 6; the reference decodes every recording of 12 s or more at long_beam_size = 3, main.py:582-586,
+ * settings.py:14-18 - BASELINE configs[4]'s 29 s fixture included).  The draft is the TRAJECTORY of an earlier search over (most of) the same
+ * audio, as wis_last_trajectory returns it: per step the k live beams it left - draft_tok [n_steps][beam_size] their newest tokens, draft_org
+ * [n_steps][beam_size] the live beam (0 .. beam_size-1 of the step before) each continued from.  While the search over the final window
+ * follows the draft, 16 steps cost ONE decoder pass: the rows of all 16 x beam_size tree nodes go through the decoder together, the steps
+ * are replayed on their logits by the ordinary sampling kernels, and ordinary steps resume behind the first step whose live set differs.
+ * Every step that counts ran the engine's beam step on the logits of its true inputs: the result is the beam search of the final window,
+ * what wis_generate returns for it (up to the summation order of the multi-row passes, as between any two batch shapes).
+ * accepted_steps: steps whose live set equalled the draft's (may be NULL).  n_steps == 0 is wis_generate. */
+int wis_generate_draft_beam(wis_model_t* m, const float* input, const int32_t* prompt, int P, const wis_gen_opts_t* opts,
+                            const int32_t* draft_tok, const int32_t* draft_org, int n_steps,
+                            int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* accepted_steps);
+/* The trajectory of utterance b of the LAST generate call on this handle (any of the three forms; beam_size k of that call): tok / org
+ * [cap_steps][k], *n_steps = steps recorded (the step that ended the search leaves no live set).  Synchronises the handle's stream. */
+int wis_last_trajectory(wis_model_t* m, int b, int32_t* tok, int32_t* org, int cap_steps, int32_t* n_steps);
+
 /* ---- a14: language detection (replaces whisper_model.detect_language(features),
  * main.py:637-643): probabilities over cfg.lang_ids, [B][n_lang]. */
 int wis_detect_language(wis_model_t* m, const float* input, int input_kind, int B, float* lang_probs);
@@ -185,6 +201,12 @@ int wis_debug_logits(wis_model_t* m, const float* input, int input_kind, int B,
  * concurrent requests) instead of the <= 8-row route; B*R <= 96 (MAX_ROWS) */
 int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, int B,
                           const int32_t* dec_in, int T, int R, float* logits);
+/* the decoder pass wis_generate_draft_beam verifies a window with, alone: the tree rows of steps 1 .. n_steps of a beam trajectory (tok / org
+ * [n_steps][beam]: per step the live beams' newest tokens and the beam each continued from) behind `prompt`, in ONE pass (tree self-attention by
+ * ancestor table, cross-attention as row groups over the utterance's one K / V); logits [n_steps][beam][n_vocab]: row (s, j) = what a step fed
+ * tok[s][j] after its chain of ancestors sees - comparable with wis_debug_logits on that chain.  n_steps <= min(16, 96 / beam). */
+int wis_debug_tree_logits(wis_model_t* m, const float* input, int input_kind, const int32_t* prompt, int P, int beam,
+                          const int32_t* tok, const int32_t* org, int n_steps, float* logits);
 
 /* rows a11-a13 on caller-supplied logits: the SAMPLING kernels wis_generate runs after every decoder pass (logits processors,
  * log-softmax statistics, candidate selection, CTranslate2's beam bookkeeping - dec_kernels.hip logit_stats_kernel /

@@ -20,6 +20,13 @@ import torch
 import torch.nn.functional as F
 
 EOT, SOT = 50257, 50258
+# CTranslate2's early exit (patience 1 and length_penalty 0 - never the WIS call, which leaves length_penalty at 1, main.py:687-693):
+# "num_hypotheses": the search ends when the top candidate is finished and `num_hypotheses` (= 1) hypotheses exist - two independent
+# recollections of decoding.cc agree on this form (the round-5 review's and the builder's: `top_beam_finished[i] &&
+# result.hypotheses.size() >= _num_hypotheses`); "max_candidates": rounds 1-5 required round(beam x patience) of them.  The rule is
+# UNPINNED like the rest of the search (no CTranslate2 artefact offline); tests/golden/make_ct2_golden.py holds cases that decide it
+# the day it runs.  The engine's switch is the same constant: csrc/kernels.hpp WIS_EARLY_EXIT_NUM_HYPOTHESES.
+EARLY_EXIT_NEEDS = "num_hypotheses"
 
 
 def _t(w, name):
@@ -172,7 +179,9 @@ class WhisperRef:
         among the first k that is EOT (or any on the last step) is a finished hypothesis - EOT not included, RAW cumulative score
         stored - and its slot continues from the next non-EOT candidate beyond the first k (`secondary_candidates_offset`; none left:
         the slot keeps the EOT candidate).  The utterance ends when round(k * patience) hypotheses exist (allow_early_exit - only for
-        patience 1 and length_penalty 0 - additionally requires the top candidate to be finished), or on the last step.  Hypotheses are
+        patience 1 and length_penalty 0 - ends it as soon as the TOP candidate is finished and `num_hypotheses` (= 1: WIS reads index 0 only)
+        hypotheses exist: with length_penalty 0 nothing still alive can overtake a finished top candidate; UNPINNED, see EARLY_EXIT_NEEDS),
+        or on the last step.  Hypotheses are
         ranked by score / len**length_penalty (C++ float semantics: a zero-length hypothesis scores -inf).
         -> dict(ids, score, hyps [(raw score, tokens)] in registration order, steps, finish_step, trace, trace_full, origins [per
         continued step: the slot every live beam descends from])
@@ -183,6 +192,8 @@ class WhisperRef:
         ncand = 2 * k
         max_cand = max(1, int(round(k * patience)))
         allow_early_exit = (patience == 1 and length_penalty == 0)
+        # hypotheses an early exit needs besides a finished top candidate: EARLY_EXIT_NEEDS (module constant; see its comment)
+        early_need = 1 if EARLY_EXIT_NEEDS == "num_hypotheses" else max_cand
         seqs = [[] for _ in range(k)]
         cum = [0.0] + [float("-inf")] * (k - 1)           # GPU path: beams tiled up front, only the first one live
         last, origin = None, None
@@ -232,7 +243,7 @@ class WhisperRef:
                             choice, second = j, j + 1
                             break
                 nxt.append(choice)
-            finished = is_last or ((top_finished and len(hyps) >= max_cand) if allow_early_exit else len(hyps) >= max_cand)
+            finished = is_last or ((top_finished and len(hyps) >= early_need) if allow_early_exit else len(hyps) >= max_cand)
             if finished:
                 finish_step = step
                 break

@@ -93,13 +93,23 @@ def run_cases(size, golden, large_steps=40):
                 opts = [dict(beam_size=1), dict(beam_size=5), dict(beam_size=3)]
                 if variant == "eot_ramp":
                     opts += [dict(beam_size=5, length_penalty=0.0), dict(beam_size=5, patience=2.0), dict(beam_size=2, patience=2.0, length_penalty=0.0)]
+                    # the early-exit rule (patience 1, length_penalty 0: oracle/whisper_ref.py EARLY_EXIT_NEEDS).  With num_hypotheses = 1 both
+                    # candidate rules return the SAME best hypothesis (raw scores only fall, so nothing found after a finished top candidate
+                    # can beat it - tests/test_oracle_whisper.py::test_early_exit_rules_agree_on_the_best_hypothesis): what decides between
+                    # them is the hypothesis LIST, so these cases ask for several (records keep every returned sequence)
+                    opts += [dict(beam_size=5, length_penalty=0.0, num_hypotheses=5), dict(beam_size=3, length_penalty=0.0, num_hypotheses=3),
+                             dict(beam_size=8, length_penalty=0.0, num_hypotheses=8)]
                 else:            # seeded weights never choose EOT: bound the run (max_new = min(max_length // 2, max_length - 4))
                     opts = [dict(o, max_length=2 * large_steps if size == "large" else 2 * 24) for o in opts]
                 for prompt in (PROMPTS if variant == "eot_ramp" else PROMPTS[:1]):
                     for o in opts:
                         r = model.generate(feats, [prompt], return_scores=True, **o)[0]
-                        out.append(dict(size=size, variant=variant, clip=clip, kind="generate", prompt=prompt, options=o,
-                                        ids=[int(t) for t in r.sequences_ids[0]], score=float(r.scores[0])))
+                        rec = dict(size=size, variant=variant, clip=clip, kind="generate", prompt=prompt, options=o,
+                                   ids=[int(t) for t in r.sequences_ids[0]], score=float(r.scores[0]))
+                        if o.get("num_hypotheses", 1) > 1:      # (fewer than asked for = the search ended early: that count IS the rule)
+                            rec["all_ids"] = [[int(t) for t in q] for q in r.sequences_ids]
+                            rec["all_scores"] = [float(x) for x in r.scores]
+                        out.append(rec)
             del model
     golden.extend(out)
 

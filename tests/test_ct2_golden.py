@@ -54,6 +54,12 @@ def test_oracle_reproduces_ctranslate2():
                                          patience=o.get("patience", 1.0), return_trace=True)
         checked += 1
         exact += ids == r["ids"]
+        if "all_ids" in r:
+            # the early-exit rule (oracle/whisper_ref.py EARLY_EXIT_NEEDS): CTranslate2 returns min(num_hypotheses, hypotheses found) sequences,
+            # so the count says when ITS search stopped; the oracle's list under the configured rule must be as long
+            want = min(o["num_hypotheses"], len(ref.last_hyps))
+            if min(trace) > MARGIN:
+                assert len(r["all_ids"]) == want, ("early-exit rule: CTranslate2 returned", len(r["all_ids"]), "hypotheses, the oracle holds", len(ref.last_hyps), o)
         if min(trace) > MARGIN:
             assert ids == r["ids"], (r["size"], r["variant"], o, ids, r["ids"])
             assert abs(score - r["score"]) <= 1e-3 * max(1.0, abs(r["score"]))
@@ -65,7 +71,7 @@ def test_oracle_reproduces_ctranslate2():
 def test_engine_reproduces_ctranslate2():
     import torch  # noqa: F401
     from wis_hip import ctranslate2 as ct2, weights as W
-    recs = [r for r in _records() if r["kind"] == "generate" and r["size"] in ("tiny", "base")]
+    recs = [r for r in _records() if r["kind"] == "generate" and r["size"] in ("tiny", "base") and r["options"].get("num_hypotheses", 1) == 1]
     models, exact = {}, 0
     for r in recs:
         key = (r["size"], r["variant"])

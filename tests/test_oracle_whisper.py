@@ -178,7 +178,10 @@ def test_search_eot_mid_search_hand_computed():
     assert r["finish_step"] == 2
     assert r["origins"] == [[0, 0], [0, 1]]                                # slot 0 of step 1 was refilled from beam 0's next candidate
     r0 = WhisperRef.search(_table_fn(table), 2, 5, 4, max_new=4, length_penalty=0.0)
-    assert r0["ids"] == [0] and abs(r0["score"] - np.log(.30)) < 1e-6 and r0["finish_step"] == 2
+    # (early exit, patience 1 and length_penalty 0: the top candidate of step 1 is the finished hypothesis A - under the num_hypotheses rule
+    # the search stops right there, under the max_candidates rule it goes on to step 2 for a second hypothesis; same answer either way)
+    import oracle.whisper_ref as WR
+    assert r0["ids"] == [0] and abs(r0["score"] - np.log(.30)) < 1e-6 and r0["finish_step"] == (1 if WR.EARLY_EXIT_NEEDS == "num_hypotheses" else 2)
     # patience 2 -> four hypotheses wanted: the run goes to the last step, where every one of the k candidates is registered with
     # its last token (no EOT): slot 0 = [1, 0, 3], slot 1 = [1, 0, 2] after step 2 (the refill takes (s1, 3), slot 1 keeps (s1, 2))
     r2 = WhisperRef.search(_table_fn(table), 2, 5, 4, max_new=4, patience=2.0)
@@ -192,6 +195,31 @@ def test_search_eot_mid_search_hand_computed():
     # by the length; WIS never sees this because suppress_blank masks EOT at the first step)
     e = WhisperRef.search(_table_fn([[[.1, .1, .1, .1, .6]]]), 1, 5, 4, max_new=5)
     assert e["ids"] == [] and e["score"] == float("-inf")
+
+
+def test_early_exit_rules_agree_on_the_best_hypothesis(monkeypatch):
+    """CTranslate2's early exit (patience 1, length_penalty 0) is restated from recall in two candidate forms (oracle/whisper_ref.py
+    EARLY_EXIT_NEEDS).  With one returned hypothesis they cannot differ in the ANSWER: raw cumulative scores only fall along a beam, so
+    once the top candidate of a step is a finished hypothesis nothing found later beats it - the rules differ in when the search stops
+    (and in the hypothesis list).  Random tables whose EOT probability climbs, beams 2 / 3 / 5."""
+    import oracle.whisper_ref as WR
+    rng = np.random.default_rng(7)
+    stopped_earlier = 0
+    for case in range(60):
+        k = (2, 3, 5)[case % 3]
+        V, eot, steps = 12, 11, 14
+        table = rng.random((steps, k, V)).astype(np.float64) + 1e-3
+        table[:, :, eot] *= np.linspace(0.05, 6.0, steps)[:, None] * rng.uniform(0.5, 1.5)
+        table /= table.sum(-1, keepdims=True)
+        out = {}
+        for rule in ("num_hypotheses", "max_candidates"):
+            monkeypatch.setattr(WR, "EARLY_EXIT_NEEDS", rule)
+            out[rule] = WhisperRef.search(_table_fn(table.tolist()), k, V, eot, max_new=steps, length_penalty=0.0)
+        a, b = out["num_hypotheses"], out["max_candidates"]
+        assert a["ids"] == b["ids"] and abs(a["score"] - b["score"]) < 1e-6, (case, a["ids"], b["ids"])
+        assert a["finish_step"] <= b["finish_step"] and len(a["hyps"]) <= len(b["hyps"])
+        stopped_earlier += a["finish_step"] < b["finish_step"]
+    assert stopped_earlier >= 10          # the rules DO differ in when they stop on these tables
 
 
 def test_generate_ends_on_eot_by_itself(setup):

@@ -1259,9 +1259,14 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 // the utterance's first slot).
 // (argument order: everything the first round of loads needs - q, the caches, the row table, the shape - sits in the first 14
 // dwords, which -amdgpu-kernarg-preload-count delivers in SGPRs at wave launch; `out` and the taps are only read at the end)
+// TREE (draft verification of a beam search, model.hip verify_beam_draft): the rows of the pass are nodes of a beam tree - row m's history is not
+// one slot but a path: positions < w0 in slot anc[m * aw], position w0 + t in slot anc[m * aw + t] (each node's K / V sits in the slot of the beam
+// that produced it).  One dependent load more than the plain form, on a path that runs once per 16 steps.
+template <bool TREE>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
                                                            const int* __restrict__ pos, int d, int ctx, int rpu, int sstride, int rmul,
-                                                           f16* __restrict__ out, unsigned long long* prof, int out_mb) {
+                                                           f16* __restrict__ out, unsigned long long* prof, int out_mb,
+                                                           const int* __restrict__ anc, int w0, int aw) {
   __shared__ float red[4][64];
   const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, pl = lane >> 3, c = lane & 7;
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
@@ -1270,8 +1275,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   // the row's history lives in ITS OWN slot (kv_reorder_kernel made it so after the last beam step): the K / V addresses of the
   // first 64 positions depend on nothing that has to be loaded, so q, the row's length and all of K and V travel in ONE round
   // trip (positions >= len are fetched from valid memory and masked below)
-  const int ls = (m / rpu) * sstride + (m % rpu) * rmul;
+  const int ls = TREE ? anc[(size_t)m * aw] : (m / rpu) * sstride + (m % rpu) * rmul;
   const int len = pos[m] + 1;
+  // slot that holds position p of this row's history
+  auto slot_of = [&](int p) -> int {
+    if (!TREE) return ls;
+    int t = p - w0; t = t < aw - 1 ? t : aw - 1;
+    return t <= 0 ? ls : anc[(size_t)m * aw + t];
+  };
   const float4 q0 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c);
   const float4 q1 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c + 4);
   const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -1279,10 +1290,20 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   const f16* krow = kc + (size_t)ls * ctx * d + hoff;
   const f16* vrow = vc + (size_t)ls * ctx * d + hoff;
   u32x4 kr[8], vr[8];
+  if (!TREE) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)(8 * i + pl) * d);      // ctx >= 64: in bounds
+    for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)(8 * i + pl) * d);      // ctx >= 64: in bounds
 #pragma unroll
-  for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(8 * i + pl) * d);
+    for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(8 * i + pl) * d);
+  } else {
+    int sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sl[i] = slot_of(8 * i + pl);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)sl[i] * ctx + 8 * i + pl) * d + hoff);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)sl[i] * ctx + 8 * i + pl) * d + hoff);
+  }
   stamp(pf, 1);
   float m_run = -INFINITY, l_run = 0.f;
   float acc[8];
@@ -1297,8 +1318,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int p = p0 + 8 * i + pl, pc = p < len ? p : len - 1;
-        kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)pc * d);
-        vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)pc * d);
+        if (!TREE) {
+          kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)pc * d);
+          vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)pc * d);
+        } else {
+          const int sl = slot_of(pc);
+          kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)sl * ctx + pc) * d + hoff);
+          vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)sl * ctx + pc) * d + hoff);
+        }
       }
     }
     float sc[8]; float mx = -INFINITY;
@@ -1351,9 +1378,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   if (lane == 0) tl_end(prof);
 }
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
-                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof, int out_mb) {
+                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof, int out_mb,
+                         const int* anc, int w0, int aw) {
   if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb);
+  if (anc) {
+    if (aw < 1) { set_error("dec_self_attn: ancestor table of width %d", aw); return WIS_E_ARG; }
+    hipLaunchKernelGGL(dec_self_attn_kernel<true>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw);
+  } else
+    hipLaunchKernelGGL(dec_self_attn_kernel<false>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw);
   return WIS_OK;
 }
 
@@ -1411,7 +1443,7 @@ template <int TPW, int CM, int FOLD, bool SPIN>
 // not wait for a kernarg fetch; what needs the later arguments - column sums / bias of the folded query, V^T's pitch - is requested behind them)
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
                                                              const float* __restrict__ xres, const float* __restrict__ q2, unsigned* epoch, int RHCC, int dT,
-                                                             int Tpad, f16* __restrict__ out, float* part, unsigned* counters,
+                                                             int TpadF, f16* __restrict__ out, float* part, unsigned* counters,
                                                              unsigned long long* prof, int out_mb,
                                                              const float* __restrict__ qcs, const float* __restrict__ qb, gran_t* gran) {
   // rows | heads << 8 | chunk length << 14 | chunks << 24, d | T << 16: six pointers + two words = the 14 preloaded dwords
@@ -1424,6 +1456,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
   const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // bit 30 of the V^T pitch argument: the row groups b = 0 .. B-1 are rows of ONE utterance (draft verification: up to 96 tree rows
+  // against utterance 0's K / V); queries, outputs, partials and tickets stay per group
+  const int Tpad = TpadF & 0x3FFFFFFF, bkv = (TpadF >> 30) ? 0 : b;
   const int klo = c * CL, n = (klo + CL <= T) ? CL : T - klo;   // 1 <= n <= 256, klo % 32 == 0
   unsigned long long* pf = (c == 0 && h == 0 && b == 0 && tid == 0) ? prof : nullptr;
   if (tid == 0) tl_begin(prof);
@@ -1485,7 +1520,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     }
   }
   // (K fragments: addressed from preloaded arguments only, so they go out before the first wait for a scalar kernarg load)
-  const f16* kb = kx + (size_t)(b * H + h) * 8 * T * 8;
+  const f16* kb = kx + (size_t)(bkv * H + h) * 8 * T * 8;
   u32x4 kf[TPW][2];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
@@ -1502,7 +1537,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     bq0 = *reinterpret_cast<const float4*>(bp); bq1 = *reinterpret_cast<const float4*>(bp + 4); bq2 = *reinterpret_cast<const float4*>(bp + 32); bq3 = *reinterpret_cast<const float4*>(bp + 36);
   }
   constexpr int NSTEP = 2 * TPW;                      // 32-key P.V steps per chunk; V^T is zero padded up to Tpad >= chunks * CL
-  const f16* vb = vt + ((size_t)(b * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
+  const f16* vb = vt + ((size_t)(bkv * H + h) * 64 + 16 * wave + l15) * Tpad + klo + 8 * kq;
   u32x4 vf[NSTEP];
   // (batched fold: the V fragments are requested BEHIND the query prologue - its column sums, biases, second q half and partials
   // are dead by then, so the kernel stays near the 88 registers of the plain form (five workgroups per CU: the 960 workgroups of an
@@ -1785,7 +1820,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
 
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
-                          const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch, const float* q2, int xres_is_stat) {
+                          const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch, const float* q2, int xres_is_stat, int kv_shared) {
   if (xres && (!qcs || !qb || R > 8 || d > (xres_is_stat ? 2048 : 1280))) { set_error("dec_cross_attn: folded query needs column sums, bias, R <= 8 and d <= 1280 (2048 from partials)"); return WIS_E_ARG; }
   if (xres_is_stat && !xres) { set_error("dec_cross_attn: the fold from partials needs the row partials"); return WIS_E_ARG; }
   if (R < 1 || R > 16 || chunks < 1 || chunks > 16) { set_error("dec_cross_attn: R=%d chunks=%d unsupported", R, chunks); return WIS_E_UNSUPPORTED; }
@@ -1797,7 +1832,7 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
   // granule hand-off: small grids only (fewer spinning combiners than CUs), the default 256-key chunking, <= 8 rows per utterance
   const bool spin = env_spin && gran && epoch && B * H <= CA_SPIN_MAX_BH && CL == 256 && used >= 2 && used <= 6 && R <= 8;
 #define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, xres, q2, epoch, \
-                                                  (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), Tpad, out, part, counters, prof, out_mb, qcs, qb, gran)
+                                                  (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), (Tpad | (kv_shared ? (1 << 30) : 0)), out, part, counters, prof, out_mb, qcs, qb, gran)
   if (xres_is_stat) {
     const bool small = (long)B * H * used <= 256;      // at most one workgroup per CU: V is requested up front (FOLD 3)
     // FOLD 4 (large grids, <= 8 rows): the folded query's operands through LDS, V requested up front (WIS_CA_FOLD4=0: FOLD 2, V behind the prologue)
@@ -2093,7 +2128,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     n_newhyp = newh;
     bs.n_hyp[b] = nh;
     bool fin = is_last;
-    if (!fin) fin = cfg.allow_early_exit ? (top_finished && nh >= cfg.max_candidates) : (nh >= cfg.max_candidates);
+    if (!fin) fin = cfg.allow_early_exit ? (top_finished && nh >= cfg.early_exit_hyps) : (nh >= cfg.max_candidates);
     s_finished = fin ? 1 : 0;
   }
   __syncthreads();
@@ -2147,6 +2182,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
       al[hist] = nb_tok[j];
       // KV slot this beam continues from: the merged prefill + first step left the prompt's K/V in the utterance's first slot
       bs.parent[r0 + j] = (step == 0) ? r0 : r0 + org;
+      { int* tr = bs.traj + ((size_t)(b * 256 + step) * MAX_R + j) * 2; tr[0] = nb_tok[j]; tr[1] = org; }      // the search's trajectory (a later call's draft)
       bs.cum[r0 + j] = nb_cum[j];
       rm.tok[r0 + j] = nb_tok[j];
       rm.pos[r0 + j] = npos;
@@ -2163,6 +2199,27 @@ int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, c
   if (cfg.beam > MAX_R || cfg.n_cand > MAX_CAND || cfg.max_new > 256 || ctx > 512 || cfg.n_vocab > (1 << 20)) { set_error("beam_step: config out of range"); return WIS_E_UNSUPPORTED; }
   if (cfg.beam * STAT_SUB * cfg.n_cand <= 16 * 256) hipLaunchKernelGGL(beam_step_kernel<16>, dim3(B), dim3(256), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
   else hipLaunchKernelGGL(beam_step_kernel<32>, dim3(B), dim3(256), 0, st, st_max, st_sum, st_val, st_idx, bs, rm, P, ctx, cfg, prof);
+  return WIS_OK;
+}
+
+// =======================================================================================
+// Draft verification at beam > 1 (model.hip verify_beam_draft; one utterance): a window of replayed beam steps is queued WITHOUT host round
+// trips; this one-thread kernel behind every replayed step compares the live set the step produced (tokens + the slots they continued from,
+// as beam_step_kernel recorded them in bs.traj) with the draft's entry for that step.  Equal: the rows the window fed for the NEXT step were
+// the right ones - go on.  Different, or no draft entry left: the step itself stands (its inputs were verified), but nothing behind it
+// does - done = 2 parks the search (beam_step_kernel and kv_reorder_kernel return at their `done` test) until the host resumes it.
+__global__ void draft_check_kernel(BeamState bs, const int* __restrict__ draft, int n_draft, int k, int* __restrict__ vstate) {
+  if (threadIdx.x != 0 || bs.done[0]) return;
+  const int s = bs.step_u[0] - 1;            // the step that just completed
+  bool ok = s >= 0 && s < n_draft;
+  if (ok) {
+    const int* tr = bs.traj + (size_t)s * MAX_R * 2; const int* dr = draft + (size_t)s * MAX_R * 2;
+    for (int j = 0; j < k; ++j) ok = ok & (tr[2 * j] == dr[2 * j]) & (tr[2 * j + 1] == dr[2 * j + 1]);
+  }
+  if (ok) vstate[0] = s + 1; else bs.done[0] = 2;
+}
+int launch_draft_check(hipStream_t st, const BeamState& bs, const int* draft, int n_draft, int beam, int* vstate) {
+  hipLaunchKernelGGL(draft_check_kernel, dim3(1), dim3(64), 0, st, bs, draft, n_draft, beam, vstate);
   return WIS_OK;
 }
 

@@ -111,8 +111,11 @@ int gemv_rows_for(int N, int K);     // tile height used for an [N][K] decoder m
 int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const int* tok, const int* pos, float* x, int M, int d, f16* xh = nullptr, float* stat = nullptr);
 // logical slot of row m = (m / rpu) * sstride + (m % rpu) * rmul
 // out_mb: 0 = out is row-major f16 [M][d]; > 0 = fragment image with that many 16-row blocks (batched decode)
+// anc (optional; draft verification at beam > 1, model.hip verify_beam_draft): the rows of a pass are the nodes of a beam TREE - row m reads
+// the cache rows of positions < w0 from slot anc[m * aw] and position w0 + t from slot anc[m * aw + t] (its ancestor at window step t)
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
-                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr, int out_mb = 0);
+                         int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr, int out_mb = 0,
+                         const int* anc = nullptr, int w0 = 0, int aw = 0);
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 // gran / epoch (optional): the granule hand-off of small grids (dec_kernels.hip, SPIN): gran = 8-byte slots [B*H][6][8][66], epoch =
@@ -122,13 +125,21 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof = nullptr, int out_mb = 0,
                           const float* xres = nullptr, const float* qcs = nullptr, const float* qb = nullptr,   // folded query: see the kernel
                           unsigned long long* gran = nullptr, unsigned* epoch = nullptr,
-                          const float* q2 = nullptr, int xres_is_stat = 0);   // batched fold: q = q + q2; xres = row partials [B*R][d/16][2] instead of the rows
+                          const float* q2 = nullptr, int xres_is_stat = 0,    // batched fold: q = q + q2; xres = row partials [B*R][d/16][2] instead of the rows
+                          int kv_shared = 0);      // 1: every row group b reads utterance 0's K / V (the B groups are rows of ONE utterance: draft verification)
 
 // sampling: per-(row, chunk) masked max / sum-exp / top-2k of the logits
 struct SampleCfg {
   int n_vocab, n_vocab_pad, eot, beam, n_cand, max_new, fixed_new, suppress_blank, greedy;
   float length_penalty; int max_hyp; int allow_early_exit; int max_candidates;
+  int early_exit_hyps;      // finished hypotheses an early exit needs besides a finished top candidate (WIS_EARLY_EXIT_NUM_HYPOTHESES)
 };
+// CTranslate2's early exit (patience 1, length_penalty 0): `top_beam_finished && hypotheses.size() >= num_hypotheses` (1: the product
+// returns one hypothesis) - or, with 0 here, `>= max_candidates` as rounds 1-5 had it.  Unpinned either way (no CTranslate2 offline);
+// the oracle's switch is oracle/whisper_ref.py EARLY_EXIT_NEEDS, the deciding cases are in tests/golden/make_ct2_golden.py.
+#ifndef WIS_EARLY_EXIT_NUM_HYPOTHESES
+#define WIS_EARLY_EXIT_NUM_HYPOTHESES 1
+#endif
 constexpr int STAT_SUB = 64;      // sub-chunks per logits row (one wave each): statistics and top-n_cand candidates per sub-chunk
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
                        float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg,
@@ -149,6 +160,8 @@ struct BeamState {
   unsigned* tick;                 // device [4]: {workgroups of beam_step_kernel that ended since init, call generation, step at which all_done reached B, -}
   const unsigned* giveup;         // word 0 of the cross-attention hand-off's epoch block (a combiner's bounded spin ran out)
   unsigned long long* host;       // device address of the HOST-mapped (fine-grained) progress block, layout HP_* below
+  int* traj;                      // [B][256 steps][MAX_R][2]: (token, beam slot it continued from) of every live beam after each step - the search's
+                                  // trajectory, what a later call verifies as its DRAFT (wis_last_trajectory / wis_generate_draft_beam)
 };
 // host-mapped progress block (uint64 words).  The workgroup of a beam step that ends LAST writes HP_REC with one system-scope
 // release store after everything else of the step - finished utterances' results included - has been made visible to the host.
@@ -167,6 +180,10 @@ __host__ __device__ inline int* hp_out_ids(unsigned long long* hp) { return rein
 int launch_kv_reorder(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const BeamState& bs, int B, int beam, int P, int ctx, int d);
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof = nullptr);
+// draft verification at beam > 1 (one utterance): after a replayed beam step, is the search where the draft says it was?  draft = [n_draft][MAX_R][2]
+// in BeamState::traj's layout.  Equal: vstate[0] = steps verified so far; different (or the draft has no entry for the step): done[0] = 2 -
+// the step itself stands (its inputs were verified), the beam steps queued behind it return at their `done` test
+int launch_draft_check(hipStream_t st, const BeamState& bs, const int* draft, int n_draft, int beam, int* vstate);
 // teacher-forced rows: the token a k = 1 beam step would take from each row's statistics, and its log-probability
 int launch_greedy_pick(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx, int rows, const SampleCfg& cfg, int* tok_out, float* lp_out);
 // language detection: softmax over lang_ids of the row's logits

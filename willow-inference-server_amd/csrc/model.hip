@@ -159,13 +159,16 @@ struct wis_model {
   bool spin_now = true;         // this call's decision (SpinClaim): dec_forward passes the granule buffers only when set
   f16 *dxf = nullptr, *daoxf = nullptr, *dhxf = nullptr; float* dstat = nullptr;   // batched rows: fragment images of x / attention out / FFN hidden, row partial sums
   RowMeta rm; BeamState bs;
+  RowMeta rm_win;               // row metadata of a draft-verification window (wis_generate_draft_beam): the search's own rows (rm, written by beam_step_kernel) stay untouched
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
   int* vstep = nullptr; int* pick_tok = nullptr; float* pick_lp = nullptr;      // wis_generate_draft: per-row step index, picked token / log-probability of the teacher-forced rows
+  int* d_draft = nullptr; int* d_anc = nullptr; int* d_vstate = nullptr;        // wis_generate_draft_beam: the draft trajectory [256][MAX_R][2], the window rows' ancestor slots [MAX_ROWS][16], {steps verified}
   float* lm_logspec = nullptr; unsigned* lm_gmax = nullptr;   // log-mel scratch of THIS replica (never shared with other callers)
   int* h_pin;      // pinned host scratch
   unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
   unsigned gen = 0;                          // generation of the current search (records of an earlier call's over-run step are ignored)
+  int last_B = 0, last_beam = 0;             // shape of the last generate call (wis_last_trajectory)
   hipEvent_t ev[8];
   hipStream_t st_enc = nullptr;             // wis_generate's front half (log-mel, encoder) runs here: it overlaps the previous call's over-run decode step on `st`
   hipEvent_t ev_enc = nullptr, ev_ckv = nullptr;      // encoder output ready (st_enc -> st); cross-K/V projection done reading it (st -> the next call's st_enc)
@@ -473,9 +476,11 @@ int alloc_buffers(wis_model* m) {
     WIS_HIP_CHECK(hipMemsetAsync(m->dhxf, 0, (size_t)(4 * d / 32) * blk * 2, m->st));
   }
   WIS_RET(dalloc(m, &m->logits, (size_t)MAX_ROWS * m->n_vocab_pad));
-  WIS_RET(dalloc(m, &m->part, (size_t)Bm * H * 16 * 16 * 66));
-  WIS_RET(dalloc(m, &m->counters, (size_t)Bm * H));
-  WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bm * H * 4, m->st));
+  // (row groups of the cross-attention: utterances - or, verifying a beam-search draft, up to MAX_ROWS / 16 groups of 16 tree rows of ONE utterance)
+  const int Bg = Bm > MAX_ROWS / 16 ? Bm : MAX_ROWS / 16;
+  WIS_RET(dalloc(m, &m->part, (size_t)Bg * H * 16 * 16 * 66));
+  WIS_RET(dalloc(m, &m->counters, (size_t)Bg * H));
+  WIS_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)Bg * H * 4, m->st));
   {
     // measured (decode ms per utterance batch, 17 steps): 8 utterances 40.7 unsplit / 38.6 two slices / 38.9 four; 12: 46.7 two / 46.9 four;
     // 16: 60.9 unsplit / 58.7 two / 59.5 four
@@ -495,6 +500,7 @@ int alloc_buffers(wis_model* m) {
   }
   WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
   WIS_RET(dalloc(m, &m->rm.slot, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.lslot, MAX_ROWS));
+  WIS_RET(dalloc(m, &m->rm_win.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm_win.pos, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm_win.slot, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm_win.lslot, MAX_ROWS));
   const int max_new = 256, max_hyp = MAX_HYP;
   WIS_RET(dalloc(m, &m->bs.step_u, Bm)); WIS_RET(dalloc(m, &m->bs.done, Bm)); WIS_RET(dalloc(m, &m->bs.n_hyp, Bm));
   WIS_RET(dalloc(m, &m->bs.cum, slots));
@@ -505,6 +511,8 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.all_done, 4));
   WIS_RET(dalloc(m, &m->bs.tick, 4));
   WIS_RET(dalloc(m, &m->vstep, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_lp, MAX_ROWS));
+  WIS_RET(dalloc(m, &m->bs.traj, (size_t)Bm * 256 * MAX_R * 2));
+  WIS_RET(dalloc(m, &m->d_draft, (size_t)256 * MAX_R * 2)); WIS_RET(dalloc(m, &m->d_anc, (size_t)MAX_ROWS * 16)); WIS_RET(dalloc(m, &m->d_vstate, 4));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.tick, 0, 16, m->st));
   WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
   WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_SUB)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_SUB));
@@ -665,9 +673,13 @@ static int spin_gave_up(wis_model* m, bool* gave_up) {
 // Batched rows (8 < M <= 48): every activation a projection reads lives in HBM as an MFMA fragment image, LayerNorm statistics
 // travel as per-16-column partial sums from the residual epilogues (kernels.hpp launch_gemv_frag): 8 launches per layer, no
 // LayerNorm launch, no per-workgroup LDS staging of the activations.
-static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, int chunks) {
+// tw (draft verification at beam > 1): the M rows are nodes of ONE utterance's beam tree - self-attention by ancestor table (anc [M][aw], first
+// window position w0), cross-attention as B = M / 16 groups of R = 16 rows that all read utterance 0's K / V
+struct TreeWin { const int* anc; int w0, aw; };
+static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, int chunks, const TreeWin* tw = nullptr) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx, MB = cdiv(M, 16);
+  if (tw && (M % 16 != 0 || R != 16 || B != M / 16)) { set_error("dec_forward_frag: a tree window takes whole groups of 16 rows"); return WIS_E_ARG; }
   WIS_RET(launch_dec_embed_xf(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, m->dxf, m->dstat, M, d, MB));
   // cross-Q folded through the self-attention out-projection (f16 weights; <= 8 rows per utterance: the cross-attention kernel's
   // statistics prologue); WIS_NO_FRAG_FOLD=1 keeps the two-launch form (A/B switch)
@@ -683,7 +695,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     GemvP g = base(m->dxf, w.p_qkv, w.s_qkv, w.b_qkv, 3 * d, d, GV_LN | GV_QKV);
     g.csum = w.c_qkv; g.stat_in = m->dstat; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     WIS_RET(launch_gemv_frag(st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB, tw ? tw->anc : nullptr, tw ? tw->w0 : 0, tw ? tw->aw : 0));
     if (fold) {
       // ONE launch, three d x d problems on 3 d / 16 workgroups: x1 = x0 + Wo a + bo (residual rows + their LayerNorm partials; nobody
       // reads x1's fragment image any more, so none is written and x0's image stays valid for the other two), q_A = W'q x0 + W'q bo
@@ -709,7 +721,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     g.csum = w.c_cq; g.stat_in = m->dstat; g.y = m->dq;
     WIS_RET(launch_gemv_frag(st, g));
     WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, nullptr, nullptr, nullptr,
-                                  m->spin_now ? m->ca_gran : nullptr, m->ca_epoch));
+                                  (m->spin_now && !tw) ? m->ca_gran : nullptr, m->ca_epoch, nullptr, 0, tw ? 1 : 0));
     }
     g = base(m->daoxf, w.p_cout, w.s_cout, w.b_cout, d, d, GV_RESID);
     g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
@@ -730,19 +742,20 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
   return WIS_OK;
 }
 
-int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul) {
+int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, const TreeWin* tw = nullptr) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
   static const int env_chunks = getenv("WIS_CROSS_CHUNKS") ? atoi(getenv("WIS_CROSS_CHUNKS")) : 0;
   // 256-key chunks (6 per utterance-head): measured faster than 128-key chunks at every batch size (fewer partials to publish and combine)
   const int chunks = env_chunks ? env_chunks : 6;
   static const bool no_frag = getenv("WIS_NO_FRAG") != nullptr;      // A/B switch: the round-1 batched path (LayerNorm launches + LDS-staged rows)
+  if (tw) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks, tw);
   if (M > 8 && !no_frag) return dec_forward_frag(m, M, R, B, want_logits, sstride, rmul, chunks);
   // fused out-proj + cross-Q stage (load_weights: cq_fold): f16 decoder weights, <= 8 rows (the LayerNorm-fused row counts)
   const bool fold = m->cq_fold && M <= 8;
   // (r5) what the LayerNorm-folded projections (QKV, FFN1, the vocabulary) read - WIS_B1_LN = rows | f16 | partials:
-  //   rows      the fp32 rows (25.6 KB per workgroup at five rows), statistics in all four waves behind the weight stream: rounds 2-4
-  //   f16       (default) the f16 copy of the rows (GV_LN16: 12.8 KB) that whoever produces residual rows leaves next to them (embedding, cross-
+  //   rows      (default) the fp32 rows (25.6 KB per workgroup at five rows), statistics in all four waves behind the weight stream: rounds 2-5
+  //   f16       (off: the statistics of rounded rows cost parity at large-v2) the f16 copy of the rows (GV_LN16: 12.8 KB) that whoever produces residual rows leaves next to them (embedding, cross-
   //             attention output projection, FFN2), statistics from those same values, still in all four waves - a third of a launch's
   //             requests through the CU's address path gone, nothing added to its tail
   //   partials  f16 rows + per-16-column (sum, M2) pairs from the producers' epilogues (GV_LNP): fewer requests still, but the merge sits in
@@ -858,6 +871,7 @@ static SampleCfg make_sample_cfg(const wis_model* m, const wis_gen_opts_t* o, in
   sc.max_candidates = (int)lroundf((float)beam * patience); if (sc.max_candidates < 1) sc.max_candidates = 1;
   // CT2: allow_early_exit = patience == 1 && length_penalty == 0 && coverage_penalty == 0
   sc.allow_early_exit = (patience == 1.f && o->length_penalty == 0.f) ? 1 : 0;
+  sc.early_exit_hyps = WIS_EARLY_EXIT_NUM_HYPOTHESES ? 1 : sc.max_candidates;      // num_hypotheses is 1 at this boundary (kernels.hpp)
   *patience_out = patience;
   return sc;
 }
@@ -875,9 +889,9 @@ static int check_patience(int beam, float patience) {
   return WIS_OK;
 }
 
-int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot, bool wait = true) {
+int upload_rows(wis_model* m, const std::vector<int>& tok, const std::vector<int>& pos, const std::vector<int>& slot, const std::vector<int>& lslot, bool wait = true, int stage = 1024) {
   const size_t n = tok.size();
-  int* h = m->h_pin + 1024;
+  int* h = m->h_pin + stage;      // (a caller that uploads twice without a wait in between passes a second staging area)
   memcpy(h, tok.data(), n * 4); memcpy(h + MAX_ROWS, pos.data(), n * 4); memcpy(h + 2 * MAX_ROWS, slot.data(), n * 4); memcpy(h + 3 * MAX_ROWS, lslot.data(), n * 4);
   WIS_HIP_CHECK(hipMemcpyAsync(m->rm.tok, h, n * 4, hipMemcpyHostToDevice, m->st));
   WIS_HIP_CHECK(hipMemcpyAsync(m->rm.pos, h + MAX_ROWS, n * 4, hipMemcpyHostToDevice, m->st));
@@ -1023,10 +1037,33 @@ int wis_model_clone(wis_model_t* parent, wis_model_t** out) {
 
 }  // extern "C" (reopened below: the generate driver is a static helper)
 
+// The decoder rows of window steps s0 .. s0 + Rw - 1 of a beam trajectory (hd: [step][MAX_R][2] = token, origin; one utterance, k beams), step-major:
+// row (s, j) feeds the token live beam j got at step s - 1 at position P - 1 + s and keeps its K / V in slot j; ha[row][16] = the slot of the
+// row's ancestor at every window step (entry 0 doubles as the slot that holds everything before the window).  Padded to whole groups of 16 rows
+// with copies of the last row (they write the same K / V to the same place).  Returns the padded row count.
+static int fill_tree_window(const int* hd, int s0, int Rw, int k, int P, std::vector<int>& tok, std::vector<int>& pos, std::vector<int>& slot, std::vector<int>& ls, int* ha) {
+  const int Mreal = k * Rw, Mpad = cdiv(Mreal, 16) * 16;
+  tok.assign(Mpad, 0); pos.assign(Mpad, 0); slot.assign(Mpad, 0); ls.assign(Mpad, 0);
+  for (int t = 0; t < Rw; ++t) for (int j = 0; j < k; ++j) {
+    const int s_ = s0 + t, r = t * k + j;
+    tok[r] = hd[((s_ - 1) * MAX_R + j) * 2]; pos[r] = P - 1 + s_; slot[r] = j; ls[r] = j;
+    int a = j;                                    // ancestor of (s_, j) at window step sp, walking the origins back to s0
+    for (int sp = s_; sp >= s0; --sp) { ha[r * 16 + (sp - s0)] = a; a = hd[((sp - 1) * MAX_R + a) * 2 + 1]; }
+    for (int u = t + 1; u < 16; ++u) ha[r * 16 + u] = ha[r * 16 + t];
+  }
+  for (int r = Mreal; r < Mpad; ++r) {
+    tok[r] = tok[Mreal - 1]; pos[r] = pos[Mreal - 1]; slot[r] = slot[Mreal - 1]; ls[r] = ls[Mreal - 1];
+    for (int u = 0; u < 16; ++u) ha[r * 16 + u] = ha[(Mreal - 1) * 16 + u];
+  }
+  return Mpad;
+}
+
 // draft / n_draft / accepted: wis_generate_draft (one utterance, beam 1): the tokens of an earlier hypothesis to verify first
+// draft_org (beam > 1, wis_generate_draft_beam): draft = [n_draft][beam] tokens, draft_org = [n_draft][beam] the beam slot each continued from -
+// the trajectory of an earlier SEARCH (wis_last_trajectory); accepted = steps verified
 static int generate_impl(wis_model_t* m, const float* input, int B, const int32_t* prompt, int P,
                  const wis_gen_opts_t* o, int32_t* out_ids, int32_t* out_len, float* out_score, bool* retry,
-                 const int32_t* draft = nullptr, int n_draft = 0, int* accepted = nullptr) {
+                 const int32_t* draft = nullptr, int n_draft = 0, int* accepted = nullptr, const int32_t* draft_org = nullptr) {
   *retry = false;
   if (accepted) *accepted = 0;
   WIS_HIP_CHECK(hipSetDevice(m->device));
@@ -1053,9 +1090,18 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   const SampleCfg sc = make_sample_cfg(m, o, beam, max_new, &patience);
   const float* bias_all = o->suppress_default ? m->bias_all : nullptr;
   const bool drafting = draft != nullptr && n_draft > 0;
-  if (drafting && (B != 1 || beam != 1)) { set_error("wis_generate_draft: one utterance, beam_size 1 (got B = %d, beam_size %d)", B, beam); return WIS_E_UNSUPPORTED; }
-  if (drafting) for (int i = 0; i < n_draft; ++i) if (draft[i] < 0 || draft[i] >= c.n_vocab) { set_error("draft token %d out of range", draft[i]); return WIS_E_ARG; }
-  if (!drafting) {
+  const bool beam_draft = drafting && draft_org != nullptr;
+  if (drafting && B != 1) { set_error("wis_generate_draft: one utterance per call (got B = %d)", B); return WIS_E_UNSUPPORTED; }
+  if (drafting && !beam_draft && beam != 1) { set_error("wis_generate_draft: beam_size 1 (a beam search is drafted by its trajectory: wis_generate_draft_beam)"); return WIS_E_UNSUPPORTED; }
+  if (beam_draft && (beam < 2 || n_draft > 256)) { set_error("wis_generate_draft_beam: beam_size >= 2 and at most 256 draft steps (got %d, %d)", beam, n_draft); return WIS_E_ARG; }
+  if (drafting) for (int i = 0; i < n_draft * (beam_draft ? beam : 1); ++i) if (draft[i] < 0 || draft[i] >= c.n_vocab) { set_error("draft token %d out of range", draft[i]); return WIS_E_ARG; }
+  if (beam_draft) for (int i = 0; i < n_draft * beam; ++i) if (draft_org[i] < 0 || draft_org[i] >= beam) { set_error("draft origin %d outside [0, beam_size)", draft_org[i]); return WIS_E_ARG; }
+  m->last_B = B; m->last_beam = beam;
+  // Verification passes keep to the ticket hand-off of the cross-attention: their picks are accepted on the host pass by pass, outside the
+  // progress record that carries the granule form's give-up flag (advisor, round 5) - the ordinary steps behind them take the call's form again
+  const bool spin_call = m->spin_now;
+  if (drafting) m->spin_now = false;
+  if (!drafting || beam_draft) {
     std::vector<int> tok(B * P), pos(B * P), slot(B * P), ls(B * P);
     for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) { tok[b * P + i] = prompt[b * P + i]; pos[b * P + i] = i; slot[b * P + i] = b * beam; ls[b * P + i] = b * beam; }
     WIS_RET(upload_rows(m, tok, pos, slot, ls, false));
@@ -1093,12 +1139,88 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   // prompt[:-1] and then feeds prompt[-1] as the first decoder input — the same arithmetic, one weight pass instead of two)
   int steps = 1;            // decoder passes done: the first step runs with the prefill pass
   bool spec_done = false;   // the draft verification already met the end of the utterance
+  bool beam_fin = false;    // ... of a beam search: the replayed beam steps finished it, results are where beam_step_kernel puts them
   std::vector<int> spec_gen; float spec_cum = 0.f; int spec_len = 0;
   if (!drafting) {
     WIS_RET(dec_forward(m, B * P, P, B, true, beam, 0));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, B, sc, P, 0, P - 1, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 + 16 : nullptr));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, B, P, ctx, sc, WIS_TAPS ? m->d_prof + (size_t)m->cfg.n_dec_layers * 8 * 16 : nullptr));
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
+  } else if (beam_draft) {
+    // ---- verify the draft of a BEAM SEARCH (round 6; BASELINE configs[4] at the reference's long-audio beam, main.py:582-586).  The draft is
+    // the trajectory of an earlier search over (most of) the same audio: per step s the live set it left - k tokens and the beam slot each
+    // continued from.  If the search over THIS window has followed it up to step s0 - 1, the decoder rows of steps s0 .. s0 + Rw - 1 are
+    // known without running those steps: row (s, j) feeds the draft's token of live beam j after step s - 1 at position P - 1 + s.  They form a
+    // TREE (a beam's history is a path through earlier live sets), so the pass runs the self-attention by ancestor table (dec_self_attn_kernel
+    // TREE: node (s, j) keeps its K / V in slot j, row (s, j) reads position P - 1 + s' from the slot of its ancestor at step s') and the
+    // cross-attention as groups of 16 rows over the utterance's one K / V.  One weight stream then yields the logits of Rw steps x k beams;
+    // the steps are REPLAYED on them by the ordinary sampling kernels (logit_stats, beam_step, kv_reorder - the search state, the hypothesis
+    // list and the cache end up exactly where Rw ordinary steps would leave them), each followed by draft_check_kernel: if the live set a
+    // replayed step produced is the draft's, the next step's rows were the right ones; the first step that differs still stands (its own
+    // inputs were verified), parks the search (done = 2), and ordinary steps resume behind it.  A whole window is queued without a host
+    // round trip; the host looks once per window.  Exact by construction: every accepted step ran beam_step_kernel on the logits of its
+    // true inputs (summed in the multi-row order, as any other batch shape of the engine).
+    const int k = beam;
+    const int nd = std::min(n_draft, max_new - 1);
+    int* hd = m->h_pin + 8192;                         // the draft in BeamState::traj's layout ([step][MAX_R][2])
+    for (int s_ = 0; s_ < nd; ++s_) for (int j = 0; j < k; ++j) { hd[(s_ * MAX_R + j) * 2] = draft[s_ * k + j]; hd[(s_ * MAX_R + j) * 2 + 1] = draft_org[s_ * k + j]; }
+    int* hv = m->h_pin + 12288;                        // [0] steps verified, [1] done flag, [2] step counter (read back per window)
+    hv[0] = 0;
+    if (nd > 0) WIS_HIP_CHECK(hipMemcpyAsync(m->d_draft, hd, (size_t)nd * MAX_R * 2 * 4, hipMemcpyHostToDevice, st));
+    WIS_HIP_CHECK(hipMemcpyAsync(m->d_vstate, hv, 4, hipMemcpyHostToDevice, st));
+    // merged prefill + first step as in the ordinary call, then: is the search where the draft's step 0 says?
+    WIS_RET(dec_forward(m, P, P, 1, true, beam, 0));
+    WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, 1, sc, P, 0, P - 1));
+    WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, 1, P, ctx, sc));
+    WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, 1, beam, P, ctx, c.d_model));
+    WIS_RET(launch_draft_check(st, m->bs, m->d_draft, nd, k, m->d_vstate));
+    const int RW = std::min(16, MAX_ROWS / k);          // steps per window: k x RW rows, padded to whole groups of 16
+    const int s_last = std::min(nd, max_new - 1);       // last step a window can hold: rows from the draft's entry s - 1; step max_new - 1 ends every search
+    int* ha = m->h_pin + 12352;                         // ancestor table of the window rows, [rows][16]
+    int done_flag = 0, step_dev = 0;
+    for (int s0 = 1;; ) {
+      const int Rw = std::min(RW, s_last - s0 + 1);
+      if (Rw >= 1) {
+        std::vector<int> tok, pos, slot, ls;
+        const int Mpad = fill_tree_window(hd, s0, Rw, k, P, tok, pos, slot, ls, ha);
+        // the window's rows go through a row table of their own: the search's table (next input rows, written by the last beam step that
+        // counted) must survive a window that turns out to sit behind a parked search (queued before the host has looked)
+        const RowMeta rm_search = m->rm;
+        m->rm = m->rm_win;
+        int rc = upload_rows(m, tok, pos, slot, ls, false, 13900);      // (the prompt rows' staging copy may still be pending: own area; windows are a sync apart)
+        if (!rc && hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * 16 * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("draft window: ancestor table upload failed"); rc = WIS_E_HIP; }
+        const TreeWin tw{m->d_anc, P - 1 + s0, 16};
+        if (!rc) rc = dec_forward(m, Mpad, 16, Mpad / 16, true, 1, 0, &tw);
+        m->rm = rm_search;
+        WIS_RET(rc);
+        for (int t = 0; t < Rw; ++t) {
+          WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, 1, sc, beam, 1, t * k));
+          WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, 1, P, ctx, sc));
+          WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, 1, beam, P, ctx, c.d_model));
+          WIS_RET(launch_draft_check(st, m->bs, m->d_draft, nd, k, m->d_vstate));
+        }
+      }
+      WIS_HIP_CHECK(hipMemcpyAsync(hv, m->d_vstate, 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(hv + 1, m->bs.done, 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(hv + 2, m->bs.step_u, 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipStreamSynchronize(st));
+      done_flag = hv[1]; step_dev = hv[2];
+      if (Rw < 1 || done_flag != 0) break;
+      s0 += Rw;
+    }
+    if (accepted) *accepted = hv[0];
+    __atomic_store_n(&m->h_prog[HP_REC], 0ull, __ATOMIC_RELAXED);      // the replayed steps' progress records count launches, not steps: the pacing loop starts from `steps`
+    if (done_flag == 1) {      // the replayed steps ended the search: hypotheses ranked, result written by beam_step_kernel
+      beam_fin = true; steps = step_dev + 1;
+    } else {                   // parked behind a step that stands (or nothing to verify): ordinary steps resume
+      steps = step_dev;
+      if (steps < 1) { set_error("wis_generate_draft_beam: verification completed no step"); return WIS_E_STATE; }
+      int* hw = m->h_pin + 4096 + 512;
+      unsigned* tk = reinterpret_cast<unsigned*>(hw);
+      tk[0] = (unsigned)steps; tk[1] = m->gen; tk[2] = 0; tk[3] = 0;
+      WIS_HIP_CHECK(hipMemcpyAsync(m->bs.tick, tk, 16, hipMemcpyHostToDevice, st));
+      WIS_HIP_CHECK(hipMemsetAsync(m->bs.done, 0, 4, st));
+    }
   } else {
     // ---- verify the draft: the prompt and the draft tokens go through the decoder as teacher-forced rows, 16 positions per pass
     // (causal by position inside the utterance's KV slot, like the merged prompt pass); row i's logits are what a greedy step fed
@@ -1161,7 +1283,9 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
       WIS_HIP_CHECK(hipMemcpyAsync(m->bs.tick, tk, 16, hipMemcpyHostToDevice, st));
     }
   }
+  m->spin_now = spin_call;
   WIS_HIP_CHECK(hipEventRecord(m->ev[4], st));
+  if (beam_fin) WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
 
   auto one_step = [&]() -> int {
     WIS_RET(dec_forward(m, Mrows, beam, B, true, beam, 1));
@@ -1202,7 +1326,7 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   };
   const int base_done = drafting ? steps : 0;      // passes the draft verification stands for: done before the first progress record of this call
   const auto t_dec0 = std::chrono::steady_clock::now();
-  if (spec_done) {
+  if (spec_done || beam_fin) {
     needed = steps;
   } else if (known) {
     // every step goes out in one burst: nothing to find out from the device before the last one
@@ -1349,6 +1473,39 @@ int wis_generate_draft(wis_model_t* m, const float* input, const int32_t* prompt
     if (retry) { set_error("wis_generate_draft: hand-off flag raised without the granule path"); return WIS_E_STATE; }
   }
   if (accepted) *accepted = acc;
+  return WIS_OK;
+}
+
+int wis_generate_draft_beam(wis_model_t* m, const float* input, const int32_t* prompt, int P, const wis_gen_opts_t* o,
+                            const int32_t* draft_tok, const int32_t* draft_org, int n_steps, int32_t* out_ids, int32_t* out_len, float* out_score, int32_t* accepted_steps) {
+  if (!m || !input || !prompt || !o || !out_ids || !out_len || n_steps < 0 || (n_steps > 0 && (!draft_tok || !draft_org))) { set_error("wis_generate_draft_beam: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_generate_draft_beam")
+  bool retry = false;
+  int acc = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    WIS_RET(generate_impl(m, input, 1, prompt, P, o, out_ids, out_len, out_score, &retry, n_steps > 0 ? draft_tok : nullptr, n_steps, &acc, n_steps > 0 ? draft_org : nullptr));
+    if (!retry) break;
+    if (attempt == 1) { set_error("wis_generate_draft_beam: hand-off flag raised without the granule path"); return WIS_E_STATE; }
+  }
+  if (accepted_steps) *accepted_steps = acc;
+  return WIS_OK;
+}
+
+int wis_last_trajectory(wis_model_t* m, int b, int32_t* tok, int32_t* org, int cap_steps, int32_t* n_steps) {
+  if (!m || !tok || !org || !n_steps || cap_steps < 0) { set_error("wis_last_trajectory: bad argument"); return WIS_E_ARG; }
+  WIS_ENTER(m, "wis_last_trajectory")
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  if (b < 0 || b >= m->last_B) { set_error("wis_last_trajectory: utterance %d outside the last call's batch of %d", b, m->last_B); return WIS_E_ARG; }
+  const int k = m->last_beam;
+  int n = 0;
+  WIS_HIP_CHECK(hipMemcpyAsync(&n, m->bs.step_u + b, 4, hipMemcpyDeviceToHost, m->st));
+  WIS_HIP_CHECK(hipStreamSynchronize(m->st));
+  if (n < 0 || n > 256) { set_error("wis_last_trajectory: step counter %d out of range", n); return WIS_E_STATE; }
+  if (n > cap_steps) n = cap_steps;
+  std::vector<int> raw((size_t)n * MAX_R * 2);
+  if (n) WIS_HIP_CHECK(hipMemcpy(raw.data(), m->bs.traj + (size_t)b * 256 * MAX_R * 2, raw.size() * 4, hipMemcpyDeviceToHost));
+  for (int s = 0; s < n; ++s) for (int j = 0; j < k; ++j) { tok[s * k + j] = raw[((size_t)s * MAX_R + j) * 2]; org[s * k + j] = raw[((size_t)s * MAX_R + j) * 2 + 1]; }
+  *n_steps = n;
   return WIS_OK;
 }
 
@@ -1519,6 +1676,48 @@ int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, in
       if (!gave_up) break;
     }
   }
+  return WIS_OK;
+}
+
+int wis_debug_tree_logits(wis_model_t* m, const float* input, int input_kind, const int32_t* prompt, int P, int beam,
+                          const int32_t* tok, const int32_t* org, int n_steps, float* logits) {
+  if (!m || !input || !prompt || !tok || !org || !logits || P < 1 || P > 16 || beam < 1 || beam > MAX_R || n_steps < 1 || n_steps > std::min(16, MAX_ROWS / std::max(beam, 1))) {
+    set_error("wis_debug_tree_logits: bad argument (1 <= n_steps <= min(16, %d / beam))", MAX_ROWS); return WIS_E_ARG;
+  }
+  WIS_ENTER(m, "wis_debug_tree_logits")
+  WIS_HIP_CHECK(hipSetDevice(m->device));
+  WIS_RET(check_batch(m, 1, beam));
+  const wis_config_t& c = m->cfg; hipStream_t st = m->st;
+  const int k = beam, V = c.n_vocab;
+  for (int i = 0; i < n_steps * k; ++i) if (tok[i] < 0 || tok[i] >= V || org[i] < 0 || org[i] >= k) { set_error("wis_debug_tree_logits: token / origin out of range"); return WIS_E_ARG; }
+  WIS_RET(stage_input(m, input, input_kind, 1));
+  WIS_RET(run_encoder(m, 1));
+  WIS_RET(run_cross_kv(m, 1));
+  m->spin_now = false;
+  // the prompt: rows at positions 0 .. P-1 of slot 0, then every slot gets a copy (what the first step's kv_reorder does)
+  std::vector<int> ptok(P), ppos(P), pslot(P, 0), pls(P, 0);
+  for (int i = 0; i < P; ++i) { ptok[i] = prompt[i]; ppos[i] = i; }
+  WIS_RET(upload_rows(m, ptok, ppos, pslot, pls));
+  WIS_RET(dec_forward(m, P, P, 1, false, beam, 0));
+  int* hs = m->h_pin + 4096;
+  for (int j = 0; j < MAX_R; ++j) hs[j] = 0;
+  hs[8] = 1; hs[9] = 0;
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.parent, hs, (size_t)k * 4, hipMemcpyHostToDevice, st));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.step_u, hs + 8, 4, hipMemcpyHostToDevice, st));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->bs.done, hs + 9, 4, hipMemcpyHostToDevice, st));
+  WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, 1, beam, P, c.n_text_ctx, c.d_model));
+  // one window: steps 1 .. n_steps, rows from trajectory entries 0 .. n_steps - 1
+  std::vector<int> hd((size_t)n_steps * MAX_R * 2, 0);
+  for (int s_ = 0; s_ < n_steps; ++s_) for (int j = 0; j < k; ++j) { hd[(s_ * MAX_R + j) * 2] = tok[s_ * k + j]; hd[(s_ * MAX_R + j) * 2 + 1] = org[s_ * k + j]; }
+  std::vector<int> wt, wp, wsl, wls;
+  int* ha = m->h_pin + 12352;
+  const int Mpad = fill_tree_window(hd.data(), 1, n_steps, k, P, wt, wp, wsl, wls, ha);
+  WIS_RET(upload_rows(m, wt, wp, wsl, wls, false, 13900));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * 16 * 4, hipMemcpyHostToDevice, st));
+  const TreeWin tw{m->d_anc, P, 16};
+  WIS_RET(dec_forward(m, Mpad, 16, Mpad / 16, true, 1, 0, &tw));
+  WIS_HIP_CHECK(hipMemcpy2DAsync(logits, (size_t)V * 4, m->logits, (size_t)m->n_vocab_pad * 4, (size_t)V * 4, (size_t)n_steps * k, hipMemcpyDeviceToHost, st));
+  WIS_HIP_CHECK(hipStreamSynchronize(st));
   return WIS_OK;
 }
 

@@ -76,10 +76,14 @@ SYMBOLS = [
     ("wis_generate", _i, [_vp, _vp, _i, C.POINTER(C.c_int32), _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),
     ("wis_generate_draft", _i, [_vp, _vp, C.POINTER(C.c_int32), _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp,
                                 C.POINTER(C.c_int32)]),
+    ("wis_generate_draft_beam", _i, [_vp, _vp, C.POINTER(C.c_int32), _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), _fp, C.POINTER(C.c_int32)]),
+    ("wis_last_trajectory", _i, [_vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32)]),
     ("wis_detect_language", _i, [_vp, _vp, _i, _i, _fp]),
     ("wis_debug_encode", _i, [_vp, _vp, _i, _i, _fp]),
     ("wis_debug_logits", _i, [_vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _fp]),
     ("wis_debug_logits_rows", _i, [_vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _fp]),
+    ("wis_debug_tree_logits", _i, [_vp, _vp, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _fp]),
     ("wis_debug_search", _i, [_vp, _vp, _i, _i, C.POINTER(GenOpts), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("wis_debug_handoff", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("wis_last_timing", _i, [_vp, C.POINTER(Timing)]),

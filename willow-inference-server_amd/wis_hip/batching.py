@@ -206,7 +206,9 @@ class MicroBatcher:
                     if self._takeable(w) and (w.state == _WOKEN or self._unclaimed_free() > 0 or self._bound_rows_waiting(w)):
                         break
                     w.state, w.cap = _IDLE, 0
-                    w.cv.wait()
+                    # (while shutting down: re-check on a timer - close() notifies once, and a worker that woke while another one was
+                    # lingering over the same rows would otherwise sleep through the end of the queue and hold close() in join())
+                    w.cv.wait(0.05 if self._stop else None)
                 w.state = _LINGER
                 w.cap = self._fill(w)[1]
                 self._linger(w)

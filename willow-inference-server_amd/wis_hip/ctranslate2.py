@@ -162,9 +162,21 @@ def create_replicas(a, arena, index, devices, max_batch=8, max_beam=5, **cfgkw):
     return handles
 
 
-def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=None, draft=None):
+def _last_trajectory(r, b, beam):
+    """(tok [n][beam], org [n][beam]) int32: the live sets the last search on replica r left after each step (wis_last_trajectory)."""
+    tok = np.zeros((256, beam), np.int32)
+    org = np.zeros((256, beam), np.int32)
+    n = C.c_int32(0)
+    i32p = C.POINTER(C.c_int32)
+    _lib.check(_lib.load().wis_last_trajectory(r.handle, b, tok.ctypes.data_as(i32p), org.ctypes.data_as(i32p), 256, C.byref(n)))
+    return tok[:n.value].copy(), org[:n.value].copy()
+
+
+def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=None, draft=None, want_traj=False):
     """mel: host ndarray [B, ...] - or, with device_ptr, just the batch size B of features already resident on r.device.
-    draft: token ids of an earlier hypothesis (one utterance, beam 1): wis_generate_draft verifies them before decoding on."""
+    draft (one utterance): token ids of an earlier hypothesis (beam 1: wis_generate_draft) or the trajectory (tok [n][beam], org [n][beam]) of
+    an earlier beam search (wis_generate_draft_beam) - verified in multi-row passes before ordinary steps go on.
+    want_traj: every result carries `.trajectory`, what a later call takes as its draft."""
     B = int(mel) if device_ptr is not None else mel.shape[0]
     o = _lib.GenOpts(kind, beam, max_new, lp, patience, int(bool(suppress_blank)), int(bool(suppress_default)), int(fixed_new), 0)
     pr = np.ascontiguousarray(np.asarray(prompts, np.int32).reshape(B, P))
@@ -172,18 +184,30 @@ def _generate_chunk(r, mel, prompts, P, beam, max_new, lp, patience, suppress_bl
     lens = np.zeros(B, np.int32)
     scores = np.zeros(B, np.float32)
     src = C.c_void_p(device_ptr) if device_ptr is not None else _lib.ptr(mel)
-    if draft:
+    i32p, lib = C.POINTER(C.c_int32), _lib.load()
+    acc = None
+    if draft is not None and len(draft) == 2 and isinstance(draft[0], np.ndarray):      # (tok, org): a beam search's trajectory
+        dt, do = (np.ascontiguousarray(np.asarray(a, np.int32)) for a in draft)
+        if dt.ndim != 2 or dt.shape != do.shape or dt.shape[1] != beam:
+            raise ValueError(f"draft trajectory must be two [steps][{beam}] arrays, got {dt.shape} / {do.shape}")
+        acc = C.c_int32(0)
+        _lib.check(lib.wis_generate_draft_beam(r.handle, src, pr.ctypes.data_as(i32p), P, C.byref(o), dt.ctypes.data_as(i32p), do.ctypes.data_as(i32p), int(dt.shape[0]),
+                                               ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), scores.ctypes.data_as(C.POINTER(C.c_float)), C.byref(acc)))
+    elif draft is not None and len(draft):
         d = np.ascontiguousarray(np.asarray(draft, np.int32))
         acc = C.c_int32(0)
-        _lib.check(_lib.load().wis_generate_draft(r.handle, src, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o), d.ctypes.data_as(C.POINTER(C.c_int32)), int(d.shape[0]),
-                                                  ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)), scores.ctypes.data_as(C.POINTER(C.c_float)), C.byref(acc)))
-        res = WhisperGenerationResult([ids[0, :lens[0]].tolist()], [float(scores[0])])
-        res.accepted_draft_tokens = int(acc.value)
-        return [res]
-    _lib.check(_lib.load().wis_generate(r.handle, src, B, pr.ctypes.data_as(C.POINTER(C.c_int32)), P, C.byref(o),
-                                        ids.ctypes.data_as(C.POINTER(C.c_int32)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
-                                        scores.ctypes.data_as(C.POINTER(C.c_float))))
-    return [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
+        _lib.check(lib.wis_generate_draft(r.handle, src, pr.ctypes.data_as(i32p), P, C.byref(o), d.ctypes.data_as(i32p), int(d.shape[0]),
+                                          ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), scores.ctypes.data_as(C.POINTER(C.c_float)), C.byref(acc)))
+    else:
+        _lib.check(lib.wis_generate(r.handle, src, B, pr.ctypes.data_as(i32p), P, C.byref(o), ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                    scores.ctypes.data_as(C.POINTER(C.c_float))))
+    out = [WhisperGenerationResult([ids[b, :lens[b]].tolist()], [float(scores[b])]) for b in range(B)]
+    if acc is not None:
+        out[0].accepted_draft_tokens = int(acc.value)      # tokens (beam 1) or search steps (beam > 1) of the draft the final decode kept
+    if want_traj:
+        for b in range(B):
+            out[b].trajectory = _last_trajectory(r, b, beam)
+    return out
 
 
 
@@ -215,6 +239,8 @@ _MEL_BYTES = 80 * 3000 * 4
 def _run_batch(replica, key, rows):
     P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind = key[:9]
     draft = key[9] if len(key) > 9 else None          # (a drafted utterance has a key of its own: it never shares a device batch)
+    want_traj = bool(key[10]) if len(key) > 10 else False
+    dr = (draft[1] if draft and len(rows) == 1 else None)
     prompts = [p for _, p in rows]
     if kind == _lib.WIS_IN_MEL_DEV:
         # features that already live in this replica's HBM (streaming sessions: audio.MelStream.finish): one utterance goes in
@@ -230,11 +256,11 @@ def _run_batch(replica, key, rows):
                     _lib.check(lib.wis_dev_copy_peer(replica.device, C.c_void_p(replica.stage.ptr.value + i * _MEL_BYTES), replica.device, C.c_void_p(int(src)), _MEL_BYTES))
                 ptr = replica.stage.ptr.value
             return _generate_chunk(replica, len(rows), prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind, device_ptr=ptr,
-                                   draft=draft[1] if draft and len(rows) == 1 else None)
+                                   draft=dr, want_traj=want_traj)
     mel = np.ascontiguousarray(np.stack([m for m, _ in rows]))
     with replica.lock:
         return _generate_chunk(replica, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind,
-                               draft=draft[1] if draft and len(rows) == 1 else None)
+                               draft=dr, want_traj=want_traj)
 
 
 class Whisper:
@@ -352,9 +378,12 @@ class Whisper:
     def generate(self, features, prompts, *, asynchronous=False, beam_size=5, patience=1, num_hypotheses=1, length_penalty=1,
                  repetition_penalty=1, no_repeat_ngram_size=0, max_length=448, return_scores=False, return_no_speech_prob=False,
                  max_initial_timestamp_index=50, suppress_blank=True, suppress_tokens=(-1,), sampling_topk=1,
-                 sampling_temperature=1, fixed_new_tokens=0, input_kind=_lib.WIS_IN_MEL_HOST, draft_tokens=None):
+                 sampling_temperature=1, fixed_new_tokens=0, input_kind=_lib.WIS_IN_MEL_HOST, draft_tokens=None, draft_trajectory=None,
+                 return_trajectory=False):
         """`draft_tokens` (one utterance, beam_size 1): the ids of an earlier hypothesis for this audio - wis_generate_draft verifies them in
-        multi-row passes and decodes on behind the accepted prefix; the result is the greedy decode of THESE features either way."""
+        multi-row passes and decodes on behind the accepted prefix; the result is the greedy decode of THESE features either way.
+        `draft_trajectory` (one utterance, beam_size > 1): `(tok, org)` as an earlier result's `.trajectory` gives it (`return_trajectory=True`) -
+        the beam search is replayed along it 16 steps per decoder pass (wis_generate_draft_beam); the result is the beam search of THESE features."""
         if num_hypotheses != 1 or repetition_penalty != 1 or no_repeat_ngram_size != 0 or sampling_topk != 1:
             raise NotImplementedError("only the decoding options WIS uses are implemented (defaults of CTranslate2 4.1.0)")
         mel = self._features(features, input_kind)
@@ -373,10 +402,23 @@ class Whisper:
         max_new = min(max_length // 2, max_length - P)
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), list(suppress_tokens) == [-1],
                int(fixed_new_tokens), int(input_kind))
-        if draft_tokens is not None and len(draft_tokens) and B == 1 and int(beam_size) == 1:
-            key = key + ((object(), tuple(int(t) for t in draft_tokens)),)
+        key = key + self._draft_key(B, beam_size, draft_tokens, draft_trajectory, return_trajectory)
         rows = [(np.ascontiguousarray(mel[b]), [int(t) for t in prompts[b]]) for b in range(B)]
         return self._batcher.submit(key, rows)
+
+    @staticmethod
+    def _draft_key(B, beam_size, draft_tokens, draft_trajectory, return_trajectory):
+        """The batcher-key tail of a drafted / trajectory-returning utterance: a draft makes the key unique (it never shares a device batch)."""
+        d = None
+        if B == 1 and int(beam_size) == 1 and draft_tokens is not None and len(draft_tokens):
+            d = (object(), tuple(int(t) for t in draft_tokens))
+        elif B == 1 and int(beam_size) > 1 and draft_trajectory is not None and len(draft_trajectory[0]):
+            tok, org = (np.ascontiguousarray(np.asarray(a, np.int32)) for a in draft_trajectory)
+            if tok.ndim == 2 and tok.shape[1] == int(beam_size) and tok.shape == org.shape:      # (a draft of another beam size cannot be followed: plain call)
+                d = (object(), (tok, org))
+        if d is None and not return_trajectory:
+            return ()
+        return (d, bool(return_trajectory))
 
     def acquire_replica(self):
         """The least-loaded replica, counted as in use until release_replica (a streaming session pins its log-mel front-end
@@ -394,7 +436,7 @@ class Whisper:
         raise ValueError(f"no replica on device {device}")
 
     def generate_from_device(self, device, mel_device_ptr, prompt, *, beam_size=5, max_length=448, length_penalty=1, patience=1,
-                             suppress_blank=True, fixed_new_tokens=0, replica=None, draft_tokens=None):
+                             suppress_blank=True, fixed_new_tokens=0, replica=None, draft_tokens=None, draft_trajectory=None, return_trajectory=False):
         """One utterance whose log-mel features ALREADY live in HBM on `device` (f32 [80][3000] at `mel_device_ptr`, e.g. an
         audio.MelStream after finish()): WIS_IN_MEL_DEV - nothing is staged through the host.  Goes through the micro-batcher bound
         to that DEVICE: any replica of the GPU can read the features, so concurrent windows of several streaming sessions on one GPU
@@ -412,8 +454,7 @@ class Whisper:
         key = (P, int(beam_size), max_new, float(length_penalty), float(patience), bool(suppress_blank), True, int(fixed_new_tokens),
                int(_lib.WIS_IN_MEL_DEV))
         _check_patience(beam_size, patience)
-        if draft_tokens is not None and len(draft_tokens) and int(beam_size) == 1:
-            key = key + ((object(), tuple(int(t) for t in draft_tokens)),)
+        key = key + self._draft_key(1, beam_size, draft_tokens, draft_trajectory, return_trajectory)
         return self._batcher.submit(key, [(int(mel_device_ptr), [int(t) for t in prompt])], affinity=("device", device))[0]
 
     def _generate_chunk(self, r, mel, prompts, P, beam, max_new, lp, patience, suppress_blank, suppress_default, fixed_new, kind):
