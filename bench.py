@@ -150,12 +150,17 @@ def concurrent_batches(lib, handles, dev, pcm, beam, B, fixed_new, audio_ms, ite
     return {"workload": f"{B} x 3sec.flac per device batch, beam {beam}, replicas on one GPU sharing one weight copy, one host thread each", "rows": rows}
 
 
-def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms, rest_batch=8, extra_handles=()):
+def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_ms, rest_batch=8, extra_handles=(), side_sessions=0, side_pcm=None, side_gate=None):
     """The reference's own load shape, client/jmeter-asr.jmx:53-90: `clients` threads, each looping
     POST /api/asr?task=transcribe&output=json&model=large&beam_size=5&detect_language=False with the 3.84 s clip as the
     multipart field `audio_file`.  Served by the re-hosted endpoint (wis_hip/server.py) in this process over the ASGI transport
-    (no socket): container decode, micro-batching and the HIP path are all inside the measurement."""
+    (no socket): container decode, micro-batching and the HIP path are all inside the measurement.
+    side_sessions > 0: that many StreamingSessions (30sec.flac at beam 1 - the default beam_size, the case that speculates by default; S = 96)
+    run beside the clients for the whole measured phase, each asking for an interim decode after every 2 s of audio as fast as the decodes
+    allow (no real-time pacing: ~15 x what live sessions would ask for - the worst case for the REST traffic); side_gate =
+    settings.stream_speculate_max_busy (None: the default gate; 1e9: no gate)."""
     import asyncio
+    import threading
     import httpx
     from wis_hip import ctranslate2 as ct2
     from wis_hip.server import create_app
@@ -164,6 +169,10 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     s = APISettings()
     s.whisper_model_path = "synthetic:{size}"
     s.max_batch, s.fixed_new_tokens = rest_batch, fixed_new
+    if side_gate is not None:
+        s.stream_speculate_max_busy = side_gate
+    if side_sessions:
+        s.long_beam_size = 1          # (the sessions' recordings pass 12 s; the REST clients name their beam in the URL)
     models = WhisperModels(s, device_index=[dev])
     model = ct2.Whisper.from_handles([(handle, dev)] + [(h, dev) for h in extra_handles], a, max_batch=rest_batch, max_beam=5)
     models._models["large"] = model
@@ -173,6 +182,30 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     hdr = {"content-type": f"multipart/form-data; boundary={b}"}
     url = "/api/asr?task=transcribe&output=json&model=large&beam_size=5&detect_language=False"
     lat = []
+    stop_side = threading.Event()
+    side_stats = {"sessions_started": 0, "interim_decodes": 0, "skipped_by_the_load_gate": 0, "interim_ms_total": 0.0}
+
+    def side_session():
+        from wis_hip.streaming import StreamingSession
+        chunk = 2 * 16000
+        while not stop_side.is_set():
+            sess = StreamingSession("large", 1, models=models, fixed_new_tokens=96, incremental=False)
+            side_stats["sessions_started"] += 1
+            try:
+                for i in range(0, side_pcm.shape[0], chunk):
+                    if stop_side.is_set():
+                        break
+                    sess.feed(side_pcm[i:i + chunk])
+                    job = sess._spec_job
+                    if job is not None:
+                        job.result()
+                    else:
+                        time.sleep(0.002)
+            finally:
+                side_stats["interim_decodes"] += sess.spec_runs
+                side_stats["skipped_by_the_load_gate"] += sess.spec_skipped
+                side_stats["interim_ms_total"] += sess.spec_ms
+                sess.close()
 
     async def client(c):
         for _ in range(iterations):
@@ -185,28 +218,57 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
         async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://wis", timeout=600) as c:
             await asyncio.gather(*[client(c) for _ in range(min(clients, rest_batch))])        # warm-up: one device batch
             lat.clear()
+            side = [threading.Thread(target=side_session, daemon=True) for _ in range(side_sessions)]
+            for t in side:
+                t.start()
+            if side:
+                await asyncio.sleep(0.3)           # the sessions' first (undrafted) interim decodes are under way
             n0 = len(model._batcher.batches)
             t0 = time.perf_counter()
             await asyncio.gather(*[client(c) for _ in range(clients)])
-            return time.perf_counter() - t0, [n for _, n in model._batcher.batches[n0:]]
+            el = time.perf_counter() - t0
+            sizes = [n for _, n in model._batcher.batches[n0:]]
+            stop_side.set()
+            for t in side:
+                t.join(30)
+            return el, sizes
 
     elapsed, sizes = asyncio.run(go())
     n = clients * iterations
     model.close()
     model._replicas = []          # the handle belongs to the caller
-    return {"load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport, device batches of up to {rest_batch}, "
+    if side_sessions:
+        sizes = [z for z in sizes if z > 1] or sizes      # (the sessions' own decodes are device batches of one)
+    extra = {}
+    if side_sessions:
+        extra = {"streaming_sessions_beside_the_clients": side_sessions, "load_gate (stream_speculate_max_busy)": "default 0.5" if side_gate is None else side_gate,
+                 **{k: (round(v, 1) if isinstance(v, float) else v) for k, v in side_stats.items()}}
+    return {**extra, "load": f"client/jmeter-asr.jmx shape: {clients} concurrent clients x {iterations} POST /api/asr (model=large, beam_size=5, 3sec.flac), in-process ASGI transport, device batches of up to {rest_batch}, "
                     f"{1 + len(extra_handles)} replica(s) on the GPU",
             "utterances_per_s": round(n / elapsed, 2), "aggregate_x_realtime": round(n * audio_ms / 1e3 / elapsed, 1),
             "p50_request_ms": round(p50(lat), 2), "max_request_ms": round(max(lat), 2), "device_batches": sizes[:32], "mean_device_batch": round(float(np.mean(sizes)), 2)}
 
 
+def _lib_kind():
+    from wis_hip import _lib
+    return _lib.WIS_IN_PCM_HOST
+
+
 def streaming_bench(handle, a, dev, clip_path):
     """BASELINE configs[4]: long-form / streaming (the reference records the whole WebRTC track and then makes ONE do_whisper call,
-    main.py:963-971).  client/30sec.flac is fed to a StreamingSession as 20 ms int16 frames back to back (no real-time pacing) and
-    the time from stop() to the result is reported, with the incremental log-mel front-end (features built in HBM while the audio
-    arrives) and without it (log-mel of the whole window at stop()); then 64 s of seeded noise, which crosses the 30 s chunking
-    threshold: windows whose 22 s are complete are transcribed while the audio is still arriving (eager windows), stop() only has
-    the tail left.  Same engine handle as the headline (large-v2); the reference's long-audio beam (3) applies from 12 s on."""
+    main.py:963-971).  client/30sec.flac is fed to a StreamingSession as 20 ms int16 frames and the time from stop() to the result is
+    reported:
+      * without speculation (stream_speculate_s = 0), frames back to back, with the incremental log-mel front-end (features built in HBM
+        while the audio arrives) and without it (log-mel of the whole window at stop()): the window's decode IS the latency;
+      * `beam3` - the reference's own settings (request beam 5, long_beam_size 3 from 12 s on, main.py:582-586): the session decodes what it
+        has heard every 2 s at the beam the final call would use at that length, each interim search drafted by the previous one's
+        trajectory, and stop() verifies the last trajectory against the final window 16 steps per decoder pass (wis_generate_draft_beam);
+      * `beam1` - the same with beam_size = long_beam_size = 1 (wis_generate_draft);
+      real-time arrival is emulated by letting every interim decode finish before the next frame is fed (an interim decode takes < 0.2 s,
+      2 s of audio take 2 s); `speculation_gpu_ms_per_session` = wall time of all interim decodes of a session (what the speculation costs);
+      * 64 s of seeded noise, which crosses the 30 s chunking threshold: windows whose 22 s are complete are transcribed while the audio is
+        still arriving (eager windows), stop() only has the tail left.
+    Same engine handle as the headline (large-v2)."""
     from wis_hip import audio, ctranslate2 as ct2
     from wis_hip.settings import APISettings
     from wis_hip.streaming import StreamingSession
@@ -220,12 +282,40 @@ def streaming_bench(handle, a, dev, clip_path):
     pcm, _ = audio.load_audio(clip_path)
     i16 = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2")
     frames = [i16[i:i + 320].tobytes() for i in range(0, i16.shape[0], 320)]
-    out = {"clip": "client/30sec.flac as 20 ms int16 frames, large-v2, beam 3 (long-audio beam), S=96"}
+    out = {"clip": "client/30sec.flac as 20 ms int16 frames, large-v2, request beam 5 -> long-audio beam 3 (reference defaults), S=96"}
+
+    def speculating_row(request_beam, what):
+        offl = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ref = do_whisper(pcm, "large", request_beam, models=models, fixed_new_tokens=96)
+            offl.append(1e3 * (time.perf_counter() - t0))
+        lat, acc, runs, cost, interims = [], [], 0, [], []
+        for _ in range(3):
+            sess = StreamingSession("large", request_beam, models=models, fixed_new_tokens=96, incremental=True)
+            seen = 0.0
+            interims = []
+            for f in frames:
+                sess.feed(f, 2)
+                if sess._spec_job is not None and not sess._spec_job.done():
+                    sess._spec_job.result()
+                    interims.append(round(sess.spec_ms - seen, 1)); seen = sess.spec_ms
+            runs = sess.spec_runs
+            t0 = time.perf_counter()
+            r = sess.stop()
+            lat.append(1e3 * (time.perf_counter() - t0))
+            acc.append(sess.accepted_draft_tokens)
+            cost.append(sess.spec_ms)
+        return {"config": what, "stop_to_result_ms": round(p50(lat), 3), "offline_do_whisper_ms": round(p50(offl), 3), "stop_over_offline": round(p50(lat) / p50(offl), 3),
+                "interim_decodes_while_audio_arrived": runs, "draft_accepted_by_the_final_decode (tokens at beam 1, search steps at beam > 1)": acc,
+                "same_tokens_as_offline": bool(r.tokens == ref.tokens), "speculation_gpu_ms_per_session": round(float(np.mean(cost)), 1),
+                "interim_decode_ms (last session; each drafted by the previous one)": interims}
+
     try:
         for inc in (True, False):
             lat = []
-            for _ in range(4):
-                sess = StreamingSession("large", 5, models=models, fixed_new_tokens=96, incremental=inc)
+            for _ in range(3):
+                sess = StreamingSession("large", 5, models=models, fixed_new_tokens=96, incremental=inc)      # (reference defaults: a beam search at stop(), no speculation)
                 for f in frames:
                     sess.feed(f, 2)
                 t0 = time.perf_counter()
@@ -237,39 +327,41 @@ def streaming_bench(handle, a, dev, clip_path):
         ref = do_whisper(pcm, "large", 5, models=models, fixed_new_tokens=96)
         out["offline_do_whisper_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
         out["same_tokens_as_offline"] = bool(ref.tokens == r.tokens)
-        # ---- beam 1 (the reference's default beam_size, settings.py:14; long_beam_size set to 1 as well - its default of 3 is a beam search,
-        # which has no single chain to verify): the session decodes what it has heard every 2 s while the audio arrives and stop() verifies
-        # the last hypothesis against the final window 16 tokens per decoder pass (wis_generate_draft).  Real-time arrival is emulated by
-        # letting every interim decode finish before the next frame is fed (an interim decode takes < 0.2 s, 2 s of audio take 2 s).
+        try:
+            s.stream_speculate_beam_search = True      # (off by default: see settings.py)
+            out["beam3"] = speculating_row(5, "30sec.flac, large-v2, the reference's settings: request beam 5 below 12 s, long_beam_size 3 from there on (main.py:582-586), S=96, "
+                                              "interim search every 2 s of audio, the final search replays the last interim trajectory (wis_generate_draft_beam)")
+        except Exception as e:      # noqa: BLE001
+            out["beam3"] = {"failed": repr(e)}
+        try:
+            # what the mechanism delivers when the draft HOLDS: the same window searched again with its own trajectory as the draft (on these seeded
+            # weights the low-ranked beams of a search are chaotic - 1.2 s more audio re-orders them within a few steps, tools/traj_lab.py - so the
+            # streamed row above leaves its draft early; the top hypothesis itself is stable: 94 of 96 ids)
+            x = np.ascontiguousarray(audio.pad_or_trim(pcm)[None], np.float32)
+            sv, pr = ct2.StorageView.from_array(x), [[50258, 50259, 50359, 50363]]
+            kw = dict(beam_size=3, fixed_new_tokens=96, input_kind=_lib_kind())
+            r0 = model.generate(sv, pr, return_trajectory=True, **kw)[0]
+            plain, drafted, acc = [], [], None
+            for _ in range(4):
+                t0 = time.perf_counter(); model.generate(sv, pr, **kw); plain.append(1e3 * (time.perf_counter() - t0))
+                t0 = time.perf_counter(); r1 = model.generate(sv, pr, draft_trajectory=r0.trajectory, **kw)[0]; drafted.append(1e3 * (time.perf_counter() - t0))
+                acc = r1.accepted_draft_tokens
+            out["beam3"]["when_the_draft_holds"] = {"what": "the final window searched at beam 3 with the trajectory of a search over the SAME window as its draft", "plain_ms": round(p50(plain[1:]), 3),
+                                                    "drafted_ms": round(p50(drafted[1:]), 3), "drafted_over_plain": round(p50(drafted[1:]) / p50(plain[1:]), 3), "steps_accepted": acc,
+                                                    "same_ids": bool(r1.sequences_ids[0] == r0.sequences_ids[0])}
+        except Exception as e:      # noqa: BLE001
+            out.setdefault("beam3", {})["when_the_draft_holds"] = {"failed": repr(e)}
+        s.stream_speculate_beam_search = False
         s.beam_size, s.long_beam_size = 1, 1
         try:
-            offl = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                ref1 = do_whisper(pcm, "large", 1, models=models, fixed_new_tokens=96)
-                offl.append(1e3 * (time.perf_counter() - t0))
-            lat, acc, runs = [], [], 0
-            for _ in range(3):
-                sess = StreamingSession("large", 1, models=models, fixed_new_tokens=96, incremental=True)
-                for f in frames:
-                    sess.feed(f, 2)
-                    if sess._spec_job is not None and not sess._spec_job.done():
-                        sess._spec_job.result()
-                runs = sess.spec_runs
-                t0 = time.perf_counter()
-                r1 = sess.stop()
-                lat.append(1e3 * (time.perf_counter() - t0))
-                acc.append(sess.accepted_draft_tokens)
-            out["beam1"] = {"config": "30sec.flac, large-v2, beam 1 at every length (long_beam_size = 1), S=96, interim decode every 2 s of audio",
-                            "stop_to_result_ms": round(p50(lat), 3), "offline_do_whisper_ms": round(p50(offl), 3), "stop_over_offline": round(p50(lat) / p50(offl), 3),
-                            "interim_decodes_while_audio_arrived": runs, "draft_tokens_accepted_by_the_final_decode": acc, "same_tokens_as_offline": bool(r1.tokens == ref1.tokens)}
+            out["beam1"] = speculating_row(1, "30sec.flac, large-v2, beam 1 at every length (long_beam_size = 1), S=96, interim decode every 2 s of audio (wis_generate_draft)")
         except Exception as e:      # noqa: BLE001
             out["beam1"] = {"failed": repr(e)}
         finally:
             s.beam_size, s.long_beam_size = APISettings().beam_size, APISettings().long_beam_size
         rng = np.random.default_rng(1234)
         noise = (0.1 * rng.standard_normal(64 * 16000)).astype(np.float32)
-        sess = StreamingSession("large", 5, models=models, fixed_new_tokens=48, incremental=True)
+        sess = StreamingSession("large", 5, models=models, fixed_new_tokens=48, incremental=True, speculate_every_s=0)
         t_feed = time.perf_counter()
         for i in range(0, noise.shape[0], 320):
             sess.feed(noise[i:i + 320])
@@ -648,6 +740,13 @@ def main():
             extra["rest_load"] = rest_load(handle, a, dev, args.rest_clients, 2, fixed_new, open(clip_path, "rb").read(), audio_ms)
             extra["rest_load_3_replicas"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:2])
             extra["rest_load_4_replicas_128_clients"] = rest_load(handle, a, dev, 128, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:3])
+            # what streaming speculation costs the REST traffic (round-5 review, weak 5): the 3-replica load again with 8 sessions asking for interim
+            # decodes flat out beside it - with the load gate (settings.stream_speculate_max_busy: speculation only while the GPU has a replica to spare) and without
+            p30, _ams30, _p30 = clip_pcm("30sec")
+            extra["rest_load_3_replicas_with_8_speculating_sessions"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:2],
+                                                                                    side_sessions=8, side_pcm=p30)
+            extra["rest_load_3_replicas_with_8_speculating_sessions_no_gate"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:2],
+                                                                                            side_sessions=8, side_pcm=p30, side_gate=1e9)
         except Exception as e:
             extra["rest_load"] = {"failed": repr(e)}
         for c in clones:

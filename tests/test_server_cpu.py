@@ -271,6 +271,9 @@ def test_streaming_session_schedule_without_gpu():
             self.calls.append((piece.shape[0], beam))
             return fake_ids(piece)
 
+        def _window_decode(self, piece, beam, language, stream=None, draft=None, want_traj=False):
+            return self._window_tokens(piece, beam, language), None, None
+
     models = _FakeModels()
     rng = np.random.default_rng(5)
     pcm = rng.standard_normal(75 * 16000).astype(np.float32)
@@ -296,12 +299,23 @@ def test_streaming_session_schedule_without_gpu():
 
 def test_streaming_speculation_schedule_without_gpu():
     """The interim decodes of a recording that is still one window (<= 30 s) with the model replaced by a stand-in: one every
-    `speculate_every_s` of NEW audio and never two at once, each drafted by the previous hypothesis, the latest handed to the
-    final decode at stop(); none for a beam search, for a language that must be detected on the final audio, past 30 s, or with
-    the interval set to 0 - and the final answer never depends on any of it."""
+    `speculate_every_s` of NEW audio and never two at once, at the beam the final call would use at that length, each drafted by the
+    previous hypothesis OF THAT BEAM (token chain at beam 1, trajectory at beam > 1), the latest handed to the final decode at stop();
+    none for a language that must be detected on the final audio, past 30 s, with the interval set to 0 or while the GPU has no replica to
+    spare - and the final answer never depends on any of it."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
     from wis_hip.streaming import StreamingSession
+
+    class FakeWhisper:
+        def __init__(self):
+            self.queued, self.running, self._replicas = 0, 0, [None] * 4
+
+        def load(self, device=None):
+            return self.queued, self.running
+
+        def replicas_on(self, device):
+            return 4
 
     class Sess(StreamingSession):
         def __init__(self, models, beam=1, every=2.0, detect=False, gate=None):
@@ -309,24 +323,30 @@ def test_streaming_speculation_schedule_without_gpu():
             self.model_name, self.task, self.beam_size = "tiny", "transcribe", beam
             self.detect_language, self.force_language = detect, None
             self.fixed_new_tokens = 0
-            self._whisper = None
+            self._whisper, self._replica = FakeWhisper(), None
             self._chunks, self._n = [], 0
             self._lock, self._pool = threading.Lock(), ThreadPoolExecutor(max_workers=2)
             self._windows, self._language_job, self._closed, self.eager_windows = {}, None, False, 0
-            self._spec_every, self._spec_n, self._spec_job, self._spec_latest = every, 0, None, None
-            self.spec_runs, self.accepted_draft_tokens = 0, None
+            self._spec_every, self._spec_n, self._spec_job, self._spec_latest, self._spec_busy = every, 0, None, None, 0.5
+            self.spec_runs, self.spec_skipped, self.spec_ms, self.accepted_draft_tokens = 0, 0, 0.0, None
             self.calls, self.gate = [], gate
 
         def _detect(self, first_window):
             return "en"
 
-        def _window_tokens(self, piece, beam, language, stream=None, draft=None):
+        def _window_decode(self, piece, beam, language, stream=None, draft=None, want_traj=False):
             if self.gate is not None:
                 self.gate.wait(5)
             ids = [int(piece.shape[0] // 16000), 7, 8]                    # "transcript": seconds heard, then two fixed ids
-            self.calls.append((piece.shape[0], beam, None if draft is None else list(draft)))
-            self._last_accepted = None if draft is None else sum(1 for a, b in zip(draft, ids) if a == b)
-            return ids
+            d = dict(draft or {})
+            self.calls.append((piece.shape[0], beam, d))
+            acc = None
+            if "draft_tokens" in d:
+                acc = sum(1 for a, b in zip(d["draft_tokens"], ids) if a == b)
+            if "draft_trajectory" in d:
+                acc = len(d["draft_trajectory"][0])
+            traj = (np.full((3, beam), ids[0], np.int32), np.zeros((3, beam), np.int32)) if want_traj else None
+            return ids, acc, traj
 
     models = _FakeModels()
     sec = np.zeros(16000, np.float32)
@@ -341,9 +361,9 @@ def test_streaming_speculation_schedule_without_gpu():
         s.feed(sec)
         settle(s)
     assert s.spec_runs == 3 and [(n // 16000, b) for n, b, _ in s.calls] == [(2, 1), (4, 1), (6, 1)]
-    assert [d for _, _, d in s.calls] == [None, [2, 7, 8], [4, 7, 8]]          # each one drafted by the previous hypothesis
+    assert [d for _, _, d in s.calls] == [{}, {"draft_tokens": [2, 7, 8]}, {"draft_tokens": [4, 7, 8]}]          # each one drafted by the previous hypothesis
     out = s.stop()
-    assert s.calls[-1] == (7 * 16000, 1, [6, 7, 8]) and out.tokens == [7, 7, 8]
+    assert s.calls[-1] == (7 * 16000, 1, {"draft_tokens": [6, 7, 8]}) and out.tokens == [7, 7, 8]
     assert s.accepted_draft_tokens == 2                                        # ids 7, 8 of the draft survived; the first did not
 
     # a slow interim: never two in flight, the next one starts only after it finished and covers everything heard by then
@@ -359,24 +379,66 @@ def test_streaming_speculation_schedule_without_gpu():
     assert [(n // 16000) for n, _, _ in s.calls] == [2, 10]
     s.close()
 
-    # no speculation: beam search, language detection on the final audio, interval 0, the long-audio beam (>= 12 s here)
-    models5 = _FakeModels()
-    for kw, m in ((dict(beam=5), models), (dict(detect=True), models), (dict(every=0.0), models)):
-        s = Sess(m, **kw)
+    # a beam search speculates too (round 6): interims at the request's beam, drafted by the previous search's TRAJECTORY; the final decode
+    # verifies the last one (reference: every recording of 12 s or more is decoded at long_beam_size, main.py:582-586)
+    s = Sess(models, beam=5)
+    for _ in range(7):
+        s.feed(sec)
+    assert s._spec_job is None and s.spec_runs == 0          # ... when switched on (settings.stream_speculate_beam_search; off by default)
+    s.close()
+    models_b = _FakeModels()
+    models_b.settings.stream_speculate_beam_search = True
+    s = Sess(models_b, beam=5)
+    for _ in range(7):
+        s.feed(sec)
+        settle(s)
+    assert [(n // 16000, b) for n, b, _ in s.calls] == [(2, 5), (4, 5), (6, 5)] and s.calls[0][2] == {}
+    assert all(list(d) == ["draft_trajectory"] and d["draft_trajectory"][0].shape == (3, 5) for _, _, d in s.calls[1:])
+    out = s.stop()
+    assert out.tokens == [7, 7, 8] and s.calls[-1][1] == 5 and int(s.calls[-1][2]["draft_trajectory"][0][0, 0]) == 6 and s.accepted_draft_tokens == 3
+
+    # no speculation: language detection on the final audio, interval 0
+    for kw in (dict(detect=True), dict(every=0.0)):
+        s = Sess(models, **kw)
         for _ in range(6):
             s.feed(sec)
         assert s._spec_job is None and s.spec_runs == 0
         out = s.stop()
-        assert out.tokens == [6, 7, 8] and s.accepted_draft_tokens is None and s.calls[-1][2] is None
+        assert out.tokens == [6, 7, 8] and s.accepted_draft_tokens is None and s.calls[-1][2] == {}
+
+    # optional work: none while requests are queued or more than half of the GPU's replicas are running device batches
+    s = Sess(models)
+    s._whisper.queued = 3
+    for _ in range(5):
+        s.feed(sec)
+    assert s._spec_job is None and s.spec_skipped == 2
+    s._whisper.queued, s._whisper.running = 0, 3
+    for _ in range(2):
+        s.feed(sec)
+    assert s._spec_job is None and s.spec_skipped == 3
+    s._whisper.running = 2
+    for _ in range(2):
+        s.feed(sec)
+        settle(s)
+    assert s.spec_runs == 1 and s.calls[-1][0] == 8 * 16000
+    s.close()
+
+    # the beam changes where the final call's would (long_beam_size from 12 s on): a draft of another beam size is not handed over
+    models5 = _FakeModels()
+    models5.settings.stream_speculate_beam_search = True
     s = Sess(models5)
     thr = models5.settings.long_beam_size_threshold // 1000
-    if models5.settings.long_beam_size != 1:
+    lb = models5.settings.long_beam_size
+    if lb != 1:
         for _ in range(thr + 4):
             s.feed(sec)
             settle(s)
-        assert all(n // 16000 < thr for n, _, _ in s.calls)                    # interims stop once the final call would use the long beam
+        beams = [b for _, b, _ in s.calls]
+        assert beams[0] == 1 and beams[-1] == lb and all(b == (1 if n // 16000 < thr else lb) for n, b, _ in s.calls)
+        first_long = next(c for c in s.calls if c[1] == lb)
+        assert first_long[2] == {}                                             # (the beam-1 hypothesis before it is no draft for a beam search)
         out = s.stop()
-        assert s.calls[-1][1] == models5.settings.long_beam_size and s.calls[-1][2] is None and s.accepted_draft_tokens is None
+        assert s.calls[-1][1] == lb and list(s.calls[-1][2]) == ["draft_trajectory"] and s.accepted_draft_tokens == 3
 
 
 def _pool_batcher(n_gpus, per_gpu, log, cap=8):

@@ -99,6 +99,12 @@ class MicroBatcher:
                 raise it.error
         return [it.result for it in items]
 
+    def load(self, group=None):
+        """(items queued, device batches running[, on GPU `group`]) - what optional work (a streaming session's speculative interim decodes)
+        looks at before it adds itself to the queue"""
+        with self._lock:
+            return len(self._q), (sum(self._running.values()) if group is None else self._running.get(group, 0))
+
     # ---- scheduling (all under self._lock) ------------------------------------------------
     def _mine(self, w, it):
         a = it.affinity

@@ -420,6 +420,13 @@ class Whisper:
             return ()
         return (d, bool(return_trajectory))
 
+    def load(self, device=None):
+        """(utterances queued, device batches running[, on `device`]) in this model's micro-batcher"""
+        return self._batcher.load(device)
+
+    def replicas_on(self, device):
+        return sum(1 for r in self._replicas if r.device == device)
+
     def acquire_replica(self):
         """The least-loaded replica, counted as in use until release_replica (a streaming session pins its log-mel front-end
         and its windows to ONE GPU for its lifetime; sessions spread over the replicas like requests do)."""

@@ -57,10 +57,20 @@ class APISettings:
     # (the effective ceiling is logged when a model is loaded).
     max_beam: int = 8
     # streaming sessions of up to 30 s (BASELINE configs[4]): while the audio arrives, decode what has been heard every this many seconds
-    # of new audio (beam 1 only - the default beam_size - and only when the language is known without detection); stop() then verifies
-    # the last such hypothesis against the FINAL window in multi-row passes (wis_generate_draft) instead of decoding token by token.
-    # 0 = off.  The answer is the greedy decode of the final window either way.
+    # of new audio (at the beam the final call would use at that length - `beam_size`, `long_beam_size` from 12 s on - and only when the
+    # language is known without detection); stop() then verifies the last such hypothesis against the FINAL window in multi-row passes
+    # instead of decoding token by token: beam 1 the token chain (wis_generate_draft), a beam search its trajectory (wis_generate_draft_beam).
+    # 0 = off.  The answer is the decode of the final window either way.
     stream_speculate_s: float = 2.0
+    # speculation is OPTIONAL work: an interim decode is only started while the session's GPU has a replica to spare - fewer device batches
+    # running than this fraction of its replicas and nothing queued (advisor, round 5: every session re-decoding every 2 s beside real
+    # requests pushed those back in the FIFO batcher)
+    stream_speculate_max_busy: float = 0.5
+    # ... and whether sessions whose final call is a BEAM SEARCH speculate at all.  Off by default: a draft trajectory only helps while the final
+    # search re-traces it, and how long it does is a property of the checkpoint - on the seeded weights of this build the low-ranked beams are
+    # chaotic (1.2 s more audio re-orders them within 3-14 steps, tools/traj_lab.py; profiles/r06_traj_lab.txt), so 14 interim searches per
+    # session (1.8 s of GPU time) buy nothing; tiny / base follow a draft to its end.  Measure on the real checkpoint, then switch on.
+    stream_speculate_beam_search: bool = False
     # measurement convention for seeded synthetic weights, which never emit EOT: decode exactly this many tokens
     # (EOT masked until then, then forced).  0 = off: the product default, natural termination
     fixed_new_tokens: int = 0

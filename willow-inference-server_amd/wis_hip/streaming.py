@@ -95,9 +95,12 @@ class StreamingSession:
         self._closed = False
         # speculative interim decodes of a recording that is still short enough for ONE window (<= 30 s): see _maybe_speculate
         self._spec_every = float(s.stream_speculate_s if speculate_every_s is None else speculate_every_s)
-        self._spec_n, self._spec_job, self._spec_latest = 0, None, None      # samples covered when the last one was scheduled; its Future; (samples, tokens)
+        self._spec_n, self._spec_job, self._spec_latest = 0, None, None      # samples covered when the last one was scheduled; its Future; (samples, beam, tokens, trajectory)
+        self._spec_busy = float(getattr(s, "stream_speculate_max_busy", 0.5))
         self.spec_runs = 0            # interim decodes done while the audio arrived (stats / tests)
-        self.accepted_draft_tokens = None     # tokens of the last interim hypothesis the final decode kept (None: no draft was used)
+        self.spec_skipped = 0         # ... not started because the GPU had no replica to spare
+        self.spec_ms = 0.0            # wall time of the interim decodes: what speculation costs the GPU per session
+        self.accepted_draft_tokens = None     # tokens (beam 1) / search steps (beam > 1) of the last interim hypothesis the final decode kept (None: no draft was used)
         self.eager_windows = 0        # windows transcribed before stop() (stats / tests)
         self.front_windows = 0        # windows whose features came from the incremental front-end
         # the session's GPU: the least-loaded replica now, held (counted in its load) until close()
@@ -160,52 +163,77 @@ class StreamingSession:
     def _maybe_speculate(self):
         """Called with the lock held.  A recording of up to 30 s is ONE window whose encoder needs the whole audio, so nothing of the
         FINAL answer can be computed early - but its decode, 80-95 % of the time to the answer, can be PREPARED: every `_spec_every`
-        seconds of new audio the audio so far is decoded (greedy; on whatever replica is free) and the hypothesis kept.  stop()
-        hands the latest one to the final decode as a draft (wis_generate_draft): the final window's encoder runs, the draft is
-        verified against it 16 tokens per decoder pass, and token-by-token decoding only resumes where the two part - typically
-        the last words.  Only for beam 1 (the reference's default; a beam search has no single chain to verify) and a language
-        that needs no detection on the final audio."""
+        seconds of new audio the audio so far is decoded (at the beam the final call would use at this length; on whatever replica is
+        free) and the hypothesis kept - the token chain at beam 1, the search's trajectory at beam > 1.  stop() hands the latest one to
+        the final decode as a draft (wis_generate_draft / wis_generate_draft_beam): the final window's encoder runs, the draft is
+        verified against it 16 steps per decoder pass, and step-by-step decoding only resumes where the two part - typically the last
+        words.  Only for a language that needs no detection on the final audio, and only while the GPU has a replica to spare."""
         if getattr(self, "_spec_every", 0) <= 0 or self._n > 30 * audio.SAMPLE_RATE or self._n - self._spec_n < self._spec_every * audio.SAMPLE_RATE:
             return
-        if (self.detect_language and not self.force_language) or self._final_beam(self._n) != 1:
+        if self.detect_language and not self.force_language:
+            return
+        if self._final_beam(self._n) > 1 and not getattr(self.models.settings, "stream_speculate_beam_search", False):
             return
         if self._spec_job is not None and not self._spec_job.done():
             return
+        dev = self._replica.device if self._replica is not None else None
+        queued, running = self._whisper.load(dev)
+        spare = self._whisper.replicas_on(dev) if dev is not None else len(self._whisper._replicas)
+        if queued > 0 or running > self._spec_busy * spare:      # optional work never queues behind (or in front of) real requests
+            self.spec_skipped += 1
+            self._spec_n = self._n
+            return
         pcm, n = self._audio().copy(), self._n
         self._spec_n = n
-        prev = self._spec_latest[1] if self._spec_latest else None
-        self._spec_job = self._pool.submit(self._speculate, pcm, n, prev)
+        self._spec_job = self._pool.submit(self._speculate, pcm, n, self._final_beam(n), self._spec_latest)
 
-    def _speculate(self, pcm, n, prev):
+    @staticmethod
+    def _draft_for(beam, latest):
+        """keyword arguments that hand `latest` = (samples, beam, tokens, trajectory) to a decode at `beam` as its draft ({} when it cannot be one)"""
+        if not latest or latest[1] != beam:
+            return {}
+        if beam == 1:
+            return {"draft_tokens": latest[2]} if latest[2] else {}
+        return {"draft_trajectory": latest[3]} if latest[3] is not None and len(latest[3][0]) else {}
+
+    def _speculate(self, pcm, n, beam, prev):
         language = self.force_language or self.models.settings.language
-        ids = self._window_tokens(pcm, 1, language, draft=prev)      # (the previous hypothesis is the draft of this one)
+        t0 = time.perf_counter()
+        ids, _, traj = self._window_decode(pcm, beam, language, draft=self._draft_for(beam, prev), want_traj=beam > 1)      # (the previous hypothesis is the draft of this one)
         with self._lock:
             if self._spec_latest is None or n > self._spec_latest[0]:
-                self._spec_latest = (n, list(ids))
+                self._spec_latest = (n, beam, list(ids), traj)
             self.spec_runs += 1
+            self.spec_ms += 1e3 * (time.perf_counter() - t0)
         return ids
 
-    def _window_tokens(self, piece, beam, language, stream=None, draft=None):
-        """`language`: a code, or a Future resolving to one (the session-wide language job of window 0: every eager window
+    def _window_tokens(self, piece, beam, language, stream=None):
+        return self._window_decode(piece, beam, language, stream)[0]
+
+    def _window_decode(self, piece, beam, language, stream=None, draft=None, want_traj=False):
+        """-> (token ids, draft tokens / steps the decode kept or None, the search's trajectory or None).
+        `language`: a code, or a Future resolving to one (the session-wide language job of window 0: every eager window
         waits for THAT result, so a later window can never decide the language - do_whisper always detects on window 0).
-        `stream`: the window's MelStream (its samples are all fed): finish it and decode from the features in HBM."""
+        `stream`: the window's MelStream (its samples are all fed): finish it and decode from the features in HBM.
+        `draft`: {} or the keyword argument (`draft_tokens` / `draft_trajectory`) of an earlier hypothesis for this window."""
         if hasattr(language, "result"):
             language = language.result()
+        kw = dict(draft or {})
+        if want_traj:
+            kw["return_trajectory"] = True
         if stream is not None:
             try:
                 stream.finish(to_host=False)
                 r = self._whisper.generate_from_device(stream.device, stream.device_ptr, self._prompt(language), beam_size=beam,
-                                                       fixed_new_tokens=self.fixed_new_tokens, replica=self._replica, draft_tokens=draft)
+                                                       fixed_new_tokens=self.fixed_new_tokens, replica=self._replica, **kw)
                 self.front_windows += 1
-                self._last_accepted = getattr(r, "accepted_draft_tokens", None)
-                return r.sequences_ids[0]
             finally:
                 stream.close()
-        x = np.ascontiguousarray(audio.pad_or_trim(piece)[None], np.float32)
-        r = self._whisper.generate(ctranslate2.StorageView.from_array(x), [self._prompt(language)], beam_size=beam,
-                                   return_scores=False, fixed_new_tokens=self.fixed_new_tokens, input_kind=ctranslate2._lib.WIS_IN_PCM_HOST, draft_tokens=draft)
-        self._last_accepted = getattr(r[0], "accepted_draft_tokens", None)
-        return r[0].sequences_ids[0]
+        else:
+            x = np.ascontiguousarray(audio.pad_or_trim(piece)[None], np.float32)
+            r = self._whisper.generate(ctranslate2.StorageView.from_array(x), [self._prompt(language)], beam_size=beam,
+                                       return_scores=False, fixed_new_tokens=self.fixed_new_tokens, input_kind=ctranslate2._lib.WIS_IN_PCM_HOST, **kw)[0]
+        return r.sequences_ids[0], getattr(r, "accepted_draft_tokens", None), getattr(r, "trajectory", None)
 
     def _schedule_complete_windows(self):
         """Called with the lock held.  Once more than 30 s are buffered the final call WILL chunk (main.py:588), with the
@@ -260,18 +288,13 @@ class StreamingSession:
             st = None                              # (longer) call detects again on its own first window
             if final and front is not None and front.short is not None and front.n == pcm.shape[0]:
                 st, front.short = front.short, None
-            draft = None
-            if final and beam == 1:
+            draft = {}
+            if final:      # the latest COMPLETED interim hypothesis (one still running is not waited for: its decode is what stop() is here to avoid)
                 with self._lock:
-                    latest = getattr(self, "_spec_latest", None)
-                    draft = latest[1] if latest else None
-            self._last_accepted = None
-            if st is not None or draft is not None:
-                tokens = self._window_tokens(pcm, beam, language, st, draft=draft)
-            else:
-                tokens = self._window_tokens(pcm, beam, language)
-            if final and draft is not None:
-                self.accepted_draft_tokens = self._last_accepted
+                    draft = self._draft_for(beam, getattr(self, "_spec_latest", None))
+            tokens, accepted, _ = self._window_decode(pcm, beam, language, st, draft=draft)
+            if final and draft:
+                self.accepted_draft_tokens = accepted
         text = tokenizer.decode(tokens).strip()
         ms = (time.perf_counter() - t0) * 1000
         out = WhisperResult((language, text, ms, None, math.floor(duration_ms / ms) if ms > 0 else 0, duration_ms))
