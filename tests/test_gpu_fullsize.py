@@ -167,6 +167,49 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
         else:
             assert abs(gscore - score) <= 1e-2
     if size == "large":
+        # ---- the DRAFT-VERIFIED decodes (BASELINE configs[4]: the final call of a streamed recording, main.py:963-971) at this size against the
+        # oracle: beam 1 (wis_generate_draft: token chain verified 16 positions per pass) and beam 3 - the reference's long-audio beam,
+        # main.py:582-586 - (wis_generate_draft_beam: the trajectory of an earlier search replayed 16 steps per pass), same bars as the plain calls
+        from test_gpu_draft_beam import tree_chains, tree_logits
+        ids1, score1, trace1 = ref.generate(None, PROMPT, beam_size=1, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN,
+                                            fixed_new=S, memory=mem[ci].numpy(), return_trace=True)
+        for name, d in (("the oracle's greedy ids", list(ids1)), ("their first half + garbage", list(ids1[:S // 2]) + [1000 + i for i in range(12)])):
+            rd = model.generate(feats, [PROMPT], beam_size=1, fixed_new_tokens=S, draft_tokens=d)[0]
+            got, gscore = rd.sequences_ids[0], rd.scores[0]
+            rescored = _oracle_rescore(ref, mem[ci].numpy(), got, S)
+            print(f"large beam 1 DRAFTED by {name}: accepted {rd.accepted_draft_tokens} tokens, oracle margin {min(trace1):.5f}, hip score {gscore:.5f}, oracle rescoring {rescored:.5f}, identical {got == ids1}")
+            assert len(got) == S and abs(gscore - rescored) <= 3e-3 and rescored >= score1 - 1e-2
+            if min(trace1) > 0.02:
+                assert got == ids1
+        ids3, score3, trace3 = ref.generate(None, PROMPT, beam_size=3, suppress_ids=W.SUPPRESS_IDS, suppress_begin=W.SUPPRESS_IDS_BEGIN,
+                                            fixed_new=S, memory=mem[ci].numpy(), return_trace=True)
+        r3 = model.generate(feats, [PROMPT], beam_size=3, fixed_new_tokens=S, return_trajectory=True)[0]
+        tok3, org3 = r3.trajectory
+        half = (tok3[:S // 2].copy(), org3[:S // 2].copy())
+        for name, d in (("no draft", None), ("its own trajectory", (tok3, org3)), ("the first half of it", half)):
+            rd = r3 if d is None else model.generate(feats, [PROMPT], beam_size=3, fixed_new_tokens=S, draft_trajectory=d)[0]
+            got, gscore = rd.sequences_ids[0], rd.scores[0]
+            rescored = _oracle_rescore(ref, mem[ci].numpy(), got, S)
+            print(f"large beam 3, {name}: accepted {getattr(rd, 'accepted_draft_tokens', None)} steps, oracle score {score3:.5f} margin {min(trace3):.5f} | hip score {gscore:.5f}, "
+                  f"oracle rescoring of the hip ids {rescored:.5f}, identical to the oracle {got == ids3}, to the undrafted call {got == r3.sequences_ids[0]}")
+            assert len(got) == S and EOT not in got and abs(gscore - rescored) <= 3e-3 and rescored >= score3 - 1e-2
+            if min(trace3) > 0.02:
+                assert got == ids3
+            if d is not None:
+                assert rd.accepted_draft_tokens >= 2          # (the steps a draft is followed for are bounded by the search's near-ties: see tools/tree_lab.py)
+        # the verification pass itself, node by node, against the oracle: 6 steps x 3 beams of the engine's own trajectory + a random tree
+        rngt = np.random.default_rng(9)
+        for name, (tt, oo) in (("the search's own tree", (tok3[:6], org3[:6])),
+                               ("a random tree", (rngt.integers(0, 50000, (6, 3)).astype(np.int32), rngt.integers(0, 3, (6, 3)).astype(np.int32)))):
+            lg = tree_logits(model, mels[ci], PROMPT, tt, oo)
+            ch = tree_chains(PROMPT, tt, oo)
+            worst = 0.0
+            for st_ in range(6):
+                exp = ref.decode_logits(np.array(ch[st_]), mem[ci:ci + 1].expand(3, -1, -1))[:, -1].numpy()
+                worst = max(worst, float(np.abs(lg[st_] - exp).max()))
+            print(f"large tree pass on {name}: 18 rows, logits max abs err vs the oracle {worst:.3e}")
+            assert worst <= 5e-2
+    if size == "large":
         # ---- BASELINE configs[3] shape against the ORACLE (reference call main.py:685-693 under client/jmeter-asr.jmx load): eight
         # utterances x beam 5 in ONE device batch (40 decoder rows: the fragment-image route end to end - prefill, KV reorder, beam
         # bookkeeping per utterance) - every utterance must come back with the oracle's answer for ITS clip
@@ -231,6 +274,26 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
             if margin > EOT_MARGIN:
                 assert got == ids
             exact += got == ids
+        # ---- natural termination through the DRAFT-VERIFIED decodes at this size (beam 1 and the reference's long-audio beam 3): the search ends on
+        # EOT inside or behind the verified steps; against the oracle under the margin rule
+        for bm in (1, 3):
+            ids_o, score_o, trace_o = ref_r.generate(None, prompts2[0], beam_size=bm, suppress_ids=W2.SUPPRESS_IDS, suppress_begin=W2.SUPPRESS_IDS_BEGIN, memory=memory, return_trace=True)
+            plain = model_r.generate(feats1, [prompts2[0]], beam_size=bm, return_trajectory=True)[0]
+            drafts = {"no draft": {}}
+            if bm == 1:
+                drafts.update({"the oracle's ids": dict(draft_tokens=list(ids_o)), "half of them + garbage": dict(draft_tokens=list(ids_o[:len(ids_o) // 2]) + [2000 + i for i in range(10)])})
+            else:
+                tk, og = plain.trajectory
+                drafts.update({"its own trajectory": dict(draft_trajectory=(tk, og)), "half of it": dict(draft_trajectory=(tk[:len(tk) // 2].copy(), og[:len(og) // 2].copy()))})
+            for name, kw in drafts.items():
+                rd = plain if not kw else model_r.generate(feats1, [prompts2[0]], beam_size=bm, **kw)[0]
+                got, gscore = rd.sequences_ids[0], rd.scores[0]
+                rescored = oracle_rescore(ref_r, memory, prompts2[0], got, 224)
+                print(f"  large, natural EOT, beam {bm}, {name}: accepted {getattr(rd, 'accepted_draft_tokens', None)}; oracle len {len(ids_o)} score {score_o:.5f} margin {min(trace_o):.4f} | hip len {len(got)} "
+                      f"score {gscore:.5f}, oracle rescoring {rescored:.5f}, identical {got == ids_o}")
+                assert EOT not in got and abs(gscore - rescored) <= 3e-3 and rescored >= score_o - 0.1
+                if min(trace_o) > EOT_MARGIN:
+                    assert got == ids_o
         finish = {pi: want[pi][3]["finish_step"] for pi in want}
         print(f"large, natural EOT: {exact} of 9 identical to the oracle; finish steps of the four prompts {finish}; engine ran {model_r.last_timing()['decode_steps']} steps")
         assert len(set(finish.values())) >= 3 and max(finish.values()) < 60 and exact >= 7          # utterances of ONE device batch end at >= 3 different steps
