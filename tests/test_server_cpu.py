@@ -556,3 +556,74 @@ def test_device_affinity_lets_any_replica_of_that_gpu_take_the_rows_and_they_coa
     assert sum(n for _, n in dev) == 6 and len(dev) <= 3   # six rows at capacity 4: two or three batches, not six
     assert sum(n for _, _, _, n, key in log if key == "host") == 3
     mb.close()
+
+
+def test_one_server_process_per_gpu_behind_one_port():
+    """`python -m wis_hip.server --workers-per-node N` (the deployment that serves a node: reference entrypoint.sh:19-21 runs ONE gunicorn worker over
+    `device_index=[*range(n)]`, main.py:295; one Python process answers ~380 requests/s, an MI355X decodes ~170 utterances/s of the jmeter shape):
+    N server processes share the port (SO_REUSEPORT), each with its own model replicas / micro-batcher, supervised by the parent.  Fake engine
+    (tools/fake_engine_app.py: a device batch of B costs 30 + 4 B ms on a GPU that runs one batch at a time), raw-socket load generator in a
+    process of its own (tools/host_ceiling.py): every worker takes traffic, nothing fails, saturated workers form full device batches, the
+    supervisor restarts a worker that dies and drains the node on SIGTERM."""
+    import json
+    import os
+    import signal
+    import socket
+    import subprocess
+    import sys
+    import time
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # ---- throughput / batching through the tool (4 processes: the build container has 8 cores for servers AND generator)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_ceiling.py"), "--processes", "4", "--replicas", "1", "--clients", "96", "--client-procs", "1", "--seconds", "3"],
+                         capture_output=True, text=True, timeout=180)
+    line = next((ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")), None)
+    assert line, out.stdout + out.stderr
+    r = json.loads(line[7:])
+    print(out.stdout.strip().splitlines()[-2])
+    assert r["errors"] == 0 and r["supervisor_exit"] == 0
+    assert len(r["batches_per_worker"]) == 4 and min(r["batches_per_worker"]) > 0          # the kernel spread the connections over every listener
+    assert r["mean_device_batch"] >= 6.0, r                                                # 24 connections per one-batch-at-a-time GPU: the batches fill
+    assert r["requests_per_s"] >= 0.6 * 4 * 8 / 0.062, r                                   # engine capacity 516 requests/s; the host keeps up with most of it
+    # ---- supervision: a worker that dies is replaced, SIGTERM drains the node
+    with socket.socket() as s0:
+        s0.bind(("127.0.0.1", 0))
+        port = s0.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tools"), os.path.join(ROOT, "willow-inference-server_amd"), os.environ.get("PYTHONPATH", "")]))
+    env.pop("HIP_VISIBLE_DEVICES", None)
+    sup = subprocess.Popen([sys.executable, "-m", "wis_hip.server", "--host", "127.0.0.1", "--port", str(port), "--workers-per-node", "2", "--app", "fake_engine_app:create_app",
+                            "--log-level", "warning", "--graceful-timeout", "3"], env=env)
+
+    def ping():
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=1) as c:
+                c.sendall(b"GET /api/ping HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n")
+                return b"200" in c.recv(64)
+        except OSError:
+            return False
+
+    def children():
+        o = subprocess.run(["ps", "-o", "pid=", "--ppid", str(sup.pid)], capture_output=True, text=True).stdout.split()
+        return sorted(int(x) for x in o)
+
+    try:
+        t_end = time.time() + 60
+        while time.time() < t_end and not (len(children()) == 2 and all(ping() for _ in range(6))):
+            time.sleep(0.2)
+        kids = children()
+        assert len(kids) == 2 and ping()
+        os.kill(kids[0], signal.SIGKILL)
+        t_end = time.time() + 30
+        while time.time() < t_end and (len(children()) != 2 or kids[0] in children()):
+            time.sleep(0.2)
+        assert len(children()) == 2 and kids[0] not in children()                             # replaced
+        t_end = time.time() + 30
+        while time.time() < t_end and not all(ping() for _ in range(8)):
+            time.sleep(0.3)
+        assert all(ping() for _ in range(8))                                                  # both listeners answer again
+        sup.send_signal(signal.SIGTERM)
+        assert sup.wait(20) == 0
+        time.sleep(0.3)
+        assert not ping()
+    finally:
+        if sup.poll() is None:
+            sup.kill()

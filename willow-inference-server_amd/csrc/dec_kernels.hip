@@ -2252,7 +2252,7 @@ __global__ __launch_bounds__(256) void kv_reorder_kernel(f16* __restrict__ kc, f
     for (int ch = tid; ch < c8; ch += 256) {
       u32x4 v[MAX_R];
 #pragma unroll
-      for (int j = 0; j < MAX_R; ++j) if (j < k) v[j] = *reinterpret_cast<const u32x4*>(cache + ((size_t)par[j] * ctx + p) * d + ch * 8);
+      for (int j = 0; j < MAX_R; ++j) if (j < k && par[j] != r0 + j) v[j] = *reinterpret_cast<const u32x4*>(cache + ((size_t)par[j] * ctx + p) * d + ch * 8);      // (a slot that continues itself moves nothing: neither read nor written)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every parent chunk is in registers before any row is overwritten
 #pragma unroll
       for (int j = 0; j < MAX_R; ++j) if (j < k && par[j] != r0 + j) *reinterpret_cast<u32x4*>(cache + ((size_t)(r0 + j) * ctx + p) * d + ch * 8) = v[j];

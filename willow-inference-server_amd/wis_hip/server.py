@@ -233,17 +233,122 @@ def create_app(models=None, settings=None, max_workers=None):
     return app
 
 
+def _listen_socket(host, port):
+    """A listening socket of its own on the SHARED (host, port): SO_REUSEPORT lets every worker process bind the same address and the kernel
+    spreads incoming connections over the listeners (by a hash of the connection's addresses) - one port for the node, no proxy process in
+    the data path."""
+    import socket
+    fam = socket.AF_INET6 if ":" in host else socket.AF_INET
+    sock = socket.socket(fam, socket.SOCK_STREAM)
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEPORT, 1)
+    sock.bind((host, port))
+    sock.listen(2048)
+    return sock
+
+
+def _load_factory(spec):
+    """'package.module:callable' -> the callable (default: this module's create_app; tests / tools/host_ceiling.py serve a fake-engine app)"""
+    import importlib
+    mod, _, name = spec.partition(":")
+    return getattr(importlib.import_module(mod), name or "create_app")
+
+
+def serve_worker(args):
+    """One server process of a node (spawned by `supervise`): sees ONE GPU (the parent set HIP_VISIBLE_DEVICES before this interpreter
+    started, so device 0 here is the node's device `args.device`), listens on the shared port, drains on SIGTERM (uvicorn: stops accepting,
+    finishes the requests in flight)."""
+    import uvicorn
+    app = _load_factory(args.app)()
+    config = uvicorn.Config(app, log_level=args.log_level, timeout_graceful_shutdown=args.graceful_timeout, timeout_keep_alive=3600,
+                            forwarded_allow_ips=os.environ.get("FORWARDED_ALLOW_IPS", "127.0.0.1"))
+    logger.info("worker %d: GPU %s, pid %d, %s:%d", args.worker_index, os.environ.get("HIP_VISIBLE_DEVICES", "all"), os.getpid(), args.host, args.port)
+    uvicorn.Server(config).run(sockets=[_listen_socket(args.host, args.port)])
+
+
+def supervise(args, devices):
+    """`--workers-per-node N`: N server processes behind ONE port - the deployment that serves a node (utterances shard over
+    the GPUs with no exchange; reference main.py:295 `device_index=[*range(n)]` inside one gunicorn worker, entrypoint.sh:19-21).  One Python
+    process answers 370-390 requests/s (tools/host_ceiling.py: ASGI + multipart + FLAC decode + batching under the GIL), an MI355X decodes
+    ~170 utterances/s of the jmeter shape, so ONE process cannot feed eight GPUs: each GPU gets a process of its own (its model replicas, its
+    micro-batcher, its thread pool), pinned with HIP_VISIBLE_DEVICES, all listening on the same address with SO_REUSEPORT.  This parent only
+    supervises: it restarts a worker that dies (three times, then gives the node up), forwards SIGTERM / SIGINT and waits `--graceful-timeout`
+    seconds for the workers to drain before it kills what is left (the reference's gunicorn flags: --graceful-timeout 10)."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    n = args.workers_per_node
+    base = [sys.executable, "-m", "wis_hip.server", "--host", args.host, "--port", str(args.port), "--log-level", args.log_level, "--app", args.app,
+            "--graceful-timeout", str(args.graceful_timeout)]
+    procs, restarts, stopping = {}, {}, []
+
+    def spawn(i):
+        env = dict(os.environ)
+        if devices:
+            env["HIP_VISIBLE_DEVICES"] = str(devices[i % len(devices)])
+        env["WIS_WORKER_INDEX"] = str(i)
+        procs[i] = subprocess.Popen(base + ["--worker-index", str(i)], env=env)
+
+    def stop(signum, _frame):
+        stopping.append(signum)
+
+    signal.signal(signal.SIGTERM, stop)
+    signal.signal(signal.SIGINT, stop)
+    for i in range(n):
+        spawn(i)
+    logger.info("supervisor pid %d: %d worker processes on %s:%d (GPUs %s)", os.getpid(), n, args.host, args.port, devices or "unpinned")
+    rc = 0
+    while not stopping:
+        time.sleep(0.2)
+        for i, p in list(procs.items()):
+            if p.poll() is not None and not stopping:
+                restarts[i] = restarts.get(i, 0) + 1
+                logger.warning("worker %d (pid %d) exited with %s", i, p.pid, p.returncode)
+                if restarts[i] > 3:
+                    logger.error("worker %d keeps dying: shutting the node down", i)
+                    stopping.append(signal.SIGTERM)
+                    rc = 1
+                    break
+                spawn(i)
+    for p in procs.values():
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)
+    deadline = time.time() + args.graceful_timeout + 2
+    for p in procs.values():
+        try:
+            p.wait(max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
 def main(argv=None):
-    """`python -m wis_hip.server [--host 0.0.0.0] [--port 19000]` - the reference serves on 19000 behind nginx
-    (entrypoint.sh:19-21, nginx.conf:99-103)."""
+    """`python -m wis_hip.server [--host 0.0.0.0] [--port 19000] [--workers-per-node N]` - the reference serves on 19000 behind nginx
+    (entrypoint.sh:19-21, nginx.conf:99-103).  N > 1: one server process per GPU behind the one port (supervise)."""
     import argparse
     import uvicorn
     ap = argparse.ArgumentParser(description="Willow Inference Server ASR endpoints over the MI355X HIP path")
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--port", type=int, default=19000)
     ap.add_argument("--log-level", default=os.environ.get("LOG_LEVEL", "info"))
+    ap.add_argument("--workers-per-node", type=int, default=1, help="server processes behind the one port: one per GPU (0 = one per visible GPU)")
+    ap.add_argument("--devices", default="", help="comma-separated GPU ids the workers are pinned to, round-robin (default: 0 .. workers-1)")
+    ap.add_argument("--graceful-timeout", type=int, default=10, help="seconds a worker may take to finish the requests in flight on SIGTERM")
+    ap.add_argument("--app", default="wis_hip.server:create_app", help="module:factory of the ASGI app the workers serve")
+    ap.add_argument("--worker-index", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
-    uvicorn.run(create_app(), host=args.host, port=args.port, log_level=args.log_level)
+    logging.basicConfig(level=getattr(logging, args.log_level.upper(), logging.INFO))
+    if args.worker_index is not None:
+        return serve_worker(args)
+    n = args.workers_per_node
+    if n == 0:
+        from . import _lib
+        n = args.workers_per_node = max(1, _lib.device_count())
+    if n > 1:
+        devices = [int(d) for d in args.devices.split(",") if d.strip()] or list(range(n))
+        raise SystemExit(supervise(args, devices))
+    uvicorn.run(_load_factory(args.app)(), host=args.host, port=args.port, log_level=args.log_level)
 
 
 if __name__ == "__main__":
