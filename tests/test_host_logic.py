@@ -225,3 +225,36 @@ def test_all_special_ids_come_from_the_checkpoint_tokenizer(tmp_path):
     seqs = [([10, 11, ts, 12, 13], (0, 0, 0)), ([12, 13, 14, W.EOT], (0, 0, 0))]
     assert list(audio.find_longest_common_sequence(seqs, t)) == [10, 11, ts, 12, 13, 14]
     assert list(audio.find_longest_common_sequence(seqs, _Tokenizer(None))) == [10, 11, 12, 13, 14]
+
+
+def test_isa_lint_scalar_load_rule():
+    """tools/isa_lint.py rule 2 (round 6): a destination SGPR of a scalar load named before the s_waitcnt that retires it is a build error -
+    the hand-issued `s_load_dword` of csrc/common.hpp uniform_load_issue_* is only safe while hipcc keeps its hands off that register."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wis_isa_lint_t", os.path.join(ROOT, "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok = """
+0000000000001000 <k_ok>:
+	s_load_dword s20, s[4:5], 0x0                              // 000000001000: C0020502
+	v_mov_b32_e32 v1, s7                                       // 000000001008: 7E020207
+	s_waitcnt lgkmcnt(0)                                       // 00000000100C: BF8CC07F
+	v_mov_b32_e32 v2, s20                                      // 000000001010: 7E040214
+	s_endpgm                                                   // 000000001014: BF810000
+"""
+    bad = ok.replace("v_mov_b32_e32 v1, s7 ", "v_mov_b32_e32 v1, s20").replace("<k_ok>", "<k_bad>")
+    joined = """
+0000000000002000 <k_join>:
+	s_load_dword s20, s[4:5], 0x0                              // 000000002000: C0020502
+	s_cbranch_scc1 2                                           // 000000002008: BF850002 <k_join+0x14>
+	s_waitcnt lgkmcnt(0)                                       // 00000000200C: BF8CC07F
+	s_mov_b32 s21, s20                                         // 000000002010: BE950014
+	s_mov_b32 s22, s20                                         // 000000002014: BE960014
+	s_endpgm                                                   // 000000002018: BF810000
+"""
+    assert mod.smem_hazards_text(ok) == []
+    hz = mod.smem_hazards_text(bad)
+    assert len(hz) == 1 and hz[0][0] == "k_bad" and "s20" in hz[0][2]
+    assert mod.smem_hazards_text(joined) == []          # (basic blocks only: what is pending at a join is not known)
+    spill = ok.replace("v_mov_b32_e32 v1, s7 ", "v_writelane_b32 v9, s20, 3")
+    assert len(mod.smem_hazards_text(spill)) == 1       # an SGPR spill of the in-flight register is the advisor's scenario

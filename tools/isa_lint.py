@@ -3,6 +3,7 @@
     python tools/isa_lint.py [--table] build/*.hip.o
 
 Rule: NO kernel that contains MFMA instructions may contain packed-f32 VALU arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32),
+(rule 2, round 6: no instruction names the destination SGPR of a scalar load before the s_waitcnt that retires it - smem_hazards below),
 whatever its occupancy (the failures were seen at three waves per SIMD, <= 168 unified VGPRs; the table prints the register bound
 so a reader can see which kernels could get there), and no kernel may use scratch.  Round 3/4 finding ("The two-tile
 kernel's corruption"): the two-n-tile skinny GEMM's 168-VGPR instantiation returned wrong LOW halves of v_pk_*_f32 results in
@@ -74,6 +75,77 @@ def kernels(co):
     return out
 
 
+SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def _sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def smem_hazards(co):
+    """Round 6 (advisor, round 5): csrc/common.hpp uniform_load_issue_* requests workgroup-uniform operands with `s_load_dword` from inline asm and
+    the caller waits by hand (uniform_load_wait) - the compiler believes the destination SGPR is defined at the asm statement, so nothing but the
+    helper's own discipline keeps a copy / spill / use of that register from being scheduled between the request and the wait.  Rule, checked on
+    the generated code of EVERY scalar load (the compiler's own obey it by construction): between an `s_load_*` and the next `s_waitcnt` that
+    retires it (lgkmcnt(0): scalar loads return out of order) no instruction may name a destination SGPR of the load.  Checked inside basic
+    blocks (the pending set is dropped at branches and at branch targets, where another path joins).  -> [(kernel, load line, offending line)]"""
+    return smem_hazards_text(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout)
+
+
+def smem_hazards_text(dis):
+    """the rule of smem_hazards over an `llvm-objdump -d --no-show-raw-insn` listing"""
+    # per kernel: [(address, instruction text)] and the set of branch-target addresses (basic-block starts)
+    kernels_, cur, base = {}, None, 0
+    for ln in dis.split("\n"):
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", ln)
+        if m:
+            cur, base = m.group(2), int(m.group(1), 16)
+            kernels_[cur] = ([], set())
+            continue
+        if cur is None or "//" not in ln:
+            continue
+        t, _, c = ln.partition("//")
+        t = t.strip()
+        ma = re.match(r"\s*([0-9A-Fa-f]+):", c)
+        if not t or not ma:
+            continue
+        kernels_[cur][0].append((int(ma.group(1), 16), t))
+        if t.startswith("s_cbranch") or t.startswith("s_branch"):
+            mt = re.search(r"<.*\+0x([0-9a-fA-F]+)>\s*$", c)
+            kernels_[cur][1].add(base + int(mt.group(1), 16) if mt else -1)
+    out = []
+    for name, (ins, targets) in kernels_.items():
+        pending = {}
+        for addr, t in ins:
+            if addr in targets:          # another path joins here: what is pending on it is not known (the compiler's own loads are waited per path)
+                pending = {}
+            op = t.split()[0]
+            if op == "s_waitcnt":
+                if "lgkmcnt(0)" in t or re.fullmatch(r"s_waitcnt\s+(0x)?[0-9a-f]+", t):
+                    pending = {}
+                continue
+            if op.startswith("s_cbranch") or op.startswith("s_branch") or op in ("s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+                pending = {}
+                continue
+            used = _sregs(t[len(op):])
+            is_load = op.startswith("s_load") or op.startswith("s_buffer_load")
+            if pending:
+                ops = t[len(op):].split(",")
+                hit = (_sregs(",".join(ops[1:])) if is_load else used) & set(pending)      # (a load may not build its address from a register still in flight)
+                if hit:
+                    out.append((name, pending[min(hit)], t))
+            if is_load:
+                for r in _sregs(t[len(op):].split(",")[0]):
+                    pending[r] = t
+    return out
+
+
 def lint(paths, table=False):
     bad, rows = [], []
     with tempfile.TemporaryDirectory() as tmp:
@@ -81,6 +153,8 @@ def lint(paths, table=False):
             co = code_object(p, tmp)
             if co is None:
                 continue
+            for kn, ld, use in smem_hazards(co):
+                bad.append((os.path.basename(p), f"{kn}: `{use}` names an SGPR of the scalar load `{ld}` before the wait that retires it", 0, 0, 0, -1, 0))
             for name, k in sorted(kernels(co).items()):
                 waves = min(8, 512 // (((k["vgpr"] + 7) // 8) * 8)) if k["vgpr"] else 8
                 rows.append((os.path.basename(p), name, k["vgpr"], waves, k["mfma"], k["pk"], k["scratch"]))
@@ -98,9 +172,12 @@ if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     bad, rows = lint(args, table="--table" in sys.argv)
     for o, n, v, w, mf, pk, sc in bad:
+        if pk < 0:
+            print(f"isa_lint: {o}: {n}", file=sys.stderr)
+            continue
         print(f"isa_lint: {o}: {n}: {mf} MFMAs and {pk} packed-f32 VALU instructions at {v} VGPRs ({w} waves per SIMD possible)", file=sys.stderr)
     scratch = [r for r in rows if r[6]]
     for o, n, v, w, mf, pk, sc in scratch:
         print(f"isa_lint: {o}: {n}: {sc} bytes of scratch per lane", file=sys.stderr)
-    print(f"isa_lint: {len(rows)} kernels, {len(bad)} packed-f32 violations, {len(scratch)} kernels with scratch")
+    print(f"isa_lint: {len(rows)} kernels, {sum(1 for b in bad if b[5] >= 0)} packed-f32 violations, {sum(1 for b in bad if b[5] < 0)} scalar-load hazards, {len(scratch)} kernels with scratch")
     sys.exit(1 if bad or scratch else 0)

@@ -114,6 +114,9 @@ def lint_objects(objs):
     scratch = [r for r in rows if r[6]]
     if bad or scratch:
         for o, n, v, w, mf, pk, sc in bad:
+            if pk < 0:
+                sys.stderr.write(f"[build] isa_lint: {o}: {n}\n")
+                continue
             sys.stderr.write(f"[build] isa_lint: {o}: {n}: {mf} MFMAs + {pk} packed-f32 VALU instructions at {v} VGPRs ({w} waves per SIMD possible)\n")
         for o, n, v, w, mf, pk, sc in scratch:
             sys.stderr.write(f"[build] isa_lint: {o}: {n}: {sc} bytes of scratch per lane (register spill)\n")

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -169,6 +170,7 @@ struct wis_model {
   unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
   unsigned gen = 0;                          // generation of the current search (records of an earlier call's over-run step are ignored)
   int last_B = 0, last_beam = 0;             // shape of the last generate call (wis_last_trajectory)
+  bool overrun_left = false;                 // the last call returned with an over-run decode step still queued (its give-up flag, if any, is not the next call's)
   hipEvent_t ev[8];
   hipStream_t st_enc = nullptr;             // wis_generate's front half (log-mel, encoder) runs here: it overlaps the previous call's over-run decode step on `st`
   hipEvent_t ev_enc = nullptr, ev_ckv = nullptr;      // encoder output ready (st_enc -> st); cross-K/V projection done reading it (st -> the next call's st_enc)
@@ -637,11 +639,27 @@ static inline void cpu_relax() {
 #endif
 }
 static std::atomic<int> g_spin_bh[64];
+// claims whose call has returned while ONE over-run decode step of it may still be running on the handle's stream (a search that ended on
+// EOT does not wait for the step queued behind the one that finished it): the combiners of that step still spin, so its share of the
+// budget is released only when the event recorded behind it has completed - checked by whoever claims next on the device (advisor, round 5:
+// released at return, the budget could be over-subscribed for the length of one step)
+struct DeferredClaim { hipEvent_t ev; int n; };
+static std::mutex g_spin_mu;
+static std::vector<DeferredClaim> g_spin_deferred[64];
+static void spin_collect(int device) {
+  std::lock_guard<std::mutex> lk(g_spin_mu);
+  auto& v = g_spin_deferred[device & 63];
+  for (size_t i = 0; i < v.size();) {
+    if (hipEventQuery(v[i].ev) != hipErrorNotReady) { g_spin_bh[device & 63].fetch_sub(v[i].n, std::memory_order_relaxed); v[i] = v.back(); v.pop_back(); }
+    else ++i;
+  }
+}
 struct SpinClaim {
   wis_model* m; int n = 0;
   SpinClaim(wis_model* mm, int B) : m(mm) {
     static const bool env_share = getenv("WIS_CA_SPIN_SHARED") != nullptr;      // test switch: ignore the budget (exercises the shared-GPU hazard on purpose)
     m->spin_now = false;
+    spin_collect(m->device);
     if (m->spin_off) return;
     if (env_share) { m->spin_now = true; return; }
     const int need = B * m->cfg.n_heads;
@@ -651,6 +669,15 @@ struct SpinClaim {
       if (a.compare_exchange_weak(cur, cur + need, std::memory_order_relaxed)) { n = need; m->spin_now = true; return; }
   }
   ~SpinClaim() { if (n) g_spin_bh[m->device & 63].fetch_sub(n, std::memory_order_relaxed); }
+  // the call returns with work of its own still queued on `st`: hand the claim to the deferred list behind an event on that stream
+  void defer(hipStream_t st) {
+    if (!n) return;
+    if (hipEventRecord(m->ev[6], st) != hipSuccess) return;      // (then the destructor releases as before)
+    std::lock_guard<std::mutex> lk(g_spin_mu);
+    auto& v = g_spin_deferred[m->device & 63];
+    for (auto& d : v) if (d.ev == m->ev[6]) { d.n += n; n = 0; return; }      // (re-recorded: the earlier share now waits for the later record too)
+    v.push_back({m->ev[6], n}); n = 0;
+  }
   SpinClaim(const SpinClaim&) = delete;
   SpinClaim& operator=(const SpinClaim&) = delete;
 };
@@ -995,6 +1022,7 @@ void wis_model_destroy(wis_model_t* m) {
   if (!m) return;
   hipSetDevice(m->device);
   if (m->st) hipStreamSynchronize(m->st);
+  spin_collect(m->device);      // (a deferred spin claim of this handle waits on one of its events: completed by the synchronise above)
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_pin) hipHostFree(m->h_pin);
@@ -1107,6 +1135,9 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     WIS_RET(upload_rows(m, tok, pos, slot, ls, false));
   }
   const unsigned long long gen = m->gen;
+  // a give-up flag raised by the PREVIOUS call's over-run step (it ran after that call had returned) says nothing about this call: cleared
+  // behind that step, in stream order, before this call's first decoder pass can raise it again
+  if (m->overrun_left) { WIS_HIP_CHECK(hipMemsetAsync(m->ca_epoch, 0, 4, st)); m->overrun_left = false; }
   __atomic_store_n(&m->h_prog[HP_REC], 0ull, __ATOMIC_RELAXED);      // (a record of an earlier call's over-run step may still land here: it carries that call's generation)
   m->h_prog[HP_DONE_STEP] = 0; m->h_prog[HP_DONE_STAMP] = 0; m->h_prog[HP_STAMP0] = 0;
 
@@ -1443,6 +1474,7 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   m->timing.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   m->timing.decode_steps = steps;             // steps enqueued (the merged prefill + first step included)
   m->timing.decode_steps_needed = needed;     // steps after which every utterance had finished: steps - needed = over-run
+  if (steps > needed) { claim.defer(st); m->overrun_left = true; }      // an over-run step is still queued: its combiners keep their share of the spin budget until it has run
   return WIS_OK;
 }
 
