@@ -181,6 +181,126 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
   return WIS_OK;
 }
 
+// 8-byte {tag, value} granules: one relaxed agent-scope (write-through) store each, "the data is the flag" (guide G16 form R2) - the hand-off of the
+// decoder cross-attention's chunk partials (dec_cross_attn_kernel SPIN) and of q / k / v from the QKV projection to the self-attention fused into its launch
+typedef unsigned long long gran_t;
+__device__ __forceinline__ void st_gran(gran_t* p, unsigned tag, float v) {
+  __hip_atomic_store(p, ((gran_t)tag << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ gran_t ld_gran(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned CA_SPIN_LIMIT = 1u << 17;      // sweeps before the combiner gives up (~0.1 s)
+
+// ---- self-attention FUSED into the QKV projection's launch (round 6; round-5 review item 4a) -----------------------------------------
+// The one-utterance decode step ran  QKV projection -> [kernel boundary] -> dec_self_attn_kernel  per layer: a 1.6 us dispatch boundary plus a 5 us
+// kernel whose only inputs from the projection are 64 floats of q and one new K / V row per (row, head).  Now the projection's launch carries
+// H extra workgroups behind its n-tiles - one per head, dispatched after every producer tile of the launch - that run dec_self_attn_kernel's
+// arithmetic (same lane mapping, same order: bit-identical results): each wave owns rows w and w + 4, requests the row's K / V HISTORY from the
+// cache at once (it was written by earlier steps: nothing to wait for), then polls the 192 granules the projection's epilogue publishes for its
+// (row, head) - q[64], k[64], v[64] of the CURRENT position, tagged with the head's epoch + 1 - and finishes.  The boundary, the kernel's own
+// start-up and its history round trip are gone from the chain; what is left behind the last projection tile is one L2 round trip and the softmax.
+// Hand-off rules as in dec_cross_attn_kernel's granule form: producers store and leave (no drain, no ticket); the head's consumer advances the
+// epoch word at the end of the launch (tags only grow: graph replays stay valid, nothing is reset); a consumer's spin is bounded and raises the
+// cross-attention's give-up flag word (the host repeats the call with both hand-offs in their kernel-boundary forms); consumers are dispatched
+// behind their producers, so they can never hold a slot a producer of the same launch still needs.
+// Only for decode rows that own their KV slot (rmul = 1: the ordinary step; prefill rows of one slot read each other's rows of the same launch).
+__device__ __forceinline__ void sa_consume(const GemvP& p, const int h, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = lane >> 3, c = lane & 7;
+  const int M = p.M, d = p.d, ctx = p.ctx;
+  float* shq = reinterpret_cast<float*>(smem) + wave * 512;                  // per wave: q f32 [64] | k f16 [64] | v f16 [64] | red f32 [4][64]
+  f16* shk = reinterpret_cast<f16*>(shq + 64); f16* shv = shk + 64; float* red = shq + 128;
+  const unsigned tag = __hip_atomic_load(p.sa_epoch + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int hoff = h * 64 + 8 * c;
+  for (int m = wave; m < M; m += 4) {
+    const int ls = (m / p.sa_rpu) * p.sa_sstride + (m % p.sa_rpu);
+    const int len = p.pos[m] + 1;
+    const f16* krow = p.kc + (size_t)ls * ctx * d + hoff;
+    const f16* vrow = p.vc + (size_t)ls * ctx * d + hoff;
+    u32x4 kr[8], vr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)(8 * i + pl) * d);      // history (position len - 1 is replaced below)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(8 * i + pl) * d);
+    // the current position's q / k / v: lane owns element `lane` of each
+    const gran_t* g = p.sa_gran + ((size_t)(h * 8 + m) * 3) * 64 + lane;
+    gran_t gq, gk, gv;
+    for (unsigned spins = 0;; ++spins) {
+      gq = ld_gran(g); gk = ld_gran(g + 64); gv = ld_gran(g + 128);
+      const bool ok = ((unsigned)(gq >> 32) == tag) & ((unsigned)(gk >> 32) == tag) & ((unsigned)(gv >> 32) == tag);
+      if (__ballot(!ok) == 0ull) break;
+      if (spins > CA_SPIN_LIMIT) { if (lane == 0) atomicOr(p.sa_flag, 1u); break; }      // the give-up flag word of the cross-attention hand-off: one host protocol for both
+      __builtin_amdgcn_s_sleep(1);
+    }
+    shq[lane] = __uint_as_float((unsigned)gq); shk[lane] = (f16)__uint_as_float((unsigned)gk); shv[lane] = (f16)__uint_as_float((unsigned)gv);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = shq[8 * c + j];
+    const u32x4 kcur = *reinterpret_cast<const u32x4*>(shk + 8 * c), vcur = *reinterpret_cast<const u32x4*>(shv + 8 * c);
+    float m_run = -INFINITY, l_run = 0.f;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    int p0 = 0;
+    do {
+      if (p0 > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int pp = p0 + 8 * i + pl, pc = pp < len ? pp : len - 1;
+          kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)pc * d);
+          vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)pc * d);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const bool cur = p0 + 8 * i + pl == len - 1; kr[i] = cur ? kcur : kr[i]; vr[i] = cur ? vcur : vr[i]; }
+      float sc[8]; float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pp = p0 + 8 * i + pl;
+        float dot = 0.f;
+        if (pp < len) {
+          const f16x8 kv = *reinterpret_cast<const f16x8*>(&kr[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dot = fmaf((float)kv[j], qv[j], dot);
+        }
+        dot += dpp_f<0xB1>(dot); dot += dpp_f<0x4E>(dot); dot += dpp_f<0x141>(dot);
+        sc[i] = (pp < len) ? dot : -INFINITY;
+        mx = fmaxf(mx, sc[i]);
+      }
+      mx = wave_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      float lsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pw = __expf(sc[i] - m_new);
+        lsum += pw;
+        if (p0 + 8 * i + pl < len) {
+          const f16x8 vv = *reinterpret_cast<const f16x8*>(&vr[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, (float)vv[j], acc[j]);
+        }
+      }
+      l_run = l_run * alpha + wave_sum(lsum) * 0.125f;
+      m_run = m_new;
+      p0 += 64;
+    } while (p0 < len);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += dpp_f<0x128>(acc[j]);
+    if ((lane & 8) == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[(lane >> 4) * 64 + 8 * c + j] = acc[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float o = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    p.sa_out[(size_t)m * d + h * 64 + lane] = (f16)(o / l_run);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // (the LDS row is reused by this wave's next row)
+  }
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p.sa_epoch + h, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch's epoch
+}
+
 // =======================================================================================
 // Skinny GEMM.  grid = Npad/16 workgroups of 4 waves; wave w streams the k-steps of its quarter of
 // every staged K-chunk.  Dynamic LDS: xs f16 [M][KC+8] | red f32 [4][MB][64][4] | stats f32 [48][2] | sred f32 [4][8]
@@ -205,7 +325,7 @@ int launch_pack_gemv(hipStream_t st, const f16* W, f16* Wp, int N, int Npad, int
 // NT (r5; MB = 1, single chunk, compile-time SC only): n-tiles per workgroup.  2: waves 0-1 own tile 2 nt, waves 2-3 tile 2 nt + 1, half of
 // K each (SC = K / 64 fragments per wave, all requested up front) - half as many workgroups stage the activation rows, each with twice
 // the weight bytes in flight: N = 4d of the one-utterance step is 160 workgroups (one per CU) instead of 320 on 256 CUs.
-template <int MB, int MODE, int SC, int RM, bool W8, int NT = 1>
+template <int MB, int MODE, int SC, int RM, bool W8, int NT = 1, bool SA = false>
 __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const int nt, char* smem) {
   static_assert(NT == 1 || (NT == 2 && MB == 1 && SC > 0), "two-tile workgroups: <= 16 rows, every fragment prefetched");
   typedef typename WFrag<W8>::T WT;
@@ -244,6 +364,9 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   unsigned long long* pf = (nt == 0 && tid == 0) ? p.prof : nullptr;
   if (tid == 0) tl_begin(p.prof);
   stamp(pf, 0);
+  // fused self-attention (sa_consume): this tile's head and the tag its granules carry (requested with everything else)
+  unsigned sa_tag = 0;
+  if (SA) { const int nh = rows * nt, sec = nh / p.d; sa_tag = __hip_atomic_load(p.sa_epoch + ((nh - sec * p.d) >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u; }
   if (x16) {
     const u32x4* x8 = reinterpret_cast<const u32x4*>(p.x);
     const int k8n16 = K >> 3, t8 = tid < k8n16 ? tid : k8n16 - 1;      // (clamped address: threads >= K / 8 load a valid chunk and drop it)
@@ -519,8 +642,13 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
       s.x += ep_bias.x; s.y += ep_bias.y; s.z += ep_bias.z; s.w += ep_bias.w;
       if (p.flags & GV_QKV) {
         const int d = p.d;
+        if (SA) {      // q / k / v of the current position to the head's consumer workgroup of this launch: four granules per lane
+          const int sec = n / d, hn = n - sec * d;
+          gran_t* gp = p.sa_gran + (((size_t)((hn >> 6) * 8 + m) * 3) + sec) * 64 + (hn & 63);
+          st_gran(gp, sa_tag, s.x); st_gran(gp + 1, sa_tag, s.y); st_gran(gp + 2, sa_tag, s.z); st_gran(gp + 3, sa_tag, s.w);
+        }
         if (n < d) {
-          *reinterpret_cast<float4*>(p.q + (size_t)m * d + n) = s;
+          if (!SA) *reinterpret_cast<float4*>(p.q + (size_t)m * d + n) = s;
         } else {
           const bool isk = n < 2 * d;
           f16* dst = (isk ? p.kc : p.vc) + ((size_t)ep_slot * p.ctx + ep_pos) * d + (n - (isk ? d : 2 * d));
@@ -569,11 +697,12 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
 #define WIS_GV_LEAD(q) (q).x, (q).x2, (q).Wp, (q).M, (q).N, (q).K, (q).xsplit
 #define WIS_GV_LEAD_DECL(s) const void* s##x, const void* s##x2, const f16* s##Wp, int s##M, int s##N, int s##K, int s##xsplit
 #define WIS_GV_LEAD_APPLY(q, s) (q).x = s##x; (q).x2 = s##x2; (q).Wp = s##Wp; (q).M = s##M; (q).N = s##N; (q).K = s##K; (q).xsplit = s##xsplit
-template <int MB, int MODE, int SC, int RM, bool W8, int NT = 1>
+template <int MB, int MODE, int SC, int RM, bool W8, int NT = 1, bool SA = false>
 __global__ __launch_bounds__(256) void gemv_kernel(WIS_GV_LEAD_DECL(l_), int KC, GemvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WIS_GV_LEAD_APPLY(p, l_);
-  gemv_body<MB, MODE, SC, RM, W8, NT>(p, KC, blockIdx.x, smem);
+  if (SA && (int)blockIdx.x >= p.sa_first) { sa_consume(p, (int)blockIdx.x - p.sa_first, smem); return; }      // the heads' self-attention workgroups, behind the n-tiles
+  gemv_body<MB, MODE, SC, RM, W8, NT, SA>(p, KC, blockIdx.x, smem);
 }
 // Two skinny GEMMs in ONE launch (workgroups [0, nA) run problem A, the rest problem B; both f16-activation, single-chunk,
 // <= 16 rows): the decoder's attention output projection together with the cross-attention query projection folded THROUGH it
@@ -686,6 +815,19 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
   if (MB == 1 && mode == 1 && sc == 10 && p.M > 3 && p.M <= 5 && !p.wscale && rows == 16 && p.N % 32 == 0 && !(p.flags & GV_RESID) &&
       (((nt2_mask & 1) && !(p.flags & GV_QKV) && p.N >= 4096) || ((nt2_mask & 2) && (p.flags & GV_QKV)))) {
     hipLaunchKernelGGL((gemv_kernel<1, 1, 20, 5, false, 2>), dim3(p.N / 32), block, lds, st, WIS_GV_LEAD(pp), KC, pp);
+    return WIS_OK;
+  }
+  if (p.sa_gran) {      // QKV projection + the heads' self-attention workgroups in one launch (sa_consume)
+    if (!(MB == 1 && mode == 1 && sc > 0 && !p.wscale && (p.flags & GV_QKV) && p.M <= 8 && p.d % 64 == 0 && p.N == 3 * p.d && p.sa_epoch && p.sa_flag && p.sa_out)) {
+      set_error("gemv: the fused self-attention needs the LayerNorm-folded f16 QKV projection of <= 8 rows (M=%d N=%d K=%d)", p.M, p.N, p.K); return WIS_E_UNSUPPORTED; }
+    pp.sa_first = (int)grid.x;
+    const dim3 gsa(grid.x + p.d / 64);
+    const size_t lds_sa = lds > 4 * 512 * 4 ? lds : 4 * 512 * 4;      // the consumer workgroups' exchange rows: 2 KiB per wave
+#define WIS_GV_SA(SCv, RMv) hipLaunchKernelGGL((gemv_kernel<1, 1, SCv, RMv, false, 1, true>), gsa, block, lds_sa, st, WIS_GV_LEAD(pp), KC, pp)
+#define WIS_GV_SA_RM(SCv) do { if (p.M <= 3) WIS_GV_SA(SCv, 3); else if (p.M <= 5) WIS_GV_SA(SCv, 5); else WIS_GV_SA(SCv, 8); } while (0)
+    switch (sc) { case 3: WIS_GV_SA_RM(3); break; case 4: WIS_GV_SA_RM(4); break; case 6: WIS_GV_SA_RM(6); break; case 8: WIS_GV_SA_RM(8); break; default: WIS_GV_SA_RM(10); }
+#undef WIS_GV_SA_RM
+#undef WIS_GV_SA
     return WIS_OK;
   }
   if (MB == 1) {
@@ -1425,12 +1567,6 @@ constexpr int CA_PSTR = 264;   // f16 row pitch of the P image (256 keys + 8: 16
 // replays stay valid.  Progress: producers never wait; at most B * H <= 192 workgroups spin, fewer than the chip's 256 CUs, so a
 // producer always finds a slot.  The spin is bounded: on exhaustion the combiner raises a flag (checked by wis_generate) instead of
 // hanging.  What it removes from the hand-off: the store drain, the returning ticket atomic and the agent-scope acquire (1.7 us).
-typedef unsigned long long gran_t;
-__device__ __forceinline__ void st_gran(gran_t* p, unsigned tag, float v) {
-  __hip_atomic_store(p, ((gran_t)tag << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ gran_t ld_gran(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-constexpr unsigned CA_SPIN_LIMIT = 1u << 17;      // sweeps before the combiner gives up (~0.1 s)
 
 // FOLD: 0 = q is the finished query; 1 = folded query, statistics reduced from the rows themselves (xres = x1 fp32 [B*R][d]: the one-utterance
 // step); 2 = folded query of the BATCHED step: q_raw arrives as two halves (q + q2: W'q x0 + W'q bo and (W'q Wo) a, model.hip

@@ -82,6 +82,10 @@ struct GemvP {
   // the weight matrix as a k-step window of a wider packed image (launch_gemv_frag / launch_gemv_frag3): wks = k-steps per n-tile of
   // the image (0: K / 32, the matrix is the whole image), wk0 = first k-step of the window
   int wks, wk0;
+  // self-attention fused into the QKV projection's launch (launch_gemv, GV_QKV at <= 8 decode rows; dec_kernels.hip sa_consume): sa_gran = 8-byte
+  // {tag, value} slots [heads][8 rows][q | k | v][64], sa_epoch = one monotonic epoch word per head, sa_flag = the give-up flag word (the cross-
+  // attention hand-off's), sa_out = attention output f16 [M][d]; slot of row m = (m / sa_rpu) * sa_sstride + m % sa_rpu; sa_first is set by the launcher
+  unsigned long long* sa_gran; unsigned* sa_epoch; unsigned* sa_flag; f16* sa_out; int sa_rpu, sa_sstride, sa_first;
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
 int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // two f16-activation skinny GEMMs in one launch

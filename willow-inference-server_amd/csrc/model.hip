@@ -155,6 +155,7 @@ struct wis_model {
   float* dq2 = nullptr;         // batched fold: second half of the cross-attention q_raw (dec_forward_frag)
   float* gf_part = nullptr; unsigned* gf_cnt = nullptr; int gf_ksplit = 1;      // K split of the batched FFN2 skinny GEMM: slice sums, tickets (GemvP::ksplit)
   unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
+  unsigned long long* sa_gran = nullptr; unsigned* sa_epoch = nullptr;      // ... of q / k / v from the QKV projection to the self-attention fused into its launch: slots [H][8][3][64], epochs [H]
   bool spin_off = false;        // sticky: a combiner's bounded spin ran out once on this handle - it keeps to the ticket hand-off from then on
   int handoff_retries = 0;      // calls repeated because a combiner's spin ran out (wis_debug_handoff: expected to stay 0)
   bool spin_now = true;         // this call's decision (SpinClaim): dec_forward passes the granule buffers only when set
@@ -499,6 +500,10 @@ int alloc_buffers(wis_model* m) {
     WIS_RET(dalloc(m, &m->ca_epoch, (size_t)bh + 1));
     WIS_HIP_CHECK(hipMemsetAsync(m->ca_gran, 0, (size_t)bh * 6 * 8 * 66 * 8, m->st));
     WIS_HIP_CHECK(hipMemsetAsync(m->ca_epoch, 0, ((size_t)bh + 1) * 4, m->st));
+    WIS_RET(dalloc(m, &m->sa_gran, (size_t)H * 8 * 3 * 64));
+    WIS_RET(dalloc(m, &m->sa_epoch, (size_t)H));
+    WIS_HIP_CHECK(hipMemsetAsync(m->sa_gran, 0, (size_t)H * 8 * 3 * 64 * 8, m->st));
+    WIS_HIP_CHECK(hipMemsetAsync(m->sa_epoch, 0, (size_t)H * 4, m->st));
   }
   WIS_RET(dalloc(m, &m->rm.tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.pos, MAX_ROWS));
   WIS_RET(dalloc(m, &m->rm.slot, MAX_ROWS)); WIS_RET(dalloc(m, &m->rm.lslot, MAX_ROWS));
@@ -769,6 +774,14 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
   return WIS_OK;
 }
 
+// WIS_SA_FUSE=1: the step's self-attention rides in the QKV projection's launch (dec_kernels.hip sa_consume).  OFF by default - built, correct (the GPU
+// suite is green with it) and measured SLOWER, same call on MI355X: decode step 1.280 against 1.250 ms, utterance 27.38 against 26.97 ms
+// (profiles/r06_sa_fuse_ab.txt).  The eager trace shows why: the fused launch averages 9.0 us where the two launches take 6.2 + 5.0, but its FLOOR
+// is 7.9 us against 3.3 + 2.3: behind the last projection tile the consumer still needs granule store -> L2 -> poll (~2 us) and the whole softmax,
+// which costs what the 1.6 us boundary + the stand-alone kernel's start cost once the graph replays them back to back - the same lesson as the
+// persistent skeleton and the flag-gated early start: an in-launch hand-off is two fabric round trips, like a kernel boundary.
+// Read per call so that a test can compare both forms in one process.
+static bool sa_fuse_enabled() { const char* e = getenv("WIS_SA_FUSE"); return e && atoi(e) != 0; }
 int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, const TreeWin* tw = nullptr) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx;
@@ -789,6 +802,9 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
   //             the one epilogue wave BEHIND the reduction barrier - measured slower than `rows` (1.357 against 1.345 ms per step)
   static const int ln_form = [] { const char* e = getenv("WIS_B1_LN"); return !e ? 0 : (!strcmp(e, "f16") ? 2 : (!strcmp(e, "partials") ? 1 : 0)); }();
   const bool ln_ok = fold && d % 64 == 0 && M * (d / 8) <= 13 * 256;
+  // (r6) the self-attention inside the QKV projection's launch (dec_kernels.hip sa_consume): decode rows that own their KV slot, f16 weights, the
+  // granule hand-off allowed for this call (it shares the cross-attention's budget and give-up protocol); WIS_SA_FUSE=0: two launches (A/B)
+  const bool sa_fuse = m->spin_now && sa_fuse_enabled() && rmul == 1 && M <= 8 && !m->w8 && d % 64 == 0 && ctx >= 64 && !m->prof_on;
   const bool lnp = ln_ok && ln_form == 1 && d <= 1280, ln16 = ln_ok && ln_form == 2 && d <= 2048;
   WIS_RET(launch_dec_embed(st, m->emb, m->dec_pos, m->rm.tok, m->rm.pos, m->dx, M, d, fold ? m->dxh : nullptr, lnp ? m->dstat : nullptr));
   for (int l = 0; l < c.n_dec_layers; ++l) {
@@ -803,8 +819,9 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     if (lnp) { g.x = m->dxh; g.stat_in = m->dstat; g.flags = GV_LNP | GV_QKV; }
     if (ln16) { g.x = m->dxh; g.flags = GV_LN16 | GV_QKV; }
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
+    if (sa_fuse && !lnp && !ln16) { g.sa_gran = m->sa_gran; g.sa_epoch = m->sa_epoch; g.sa_flag = m->ca_epoch; g.sa_out = m->dao; g.sa_rpu = R; g.sa_sstride = sstride; }
     WIS_RET(launch_ln_gemv(m, st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
+    if (!g.sa_gran) WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
     if (fold) {
       // ONE launch: x1 = x0 + Wo a + bo (tiles [0, d/16)) and q_raw = W'q x0 + (W'q Wo) a + W'q bo (the other d/16 tiles); the
       // cross-attention kernel applies the LayerNorm statistics of x1 (rs, mu) and b' to q_raw
@@ -1329,7 +1346,7 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
   if (m->use_graph) {
     GraphKey key; memset(&key, 0, sizeof(key));
     key.B = B; key.beam = beam; key.P = P; key.max_new = max_new; key.fixed_new = sc.fixed_new; key.suppress_blank = sc.suppress_blank;
-    key.suppress_default = o->suppress_default; key.early_exit = sc.allow_early_exit; key.lp = sc.length_penalty; key.patience = patience; key.spin = m->spin_now;
+    key.suppress_default = o->suppress_default; key.early_exit = sc.allow_early_exit; key.lp = sc.length_penalty; key.patience = patience; key.spin = (m->spin_now ? 1 : 0) | (sa_fuse_enabled() ? 2 : 0);
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) gexec = it->second;
     else {
