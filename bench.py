@@ -94,7 +94,9 @@ def cpu_baseline(size, weights, pcm, beam, fixed_new, audio_ms):
     t3 = time.perf_counter()
     enc_s, dec_s = t2e - t0, t3 - t2
     total = enc_s + dec_s
-    return {"value": round(audio_ms / 1000.0 / total, 4), "unit": "x realtime", "cores": max(enc_t, best_t), "kind": "port",
+    # (round-5 review item 7: `kind` says which log-mel the host timed - "port" alone only where the reference's own wis/audio.py ran)
+    kind = "port" if mel_src.startswith("the reference") else "port (log-mel: numpy oracle)"
+    return {"value": round(audio_ms / 1000.0 / total, 4), "unit": "x realtime", "cores": max(enc_t, best_t), "kind": kind,
             "logmel_timed": mel_src,          # which log-mel ran on the host: the reference's own module only where /root/reference exists (not on the GPU box)
             "sample": (f"torch-fp32 oracle (KV-cached), the whole utterance measured: log-mel {1e3 * (t1 - t0):.0f} ms [{mel_src}] + encoder {1e3 * (t2e - t1):.0f} ms on {enc_t} host "
                        f"threads (best of 16/32/64/{cores} on a probe GEMM) + cross-KV, prefill and all {fixed_new + 1} beam-{beam} steps {1e3 * dec_s:.0f} ms on {best_t} threads "
@@ -635,7 +637,7 @@ def main():
         per_launch_us = 1e3 * ms.value / (passes * nl.value)
         achieved = nb.value / nl.value / (per_launch_us * 1e-6) / 1e9
         traffic = None
-        for name in ("r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
+        for name in ("r06_pmc_decode.json", "r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_gemv.json", "r01_pmc_gemv.json"):       # filled from the separate --pmc rocprofv3 passes (tools/gpu_session.sh pmc, tools/make_profiles.py)
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -701,7 +703,7 @@ def main():
                                           "frac_of_hbm_peak": round(sb / (tm["decode_ms"] / sd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                     if Bc == 8:
                         try:      # HBM traffic of the step's two byte-heavy kernels from the --pmc passes (profiles/r03_pmc_decode.json)
-                            b8 = json.load(open(next(pp for pp in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json")) if os.path.exists(pp))))["batch_8"]
+                            b8 = json.load(open(next(pp for pp in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_decode.json", "r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json")) if os.path.exists(pp))))["batch_8"]
                             row["decode_step"]["traffic_over_algorithmic"] = {"skinny_gemm (gemv_frag_kernel)": b8["skinny_gemm_traffic_over_algorithmic"],
                                                                               "cross_attention": b8["per_kernel"]["dec_cross_attn_kernel 245760"]["traffic_over_algorithmic"]}
                         except Exception:

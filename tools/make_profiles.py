@@ -18,9 +18,16 @@ G = os.path.join(ROOT, "gpurun_out")
 RND = "r03"      # file prefix under profiles/ (--round)
 P = os.path.join(ROOT, "profiles")
 D = 1280
-ALG_B1 = {"gemv_kernel<1, 2, 0, 1, false> 20480": 8 * D * D, "gemv_kernel<1, 1, 10, 5, false> 81920": 8 * D * D, "gemv_kernel<1, 1, 10, 5, false> 61440": 6 * D * D,
-          "gemv_kernel<1, 2, 10, 1, false> 20480": 2 * D * D, "gemv_dual_kernel<10, 20> 40960": 6 * D * D, "gemv_kernel<1, 1, 10, 5, false> 829952": 2 * 51872 * D,
-          "dec_cross_attn_kernel 30720": 2 * 2 * 1500 * D}
+# (round 6, round-5 review item 7: the one-utterance kernels are matched by the LEADING template arguments - MB, MODE, SC = k-steps per wave - and the grid,
+# so that a template parameter added behind them does not drop a kernel from the table: round 5's names carried six arguments, the keys four, and
+# `roofline.traffic` came from gemv_dual_kernel alone)
+ALG_B1 = {r"gemv_kernel<1, 2, 40, .* 20480": 8 * D * D,            # FFN2: all 40 fragments of a wave up front
+          r"gemv_kernel<1, 1, 20, .* 40960": 8 * D * D,            # FFN1 on two-tile workgroups
+          r"gemv_kernel<1, 1, 10, .* 61440": 6 * D * D,            # QKV
+          r"gemv_kernel<1, 2, 10, .* 20480": 2 * D * D,            # cross-attention output projection
+          r"gemv_dual_kernel<10, 20> 40960": 6 * D * D,            # out-projection + the folded cross-Q
+          r"gemv_kernel<1, 1, 20, .* 414976": 2 * 51872 * D,       # vocabulary projection (two-tile workgroups)
+          r"dec_cross_attn_kernel 30720": 2 * 2 * 1500 * D}
 ALG_B8 = {"gemv_frag_kernel<3, 8, false> 40960": 8 * D * D,      # FFN2: two K slices per n-tile (grid.y = 2)
           "gemv_frag_kernel<3, 10, false> 81920": 8 * D * D, "gemv_frag_kernel<3, 10, false> 61440": 6 * D * D,
           "gemv_frag_kernel<3, 10, false> 20480": 2 * D * D, "gemv_frag_kernel<3, 10, false> 829952": 2 * 51872 * D, "dec_cross_attn_kernel 245760": 8 * 2 * 2 * 1500 * D,
@@ -129,6 +136,8 @@ def pmc_decode(tag):
             if key not in ALG and not short(name).startswith("gemv"):      # (the attention kernels are listed without their template arguments)
                 key = f"{short(name).split('<')[0]} {grid}"
             alg = ALG.get(key)
+            if alg is None:
+                alg = next((v for pat, v in ALG.items() if re.fullmatch(pat, key)), None)
             if alg is None or "FETCH_SIZE" not in cs:
                 continue
             n, fetch = cs["FETCH_SIZE"]
