@@ -191,6 +191,44 @@ def test_streaming_speculation_beam1_final_equals_offline(golden_dir, size):
     models.get(size).close()
 
 
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_streaming_speculation_beam_search_final_equals_offline(golden_dir, size):
+    """The same at the reference's OWN settings (request beam 5, long_beam_size 3 from 12 s on, main.py:582-586) with beam-search speculation switched
+    on (settings.stream_speculate_beam_search): the session searches what it has heard every 2 s at the beam the final call would use at that length,
+    every interim search drafted by the previous one's trajectory, and stop() replays the last trajectory against the final window
+    (wis_generate_draft_beam).  Whatever part of the draft the final search follows, the answer must be the offline do_whisper answer."""
+    from wis_hip import audio
+    from wis_hip.settings import APISettings
+    from wis_hip.streaming import StreamingSession
+    from wis_hip.whisper import WhisperModels, do_whisper
+    s = APISettings()
+    s.whisper_model_path = "synthetic:{size}"
+    s.stream_speculate_s, s.stream_speculate_beam_search = 2.0, True
+    assert s.long_beam_size == 3 and s.long_beam_size_threshold == 12000          # the reference's defaults (settings.py:14-18)
+    models = WhisperModels(s, device_index=[0])
+    for clip, S in (("30sec", 48), ("10sec", 24)):
+        pcm, _ = audio.load_audio(os.path.join(golden_dir, "clips", clip + ".flac"))
+        off = do_whisper(pcm, size, 5, models=models, fixed_new_tokens=S)
+        sess = StreamingSession(size, 5, models=models, fixed_new_tokens=S)
+        beams = []
+        for i in range(0, pcm.shape[0], 8000):
+            sess.feed((pcm[i:i + 8000] * 32768.0).astype("<i2").tobytes(), 2)
+            if sess._spec_job is not None:
+                sess._spec_job.result()
+                beams.append(sess._spec_latest[1])
+        runs = sess.spec_runs
+        t0 = time.perf_counter()
+        fin = sess.stop()
+        dt = 1e3 * (time.perf_counter() - t0)
+        final_beam = 3 if pcm.shape[0] >= 12 * 16000 else 5
+        print(f"{size} {clip}: {runs} interim searches (beams {sorted(set(beams))}) while the audio arrived; stop() -> result {dt:.1f} ms at beam {final_beam} (offline call {off[2]:.1f} ms), "
+              f"the final search followed the last trajectory for {sess.accepted_draft_tokens} steps; identical to offline: {fin.tokens == off.tokens}")
+        assert runs >= pcm.shape[0] // (2 * 16000) - 1 and beams[0] == 5 and beams[-1] == final_beam
+        assert sess.accepted_draft_tokens is not None          # a draft of the right beam size was handed over
+        assert fin.tokens == off.tokens and fin[1] == off[1]
+    models.get(size).close()
+
+
 def test_logmel_is_reentrant_across_threads(golden_dir):
     """SURVEY 8(b) conventions / round-1 review: wis_logmel called from 32 threads at once with DIFFERENT audio (the three
     reference clips, batches of 1 and 2 windows interleaved so workspaces of different sizes are recycled) - every caller must
