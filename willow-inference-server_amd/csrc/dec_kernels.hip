@@ -871,6 +871,11 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
   const int M = p.M, K = p.K, ksteps = K >> 5, S = ksteps / (4 * KS);
   // (wks / wk0: the matrix is a k-step window of a wider packed image - the two halves of the folded cross-Q matrix [W'q | W'q Wo])
   const int wks = p.wks ? p.wks : ksteps;
+  // phase stamps of ONE wave (tap builds only; stamp() is empty otherwise): workgroup 0 / slice 0 / thread 0 -
+  // 0 start, 1 first PF k-steps requested, 2 stream consumed (MFMA loop), 3 epilogue operands requested + partial sums in LDS + barrier,
+  // 4 K-split merge passed (ticket), 5 epilogue done
+  unsigned long long* pf = (nt == 0 && ksi == 0 && tid == 0) ? p.prof : nullptr;
+  stamp(pf, 0);
   const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * wks + p.wk0 + (size_t)(ksi * 4 + wave) * S) * 64 + lane;
   const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)(ksi * 4 + wave) * S * MB * 64 + lane;
   WT a[PF]; u32x4 b[PF][MB];
@@ -882,6 +887,7 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
       for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(u * MB + mb) * 64];
     }
   }
+  stamp(pf, 1);
   f32x4 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -901,6 +907,7 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
       }
     }
   }
+  stamp(pf, 2);
   // epilogue operands: requested behind the whole stream, covered by the reduction barrier
   const int l15 = lane & 15, kq = lane >> 4;
   const int ep_n = 16 * nt + 4 * kq;
@@ -953,6 +960,7 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
   for (int mb = 0; mb < MB; ++mb)
     *reinterpret_cast<float4*>(red + ((size_t)(wave * MB + mb) * 64 + lane) * 4) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
+  stamp(pf, 3);
   if (KS > 1) {
     // publish this slice's sums (write-through, agent scope: the other slices of the n-tile run on other XCDs), take a ticket; the
     // last arriver re-arms the ticket, drops its stale L1 lines and goes on to add the slices in index order (the order never
@@ -983,11 +991,12 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
       s_last = last;
     }
     __syncthreads();
+    stamp(pf, 4);
     if (!s_last) return;
   }
 #pragma unroll
   for (int e = 0; e < EPN; ++e) {
-    if (!ep_act[e]) continue;                                   // whole waves: a row block belongs to one wave
+    if (!ep_act[e]) { if (e == EPN - 1) stamp(pf, 5); continue; }                                   // whole waves: a row block belongs to one wave
     const int ep_mb = wave + 4 * e;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KS > 1) {
@@ -1056,6 +1065,7 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
       *reinterpret_cast<f16x4*>(yo + (p.ymb ? xf_index(m, n, p.ymb) : (size_t)m * p.N + n)) = h;
     }
   }
+  stamp(pf, 6);
 }
 
 template <int MB, int PF, bool W8>
@@ -1093,6 +1103,8 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), G
   const WT* wq0 = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt0 * ksteps + (size_t)wave * S) * 64 + lane;
   const WT* wq1 = wq0 + (size_t)ksteps * 64;
   const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)wave * S * MB * 64 + lane;
+  unsigned long long* pf = (blockIdx.x == 0 && tid == 0) ? p.prof : nullptr;      // (phase stamps as in gemv_frag_body; tap builds only)
+  stamp(pf, 0);
   WT a0[PF], a1[PF]; u32x4 b[PF][MB];
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
@@ -1103,6 +1115,7 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), G
       for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(u * MB + mb) * 64];
     }
   }
+  stamp(pf, 1);
   f32x4 acc[MB][2];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) { acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1127,6 +1140,7 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), G
       }
     }
   }
+  stamp(pf, 2);
   // epilogue operands (requested behind the whole stream, covered by the reduction barrier): per n-tile the bias / column sums /
   // row scales, per owned row block the LayerNorm statistics (one pass about the first tile's mean, as in gemv_frag_kernel)
   const int l15 = lane & 15, kq = lane >> 4;
@@ -1165,6 +1179,8 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), G
     for (int nb = 0; nb < 2; ++nb)
       *reinterpret_cast<float4*>(red + ((size_t)((wave * MB + mb) * 2 + nb) * 64 + lane) * 4) = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
   __syncthreads();
+  stamp(pf, 3);
+  stamp(pf, 4);
 #pragma unroll
   for (int e = 0; e < EPN; ++e) {
     if (!ep_act[e]) continue;                                   // whole waves: a row block belongs to one wave
@@ -1210,6 +1226,8 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), G
       }
     }
   }
+  stamp(pf, 5);
+  stamp(pf, 6);
 }
 
 int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n) {

@@ -724,8 +724,12 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
   };
   for (int l = 0; l < c.n_dec_layers; ++l) {
     const DecLayerW& w = m->dec[l];
+    // (tap builds: stamp rows of layer 0's kernels, same row numbering as dec_forward: 0 QKV, 1 self-attn, 2 out-proj (+ q halves), 4 cross-attn,
+    // 5 cross-out, 6 FFN1, 7 FFN2)
+    unsigned long long* pr = (m->prof_on && l == 0) ? m->d_prof : nullptr;
     GemvP g = base(m->dxf, w.p_qkv, w.s_qkv, w.b_qkv, 3 * d, d, GV_LN | GV_QKV);
     g.csum = w.c_qkv; g.stat_in = m->dstat; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
+    g.prof = pr;
     WIS_RET(launch_gemv_frag(st, g));
     WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB, tw ? tw->anc : nullptr, tw ? tw->w0 : 0, tw ? tw->aw : 0));
     if (fold) {
@@ -737,7 +741,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
       // its own (6.4 us per layer at 8 utterances) is gone.
       GemvP g3[3];
       g3[0] = base(m->daoxf, w.p_out, nullptr, w.b_out, d, d, GV_RESID);
-      g3[0].y = m->dx; g3[0].ymb = MB; g3[0].stat_out = m->dstat;
+      g3[0].y = m->dx; g3[0].ymb = MB; g3[0].stat_out = m->dstat; g3[0].prof = pr ? pr + 32 : nullptr;
       g3[1] = base(m->dxf, w.p_cqo, nullptr, w.b_cqo, d, d, GV_OUT_F32);
       g3[1].y = m->dq; g3[1].wks = 2 * d / 32; g3[1].wk0 = 0;
       g3[2] = base(m->daoxf, w.p_cqo, nullptr, nullptr, d, d, GV_OUT_F32);
@@ -756,13 +760,13 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
                                   (m->spin_now && !tw) ? m->ca_gran : nullptr, m->ca_epoch, nullptr, 0, tw ? 1 : 0));
     }
     g = base(m->daoxf, w.p_cout, w.s_cout, w.b_cout, d, d, GV_RESID);
-    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
+    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat; g.prof = pr ? pr + 80 : nullptr;
     WIS_RET(launch_gemv_frag(st, g));
     g = base(m->dxf, w.p_f1, w.s_f1, w.b_f1, 4 * d, d, GV_LN | GV_GELU);
-    g.csum = w.c_f1; g.stat_in = m->dstat; g.y = m->dhxf; g.ymb = MB;
+    g.csum = w.c_f1; g.stat_in = m->dstat; g.y = m->dhxf; g.ymb = MB; g.prof = pr ? pr + 96 : nullptr;
     WIS_RET(launch_gemv_frag(st, g));
     g = base(m->dhxf, w.p_f2, w.s_f2, w.b_f2, d, 4 * d, GV_RESID);
-    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat;
+    g.y = m->dx; g.y_xf = m->dxf; g.ymb = MB; g.stat_out = m->dstat; g.prof = pr ? pr + 112 : nullptr;
     if (m->gf_ksplit > 1 && (4 * d / 32) % (4 * m->gf_ksplit) == 0) { g.ksplit = m->gf_ksplit; g.kpart = m->gf_part; g.kcnt = m->gf_cnt; }      // K = 4d over `ksplit` workgroups per n-tile
     WIS_RET(launch_gemv_frag(st, g));
   }
@@ -1790,7 +1794,10 @@ int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* o
   m->prof_on = false;
   WIS_RET(rc);
   // API order: QKV gemv, out-proj gemv, cross-attn, self-attn, FFN1 gemv, FFN2 gemv  <-  rows 0, 2, 4, 1, 6, 7
-  static const int rows[6] = {0, 2, 4, 1, 6, 7};
+  // (more than 8 rows - the batched-row kernels, round 6: the fourth slot carries the cross-attention output projection (row 5); the attention
+  // kernels' stamps are the one-utterance forms' and stay empty there)
+  static const int rows_small[6] = {0, 2, 4, 1, 6, 7}, rows_frag[6] = {0, 2, 4, 5, 6, 7};
+  const int* rows = Mrows > 8 ? rows_frag : rows_small;
   for (int i = 0; i < 6; ++i)
     WIS_HIP_CHECK(hipMemcpyAsync(out + i * 16, m->d_prof + rows[i] * 16, 16 * 8, hipMemcpyDeviceToHost, m->st));
   bool gave_up = false;
