@@ -742,6 +742,10 @@ def main():
             extra["rest_load"] = rest_load(handle, a, dev, args.rest_clients, 2, fixed_new, open(clip_path, "rb").read(), audio_ms)
             extra["rest_load_3_replicas"] = rest_load(handle, a, dev, args.rest_clients, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:2])
             extra["rest_load_4_replicas_128_clients"] = rest_load(handle, a, dev, 128, 3, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:3])
+            # BASELINE configs[3] as ONE GPU of the node sees it: 64 concurrent clients over 8 GPUs = 8 closed-loop clients per GPU (one server process per GPU,
+            # `python -m wis_hip.server --workers-per-node 8`); with one replica the eight requests form one device batch, with four they spread over concurrent smaller ones
+            extra["rest_load_8_clients_per_gpu"] = {f"{1 + k}_replica(s)": {kk: vv for kk, vv in rest_load(handle, a, dev, 8, 12, fixed_new, open(clip_path, "rb").read(), audio_ms, extra_handles=clones[:k]).items()
+                                                                           if kk in ("utterances_per_s", "p50_request_ms", "mean_device_batch")} for k in (0, 1, 3)}
             # what streaming speculation costs the REST traffic (round-5 review, weak 5): the 3-replica load again with 8 sessions asking for interim
             # decodes flat out beside it - with the load gate (settings.stream_speculate_max_busy: speculation only while the GPU has a replica to spare) and without
             p30, _ams30, _p30 = clip_pcm("30sec")

@@ -179,7 +179,7 @@ class StreamingSession:
         dev = self._replica.device if self._replica is not None else None
         queued, running = self._whisper.load(dev)
         spare = self._whisper.replicas_on(dev) if dev is not None else len(self._whisper._replicas)
-        if queued > 0 or running > self._spec_busy * spare:      # optional work never queues behind (or in front of) real requests
+        if self._spec_busy < 1e6 and (queued > 0 or running > self._spec_busy * spare):      # optional work never queues behind (or in front of) real requests (>= 1e6: gate off, A/B)
             self.spec_skipped += 1
             self._spec_n = self._n
             return
