@@ -224,3 +224,33 @@ def test_beam_draft_argument_checks(rig, mels):
     a = model.generate(one, [_prompt(0)], beam_size=5, draft_trajectory=(tok, org))[0]
     b = model.generate(one, [_prompt(0)], beam_size=5)[0]
     assert a.sequences_ids == b.sequences_ids and not hasattr(a, "accepted_draft_tokens")
+
+
+def test_beam_draft_on_a_one_utterance_handle_and_with_8bit_weights(mels):
+    """Handles as the server creates them for a lone session (max_batch 1: the row-group buffers of the cross-attention must still hold the 3-6 groups of a
+    window) and the reference's GPU compute type (`int8_float16`, main.py:242: the batched-row kernels' 8-bit weight path inside the tree pass)."""
+    from eot_ramp import with_eot_ramp
+    from wis_hip import ctranslate2 as ct2, weights as W
+    w = with_eot_ramp(W.synthetic_weights("tiny", seed=1234, std=0.02, emb_std=0.06, ln_jitter=0.1), 6, 0.1)
+    for kw in (dict(max_batch=1, max_beam=5), dict(max_batch=1, max_beam=5, compute_type="int8_float16")):
+        model = ct2.Whisper("unused", weights=w, arch=W.arch("tiny"), **kw)
+        for beam in (3, 5):
+            ids, score, traj, _ = _gen(model, mels[0], _prompt(1), beam)
+            for name, d in (("own trajectory", traj), ("first 9 steps", (traj[0][:9].copy(), traj[1][:9].copy()))):
+                got, gscore, gtraj, acc = _gen(model, mels[0], _prompt(1), beam, draft_trajectory=d)
+                print(f"  tiny {kw.get('compute_type', 'float16')} max_batch 1 beam {beam} draft '{name}': accepted {acc} of {len(d[0])}, identical {got == ids}, score {gscore:.5f} vs {score:.5f}")
+                assert got == ids and abs(gscore - score) <= 2e-3 and acc >= min(len(d[0]), 5)
+        if kw.get("compute_type"):      # the 8-bit tree pass node by node against the oracle on the de-quantised weights
+            import torch
+            from oracle.whisper_ref import WhisperRef
+            a = W.arch("tiny")
+            ref8 = WhisperRef(W.quantize_decoder_weights(w), a["d_model"], a["n_layers"], a["n_heads"])
+            mem = ref8.encode(mels[0][None])
+            rng = np.random.default_rng(3)
+            tok, org = rng.integers(0, 50000, (12, 5)).astype(np.int32), rng.integers(0, 5, (12, 5)).astype(np.int32)
+            got_l = tree_logits(model, mels[0], _prompt(1), tok, org)
+            ch = tree_chains(_prompt(1), tok, org)
+            worst = max(float(np.abs(got_l[s_] - ref8.decode_logits(np.array(ch[s_]), mem.expand(5, -1, -1))[:, -1].numpy()).max()) for s_ in range(12))
+            print(f"  tiny int8_float16 tree pass, 60 rows: logits max abs err vs the oracle on de-quantised weights {worst:.3e}")
+            assert worst <= 5e-2
+        model.close()
