@@ -204,7 +204,7 @@ int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, in
 /* the decoder pass wis_generate_draft_beam verifies a window with, alone: the tree rows of steps 1 .. n_steps of a beam trajectory (tok / org
  * [n_steps][beam]: per step the live beams' newest tokens and the beam each continued from) behind `prompt`, in ONE pass (tree self-attention by
  * ancestor table, cross-attention as row groups over the utterance's one K / V); logits [n_steps][beam][n_vocab]: row (s, j) = what a step fed
- * tok[s][j] after its chain of ancestors sees - comparable with wis_debug_logits on that chain.  n_steps <= min(16, 96 / beam). */
+ * tok[s][j] after its chain of ancestors sees - comparable with wis_debug_logits on that chain.  n_steps <= min(32, 96 / beam). */
 int wis_debug_tree_logits(wis_model_t* m, const float* input, int input_kind, const int32_t* prompt, int P, int beam,
                           const int32_t* tok, const int32_t* org, int n_steps, float* logits);
 

@@ -75,7 +75,7 @@ def tree_chains(prompt, tok, org):
     return chains
 
 
-@pytest.mark.parametrize("beam,n", [(3, 16), (5, 16), (8, 12), (2, 5), (1, 16)])
+@pytest.mark.parametrize("beam,n", [(3, 16), (3, 32), (2, 32), (5, 19), (8, 12), (2, 5), (1, 16)])
 def test_tree_pass_logits_vs_oracle(rig, mels, beam, n):
     """The verification pass against the ORACLE, node by node, on a random tree (random tokens, random origins: every branch pattern, dead ends
     included): the logits of row (s, j) must be the oracle's teacher-forced logits of the node's own chain.  A wrong ancestor slot, position or
@@ -143,7 +143,7 @@ def test_beam_draft_equals_plain_beam_search_whatever_the_draft(rig, mels, beam,
         tail = (np.concatenate([traj[0], junk[0]]), np.concatenate([traj[1], junk[1]]))
         drafts = {"the trajectory": traj, "half of it": cut(traj, n // 2), "one step": cut(traj, 1), "wrong token at step 5": bad_token(traj, 5),
                   "wrong origin at step 3": bad_origin(traj, 3), "wrong first step": bad_token(traj, 0), "garbage": junk, "the trajectory + a tail": tail,
-                  "another clip's": other, "a window + 1": cut(traj, min(n, 17))}
+                  "another clip's": other, "a window + 1": cut(traj, min(n, min(32, 96 // beam) + 1))}
         for name, d in drafts.items():
             got, gscore, gtraj, acc = _gen(model, mel, prompt, beam, draft_trajectory=d, **kw)
             tm = model.last_timing()

@@ -165,7 +165,7 @@ struct wis_model {
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
   int* vstep = nullptr; int* pick_tok = nullptr; float* pick_lp = nullptr;      // wis_generate_draft: per-row step index, picked token / log-probability of the teacher-forced rows
-  int* d_draft = nullptr; int* d_anc = nullptr; int* d_vstate = nullptr;        // wis_generate_draft_beam: the draft trajectory [256][MAX_R][2], the window rows' ancestor slots [MAX_ROWS][16], {steps verified}
+  int* d_draft = nullptr; int* d_anc = nullptr; int* d_vstate = nullptr;        // wis_generate_draft_beam: the draft trajectory [256][MAX_R][2], the window rows' ancestor slots [MAX_ROWS][32], {steps verified}
   float* lm_logspec = nullptr; unsigned* lm_gmax = nullptr;   // log-mel scratch of THIS replica (never shared with other callers)
   int* h_pin;      // pinned host scratch
   unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
@@ -519,7 +519,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.tick, 4));
   WIS_RET(dalloc(m, &m->vstep, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_lp, MAX_ROWS));
   WIS_RET(dalloc(m, &m->bs.traj, (size_t)Bm * 256 * MAX_R * 2));
-  WIS_RET(dalloc(m, &m->d_draft, (size_t)256 * MAX_R * 2)); WIS_RET(dalloc(m, &m->d_anc, (size_t)MAX_ROWS * 16)); WIS_RET(dalloc(m, &m->d_vstate, 4));
+  WIS_RET(dalloc(m, &m->d_draft, (size_t)256 * MAX_R * 2)); WIS_RET(dalloc(m, &m->d_anc, (size_t)MAX_ROWS * 32)); WIS_RET(dalloc(m, &m->d_vstate, 4));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.tick, 0, 16, m->st));
   WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
   WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_SUB)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_SUB));
@@ -708,6 +708,7 @@ static int spin_gave_up(wis_model* m, bool* gave_up) {
 // tw (draft verification at beam > 1): the M rows are nodes of ONE utterance's beam tree - self-attention by ancestor table (anc [M][aw], first
 // window position w0), cross-attention as B = M / 16 groups of R = 16 rows that all read utterance 0's K / V
 struct TreeWin { const int* anc; int w0, aw; };
+constexpr int ANC_W = 32;      // ancestor-table entries per row = the most steps a window holds (beam 2 / 3: 32 steps = 64 / 96 rows)
 static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, int chunks, const TreeWin* tw = nullptr) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
   const int d = c.d_model, H = c.n_heads, T = c.n_audio_ctx, ctx = c.n_text_ctx, MB = cdiv(M, 16);
@@ -1087,7 +1088,7 @@ int wis_model_clone(wis_model_t* parent, wis_model_t** out) {
 }  // extern "C" (reopened below: the generate driver is a static helper)
 
 // The decoder rows of window steps s0 .. s0 + Rw - 1 of a beam trajectory (hd: [step][MAX_R][2] = token, origin; one utterance, k beams), step-major:
-// row (s, j) feeds the token live beam j got at step s - 1 at position P - 1 + s and keeps its K / V in slot j; ha[row][16] = the slot of the
+// row (s, j) feeds the token live beam j got at step s - 1 at position P - 1 + s and keeps its K / V in slot j; ha[row][ANC_W] = the slot of the
 // row's ancestor at every window step (entry 0 doubles as the slot that holds everything before the window).  Padded to whole groups of 16 rows
 // with copies of the last row (they write the same K / V to the same place).  Returns the padded row count.
 static int fill_tree_window(const int* hd, int s0, int Rw, int k, int P, std::vector<int>& tok, std::vector<int>& pos, std::vector<int>& slot, std::vector<int>& ls, int* ha) {
@@ -1097,12 +1098,12 @@ static int fill_tree_window(const int* hd, int s0, int Rw, int k, int P, std::ve
     const int s_ = s0 + t, r = t * k + j;
     tok[r] = hd[((s_ - 1) * MAX_R + j) * 2]; pos[r] = P - 1 + s_; slot[r] = j; ls[r] = j;
     int a = j;                                    // ancestor of (s_, j) at window step sp, walking the origins back to s0
-    for (int sp = s_; sp >= s0; --sp) { ha[r * 16 + (sp - s0)] = a; a = hd[((sp - 1) * MAX_R + a) * 2 + 1]; }
-    for (int u = t + 1; u < 16; ++u) ha[r * 16 + u] = ha[r * 16 + t];
+    for (int sp = s_; sp >= s0; --sp) { ha[r * ANC_W + (sp - s0)] = a; a = hd[((sp - 1) * MAX_R + a) * 2 + 1]; }
+    for (int u = t + 1; u < ANC_W; ++u) ha[r * ANC_W + u] = ha[r * ANC_W + t];
   }
   for (int r = Mreal; r < Mpad; ++r) {
     tok[r] = tok[Mreal - 1]; pos[r] = pos[Mreal - 1]; slot[r] = slot[Mreal - 1]; ls[r] = ls[Mreal - 1];
-    for (int u = 0; u < 16; ++u) ha[r * 16 + u] = ha[(Mreal - 1) * 16 + u];
+    for (int u = 0; u < ANC_W; ++u) ha[r * ANC_W + u] = ha[(Mreal - 1) * ANC_W + u];
   }
   return Mpad;
 }
@@ -1226,9 +1227,9 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, 1, P, ctx, sc));
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, 1, beam, P, ctx, c.d_model));
     WIS_RET(launch_draft_check(st, m->bs, m->d_draft, nd, k, m->d_vstate));
-    const int RW = std::min(16, MAX_ROWS / k);          // steps per window: k x RW rows, padded to whole groups of 16
+    const int RW = std::min(ANC_W, MAX_ROWS / k);       // steps per window: k x RW rows (beam 2 / 3: 32 steps, 5: 19, 8: 12), padded to whole groups of 16
     const int s_last = std::min(nd, max_new - 1);       // last step a window can hold: rows from the draft's entry s - 1; step max_new - 1 ends every search
-    int* ha = m->h_pin + 12352;                         // ancestor table of the window rows, [rows][16]
+    int* ha = m->h_pin + 12352;                         // ancestor table of the window rows, [rows][ANC_W] (.. 15424; the rows' staging follows at 15488)
     int done_flag = 0, step_dev = 0;
     for (int s0 = 1;; ) {
       const int Rw = std::min(RW, s_last - s0 + 1);
@@ -1239,9 +1240,9 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
         // counted) must survive a window that turns out to sit behind a parked search (queued before the host has looked)
         const RowMeta rm_search = m->rm;
         m->rm = m->rm_win;
-        int rc = upload_rows(m, tok, pos, slot, ls, false, 13900);      // (the prompt rows' staging copy may still be pending: own area; windows are a sync apart)
-        if (!rc && hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * 16 * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("draft window: ancestor table upload failed"); rc = WIS_E_HIP; }
-        const TreeWin tw{m->d_anc, P - 1 + s0, 16};
+        int rc = upload_rows(m, tok, pos, slot, ls, false, 15488);      // (the prompt rows' staging copy may still be pending: own area; windows are a sync apart)
+        if (!rc && hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * ANC_W * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("draft window: ancestor table upload failed"); rc = WIS_E_HIP; }
+        const TreeWin tw{m->d_anc, P - 1 + s0, ANC_W};
         if (!rc) rc = dec_forward(m, Mpad, 16, Mpad / 16, true, 1, 0, &tw);
         m->rm = rm_search;
         WIS_RET(rc);
@@ -1284,14 +1285,25 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     std::vector<int> seq(P + nd);
     for (int i = 0; i < P; ++i) seq[i] = prompt[i];
     for (int i = 0; i < nd; ++i) seq[P + i] = draft[i];
-    const int R = 16;
+    // (r6) up to 96 positions per pass: more than 16 rows of one utterance go through the row-group form of the tree pass (a chain is a tree whose
+    // every ancestor sits in slot 0: dec_self_attn_kernel<TREE> with an all-zero table is "causal by position in the slot", the cross-attention
+    // takes the rows as groups of 16 over the one K / V) - the 100 rows of a 96-token draft are 2 passes (3.5 + 1.3 ms) instead of 7 x 1.35 ms.
+    // WIS_DRAFT_ROWS=16: the round-5 schedule (A/B)
+    static const int env_rows = getenv("WIS_DRAFT_ROWS") ? atoi(getenv("WIS_DRAFT_ROWS")) : 0;
+    const int R = (env_rows >= 16 && env_rows <= MAX_ROWS) ? env_rows / 16 * 16 : MAX_ROWS;
     bool stop = false; int n_acc = 0;
     for (int t0 = 0; t0 < P + nd && !stop; t0 += R) {
       const int rows = std::min(R, P + nd - t0);
       const int f = std::max(P - 1 - t0, 0), nv = rows - f;      // rows f .. rows-1 of this pass predict generated tokens
-      std::vector<int> tok(rows), pos(rows), slot(rows, 0), ls(rows, 0);
-      for (int i = 0; i < rows; ++i) { tok[i] = seq[t0 + i]; pos[i] = t0 + i; }
+      const int Mp = rows > 16 ? cdiv(rows, 16) * 16 : rows;      // (row groups: padded with copies of the last row - same K / V to the same place)
+      std::vector<int> tok(Mp), pos(Mp), slot(Mp, 0), ls(Mp, 0);
+      for (int i = 0; i < Mp; ++i) { const int ii = std::min(i, rows - 1); tok[i] = seq[t0 + ii]; pos[i] = t0 + ii; }
       WIS_RET(upload_rows(m, tok, pos, slot, ls));
+      if (rows > 16) {
+        WIS_HIP_CHECK(hipMemsetAsync(m->d_anc, 0, (size_t)Mp * 16 * 4, st));
+        const TreeWin tw{m->d_anc, t0, 16};
+        WIS_RET(dec_forward(m, Mp, 16, Mp / 16, nv > 0, 1, 0, &tw));
+      } else
       WIS_RET(dec_forward(m, rows, rows, 1, nv > 0, 1, 0));
       if (nv <= 0) continue;
       int* hv = m->h_pin + 4096;
@@ -1734,8 +1746,8 @@ int wis_debug_logits_rows(wis_model_t* m, const float* input, int input_kind, in
 
 int wis_debug_tree_logits(wis_model_t* m, const float* input, int input_kind, const int32_t* prompt, int P, int beam,
                           const int32_t* tok, const int32_t* org, int n_steps, float* logits) {
-  if (!m || !input || !prompt || !tok || !org || !logits || P < 1 || P > 16 || beam < 1 || beam > MAX_R || n_steps < 1 || n_steps > std::min(16, MAX_ROWS / std::max(beam, 1))) {
-    set_error("wis_debug_tree_logits: bad argument (1 <= n_steps <= min(16, %d / beam))", MAX_ROWS); return WIS_E_ARG;
+  if (!m || !input || !prompt || !tok || !org || !logits || P < 1 || P > 16 || beam < 1 || beam > MAX_R || n_steps < 1 || n_steps > std::min(32, MAX_ROWS / std::max(beam, 1))) {
+    set_error("wis_debug_tree_logits: bad argument (1 <= n_steps <= min(32, %d / beam))", MAX_ROWS); return WIS_E_ARG;
   }
   WIS_ENTER(m, "wis_debug_tree_logits")
   WIS_HIP_CHECK(hipSetDevice(m->device));
@@ -1765,9 +1777,9 @@ int wis_debug_tree_logits(wis_model_t* m, const float* input, int input_kind, co
   std::vector<int> wt, wp, wsl, wls;
   int* ha = m->h_pin + 12352;
   const int Mpad = fill_tree_window(hd.data(), 1, n_steps, k, P, wt, wp, wsl, wls, ha);
-  WIS_RET(upload_rows(m, wt, wp, wsl, wls, false, 13900));
-  WIS_HIP_CHECK(hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * 16 * 4, hipMemcpyHostToDevice, st));
-  const TreeWin tw{m->d_anc, P, 16};
+  WIS_RET(upload_rows(m, wt, wp, wsl, wls, false, 15488));
+  WIS_HIP_CHECK(hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * ANC_W * 4, hipMemcpyHostToDevice, st));
+  const TreeWin tw{m->d_anc, P, ANC_W};
   WIS_RET(dec_forward(m, Mpad, 16, Mpad / 16, true, 1, 0, &tw));
   WIS_HIP_CHECK(hipMemcpy2DAsync(logits, (size_t)V * 4, m->logits, (size_t)m->n_vocab_pad * 4, (size_t)V * 4, (size_t)n_steps * k, hipMemcpyDeviceToHost, st));
   WIS_HIP_CHECK(hipStreamSynchronize(st));
