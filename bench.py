@@ -159,7 +159,7 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
     (no socket): container decode, micro-batching and the HIP path are all inside the measurement.
     side_sessions > 0: that many StreamingSessions (30sec.flac at beam 1 - the default beam_size, the case that speculates by default; S = 96)
     run beside the clients for the whole measured phase, each asking for an interim decode after every 2 s of audio as fast as the decodes
-    allow (no real-time pacing: ~15 x what live sessions would ask for - the worst case for the REST traffic); side_gate =
+    allow, at most 40 x real time (the worst case for the REST traffic); side_gate =
     settings.stream_speculate_max_busy (None: the default gate; 1e9: no gate)."""
     import asyncio
     import threading
@@ -201,8 +201,7 @@ def rest_load(handle, a, dev, clients, iterations, fixed_new, clip_bytes, audio_
                     job = sess._spec_job
                     if job is not None:
                         job.result()
-                    else:
-                        time.sleep(0.002)
+                    time.sleep(0.05)       # 2 s of audio every >= 50 ms: 40 x real time (the feeding itself must not be what the REST clients compete with)
             finally:
                 side_stats["interim_decodes"] += sess.spec_runs
                 side_stats["skipped_by_the_load_gate"] += sess.spec_skipped
