@@ -153,16 +153,16 @@ def test_beam_draft_equals_plain_beam_search_whatever_the_draft(rig, mels, beam,
             n_cases += 1
             n_same += got == ids
             assert acc is not None and EOT not in got
-            # the steps the engine accepted ARE the draft's (and the search went on from them)
-            assert acc <= len(d[0]) and np.array_equal(gtraj[0][:acc], d[0][:acc]) and np.array_equal(gtraj[1][:acc], d[1][:acc])
+            # the steps the engine accepted ARE the draft's live sets (as sets: the matching is blind to the slot order) and the search went on from them
+            assert acc <= len(d[0]) and all(sorted(gtraj[0][s_].tolist()) == sorted(d[0][s_].tolist()) for s_ in range(acc))
             # ... normally all the steps on which the draft and the plain call's trajectory agree; two candidates whose scores tie to within
             # the summation order of the multi-row pass may swap beam slots (same live set, another order: the draft is left one step
             # early, nothing else changes) - seen at beam 8 on the tiny weights, whose 16 candidates per step are crowded
-            n_full += acc == want_acc
+            n_full += acc >= want_acc
             if got == ids:
-                assert acc <= want_acc and abs(gscore - score) <= 2e-3
+                assert abs(gscore - score) <= 2e-3
                 same_traj = gtraj[0].shape == traj[0].shape and np.array_equal(gtraj[0], traj[0]) and np.array_equal(gtraj[1], traj[1])
-                n_traj += same_traj
+                n_traj += gtraj[0].shape == traj[0].shape and all(sorted(gtraj[0][s_].tolist()) == sorted(traj[0][s_].tolist()) for s_ in range(len(traj[0])))      # the same live sets, whatever their slot order
                 if not same_traj:      # (cumulative scores that came out of multi-row passes differ in their last bits: a tie may order two slots differently later on)
                     sd = _common_steps(gtraj, traj, beam)
                     if sd < min(len(gtraj[0]), len(traj[0])):
@@ -174,11 +174,46 @@ def test_beam_draft_equals_plain_beam_search_whatever_the_draft(rig, mels, beam,
     # the multi-row passes sum in another order than the one-utterance step: a near-tie may fall differently (rare on these weights)
     assert n_same >= n_cases - 2, (n_same, n_cases)
     print(f"  {size} beam {beam} fixed_new {fixed_new}: {n_same} of {n_cases} identical to the plain call, {n_full} followed the draft as far as the plain trajectory does, "
-          f"{n_traj} left the plain call's trajectory")
-    # (observed on MI355X: beams 2 / 3 follow every draft to the end and leave the plain call's trajectory in 20 of 20 cases; at beams 5 / 8 ties between
-    # candidates - the same live set in another slot order at base, a k-th / (k+1)-th candidate swap on the crowded tiny weights - end some drafts early
-    # or permute slots afterwards: the ANSWER is the plain call's in every case; test_tree_pass_logits_vs_oracle pins the pass itself node by node)
-    assert n_full >= (0.8 if beam <= 5 else 0.5) * n_cases and n_traj >= (0.8 if beam <= 3 else 0.3) * n_cases, (n_full, n_traj, n_cases)
+          f"{n_traj} left the plain call's live sets step by step")
+    # (observed on MI355X with the set matching: every draft is followed as far as the plain trajectory agrees with it at beams 2 / 3 / 5; at beam 8 a k-th /
+    # (k+1)-th candidate swap on the crowded tiny weights - another live SET, not another order - still ends some drafts early; the ANSWER is the plain call's
+    # in every case; test_tree_pass_logits_vs_oracle pins the pass itself node by node)
+    assert n_full >= (0.8 if beam <= 5 else 0.5) * n_cases and n_traj >= (0.8 if beam <= 5 else 0.3) * n_cases, (n_full, n_traj, n_cases)
+
+
+@pytest.mark.parametrize("beam", [2, 3, 5, 8])
+def test_beam_draft_is_matched_as_a_set_not_slot_by_slot(rig, mels, beam):
+    """Two candidates whose scores tie to within a pass's summation order may swap beam slots between the draft's search and the final one; that permutes
+    the live set and changes nothing else, so the verification matches live sets as SETS (dec_kernels.hip draft_match_kernel: every live beam must be found
+    exactly once in the draft's entry, origins translated through the previous step's matching) and reads each beam's logits from the row of the node it was
+    matched to.  Here the plain call's trajectory is relabelled with a fresh random slot permutation at EVERY step: the search must follow it to its end, the
+    answer must be the plain call's, and the cache must come out right (the steps behind the draft - and the score - depend on it)."""
+    size, model, ref, memory = rig
+    rng = np.random.default_rng(77 + beam)
+    for ci, mel in enumerate(mels):
+        for fixed_new in (0, 40):
+            kw = dict(fixed_new_tokens=fixed_new)
+            prompt = _prompt(ci)
+            ids, score, (tok, org), _ = _gen(model, mel, prompt, beam, **kw)
+            n = tok.shape[0]
+            ptok, porg = np.zeros_like(tok), np.zeros_like(org)
+            prev = np.arange(beam)
+            for s_ in range(n):
+                pi = rng.permutation(beam)
+                for i in range(beam):
+                    ptok[s_, pi[i]] = tok[s_, i]
+                    porg[s_, pi[i]] = prev[org[s_, i]] if s_ else 0
+                prev = pi
+            for name, d in (("every step permuted", (ptok, porg)), ("permuted, first 3/4", (ptok[:3 * n // 4].copy(), porg[:3 * n // 4].copy()))):
+                got, gscore, gtraj, acc = _gen(model, mel, prompt, beam, draft_trajectory=d, **kw)
+                print(f"  {size} beam {beam} clip {ci} fixed_new {fixed_new} draft '{name}' ({len(d[0])} steps): accepted {acc}, identical {got == ids}, score {gscore:.5f} vs {score:.5f}")
+                assert EOT not in got and abs(gscore - score) <= 2e-3
+                if fixed_new == 0:
+                    assert abs(gscore - oracle_rescore(ref, memory[ci], prompt, got, 224)) <= 3e-3
+                if got == ids and beam <= 3:
+                    assert acc == len(d[0])          # (beams 5 / 8: a k-th / (k+1)-th candidate swap may still end a draft early - another SET, not another order)
+                assert acc >= min(len(d[0]), 4)
+            # the plain trajectory itself must be followed at least as far as before
 
 
 @pytest.mark.parametrize("beam", [3, 5])

@@ -1426,7 +1426,7 @@ template <bool TREE>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
                                                            const int* __restrict__ pos, int d, int ctx, int rpu, int sstride, int rmul,
                                                            f16* __restrict__ out, unsigned long long* prof, int out_mb,
-                                                           const int* __restrict__ anc, int w0, int aw) {
+                                                           const int* __restrict__ anc, int w0, int aw, const int* __restrict__ base) {
   __shared__ float red[4][64];
   const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, pl = lane >> 3, c = lane & 7;
   unsigned long long* pf = (m == 0 && h == 0 && lane == 0) ? prof : nullptr;
@@ -1435,13 +1435,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   // the row's history lives in ITS OWN slot (kv_reorder_kernel made it so after the last beam step): the K / V addresses of the
   // first 64 positions depend on nothing that has to be loaded, so q, the row's length and all of K and V travel in ONE round
   // trip (positions >= len are fetched from valid memory and masked below)
-  const int ls = TREE ? anc[(size_t)m * aw] : (m / rpu) * sstride + (m % rpu) * rmul;
+  // (TREE: positions before the window live in slot base[m] - or, without a base table, in the slot of the row's window-step-0 ancestor)
+  const int ls = TREE ? (base ? base[m] : anc[(size_t)m * aw]) : (m / rpu) * sstride + (m % rpu) * rmul;
   const int len = pos[m] + 1;
   // slot that holds position p of this row's history
   auto slot_of = [&](int p) -> int {
     if (!TREE) return ls;
     int t = p - w0; t = t < aw - 1 ? t : aw - 1;
-    return t <= 0 ? ls : anc[(size_t)m * aw + t];
+    return t < 0 ? ls : anc[(size_t)m * aw + t];
   };
   const float4 q0 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c);
   const float4 q1 = *reinterpret_cast<const float4*>(q + (size_t)m * d + h * 64 + 8 * c + 4);
@@ -1539,13 +1540,13 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
 }
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof, int out_mb,
-                         const int* anc, int w0, int aw) {
+                         const int* anc, int w0, int aw, const int* base) {
   if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
   if (anc) {
     if (aw < 1) { set_error("dec_self_attn: ancestor table of width %d", aw); return WIS_E_ARG; }
-    hipLaunchKernelGGL(dec_self_attn_kernel<true>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw);
+    hipLaunchKernelGGL(dec_self_attn_kernel<true>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
   } else
-    hipLaunchKernelGGL(dec_self_attn_kernel<false>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw);
+    hipLaunchKernelGGL(dec_self_attn_kernel<false>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
   return WIS_OK;
 }
 
@@ -2018,7 +2019,7 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
                                                           const float* __restrict__ bias_begin, const int* __restrict__ step_u,
                                                           float* __restrict__ st_max, float* __restrict__ st_sum,
                                                           float* __restrict__ st_val, int* __restrict__ st_idx, SampleCfg cfg,
-                                                          int lr_b, int lr_j, int lr_off, unsigned long long* prof) {
+                                                          int lr_b, int lr_j, int lr_off, unsigned long long* prof, const int* __restrict__ rowmap) {
   constexpr int PT = 16;   // values per lane: supports n_vocab <= 64 * 64 * 16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sc = blockIdx.x * 4 + wave, m = blockIdx.y, b = m / cfg.beam;
@@ -2029,7 +2030,9 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
   const int lo = sc * SL, hi = (lo + SL < cfg.n_vocab) ? lo + SL : cfg.n_vocab;
   // logits row of (utterance b, beam j): decode steps b*beam + j; the merged prefill+first step samples every beam from the
   // utterance's last prompt row (beams > 0 carry cum = -inf there)
-  const float* row = logits + (size_t)(b * lr_b + (m - b * cfg.beam) * lr_j + lr_off) * cfg.n_vocab_pad;
+  // (rowmap: draft verification of a beam search - live beam j's logits sit in the row of the draft node it was matched to)
+  const int jb = m - b * cfg.beam;
+  const float* row = logits + (size_t)(b * lr_b + (rowmap ? rowmap[jb] : jb) * lr_j + lr_off) * cfg.n_vocab_pad;
   const bool first = (step == 0) && cfg.suppress_blank;
   const bool mask_eot = cfg.fixed_new > 0 && step < cfg.fixed_new;
   const bool force_eot = cfg.fixed_new > 0 && step >= cfg.fixed_new;
@@ -2089,10 +2092,10 @@ __global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restric
 }
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
                        float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg, int lr_b, int lr_j, int lr_off,
-                       unsigned long long* prof) {
+                       unsigned long long* prof, const int* rowmap) {
   if (cdiv(cfg.n_vocab, STAT_SUB) > 16 * 64) { set_error("logit_stats: vocab too large"); return WIS_E_UNSUPPORTED; }
   hipLaunchKernelGGL(logit_stats_kernel, dim3(STAT_SUB / 4, B * cfg.beam), dim3(256), 0, st, logits, bias_all, bias_begin, step_u,
-                     st_max, st_sum, st_val, st_idx, cfg, lr_b, lr_j, lr_off, prof);
+                     st_max, st_sum, st_val, st_idx, cfg, lr_b, lr_j, lr_off, prof, rowmap);
   return WIS_OK;
 }
 
@@ -2357,23 +2360,89 @@ int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, c
 }
 
 // =======================================================================================
-// Draft verification at beam > 1 (model.hip verify_beam_draft; one utterance): a window of replayed beam steps is queued WITHOUT host round
-// trips; this one-thread kernel behind every replayed step compares the live set the step produced (tokens + the slots they continued from,
-// as beam_step_kernel recorded them in bs.traj) with the draft's entry for that step.  Equal: the rows the window fed for the NEXT step were
-// the right ones - go on.  Different, or no draft entry left: the step itself stands (its inputs were verified), but nothing behind it
-// does - done = 2 parks the search (beam_step_kernel and kv_reorder_kernel return at their `done` test) until the host resumes it.
-__global__ void draft_check_kernel(BeamState bs, const int* __restrict__ draft, int n_draft, int k, int* __restrict__ vstate) {
-  if (threadIdx.x != 0 || bs.done[0]) return;
+// Draft verification at beam > 1 (model.hip generate_impl; one utterance): a window of replayed beam steps is queued WITHOUT host round trips; this
+// one-workgroup kernel behind every replayed step matches the live set the step produced (tokens + the beams they continued from, as beam_step_kernel
+// recorded them in bs.traj) with the draft's entry for that step - as SETS: two candidates whose scores tie to within the summation order of a pass may
+// swap beam slots between the draft's search and this one, which changes nothing about the search itself, so live beam j may sit in ANY slot of the draft
+// as long as every live beam is found exactly once: (token, origin) of real beam j == (token, origin) of draft node i with the origin translated
+// through the previous step's matching.  vs[8 + j] = the draft node live beam j is matched to: the replay reads beam j's logits from that node's row
+// (logit_stats_kernel rowmap).  All matched: vs[0] = steps verified so far.  A live beam the draft does not have - or no draft entry left - : the step
+// itself stands (its inputs were verified), but nothing behind it does - done = 2 parks the search (beam_step_kernel and the kernels below return at
+// their `done` test) until the host resumes it.
+// Cache bookkeeping (book = 1: the steps of a window): the window's pass left node (s, i)'s K / V in slot i (draft index), so a live beam's history is a
+// path through slots; per live beam the kernel maintains that path - vs[32 + 32 j + t] = the slot that holds beam j's row of window step t, vs[16 + j] =
+// the slot that holds everything before the window - by pulling the parent's path and appending the parent's node; kv_gather_kernel below turns the
+// paths into the layout ordinary steps expect (slot j = beam j's whole history) once per window.
+// vs layout (ints): 0 steps verified | 2 window steps applied | 8.. matching | 16.. pre-window slot | 32.. paths [8][32]
+constexpr int VS_PERM = 8, VS_BASE = 16, VS_PATH = 32, VS_PATH_W = 32, VS_INTS = VS_PATH + MAX_R * VS_PATH_W;
+__global__ __launch_bounds__(64) void draft_match_kernel(BeamState bs, const int* __restrict__ draft, int n_draft, int k, int* __restrict__ vs, int book) {
+  __shared__ int org_r[MAX_R], tok_r[MAX_R], perm_prev[MAX_R], old_base[MAX_R], old_path[MAX_R][VS_PATH_W];
+  const int tid = threadIdx.x;
+  if (bs.done[0]) return;                    // (uniform: finished, or parked by an earlier step)
   const int s = bs.step_u[0] - 1;            // the step that just completed
-  bool ok = s >= 0 && s < n_draft;
-  if (ok) {
-    const int* tr = bs.traj + (size_t)s * MAX_R * 2; const int* dr = draft + (size_t)s * MAX_R * 2;
-    for (int j = 0; j < k; ++j) ok = ok & (tr[2 * j] == dr[2 * j]) & (tr[2 * j + 1] == dr[2 * j + 1]);
+  const int t = vs[2];
+  if (tid < k) {
+    const int* tr = bs.traj + ((size_t)s * MAX_R + tid) * 2;
+    tok_r[tid] = tr[0]; org_r[tid] = tr[1]; perm_prev[tid] = vs[VS_PERM + tid]; old_base[tid] = vs[VS_BASE + tid];
   }
-  if (ok) vstate[0] = s + 1; else bs.done[0] = 2;
+  for (int e = tid; e < k * VS_PATH_W; e += 64) old_path[e / VS_PATH_W][e % VS_PATH_W] = vs[VS_PATH + e];
+  __syncthreads();
+  if (book) {
+    for (int e = tid; e < k * VS_PATH_W; e += 64) {
+      const int j = e / VS_PATH_W, u = e % VS_PATH_W, pj = org_r[j];
+      if (u < t) vs[VS_PATH + e] = old_path[pj][u];
+      else if (u == t) vs[VS_PATH + e] = perm_prev[pj];      // the parent's own row of this step sits in the slot of the draft node it was matched to
+    }
+    if (tid < k) vs[VS_BASE + tid] = old_base[org_r[tid]];
+  }
+  if (tid == 0) {
+    bool ok = s >= 0 && s < n_draft;
+    int pn[MAX_R]; unsigned used = 0;
+    if (ok) {
+      const int* dr = draft + (size_t)s * MAX_R * 2;
+      for (int j = 0; j < k && ok; ++j) {
+        const int want_org = perm_prev[org_r[j]];
+        int hit = -1;
+        for (int i = 0; i < k; ++i) if (!((used >> i) & 1u) && dr[2 * i] == tok_r[j] && dr[2 * i + 1] == want_org) { hit = i; break; }
+        if (hit < 0) ok = false; else { pn[j] = hit; used |= 1u << hit; }
+      }
+    }
+    if (ok) { for (int j = 0; j < k; ++j) vs[VS_PERM + j] = pn[j]; vs[0] = s + 1; }
+    else bs.done[0] = 2;
+    if (book) vs[2] = t + 1;
+  }
 }
-int launch_draft_check(hipStream_t st, const BeamState& bs, const int* draft, int n_draft, int beam, int* vstate) {
-  hipLaunchKernelGGL(draft_check_kernel, dim3(1), dim3(64), 0, st, bs, draft, n_draft, beam, vstate);
+int launch_draft_match(hipStream_t st, const BeamState& bs, const int* draft, int n_draft, int beam, int* vstate, int book) {
+  hipLaunchKernelGGL(draft_match_kernel, dim3(1), dim3(64), 0, st, bs, draft, n_draft, beam, vstate, book);
+  return WIS_OK;
+}
+// The paths of draft_match_kernel applied to the cache, once per window: slot j becomes beam j's history - positions before the window from slot
+// vs[16 + j], window step u (position w0 + u) from slot vs[32 + 32 j + u], for the vs[2] steps the window's replay completed (a parked search included:
+// the step that parked it stands).  grid (8 position slices, 2 L), one thread = one 16-byte column chunk of ALL k slots at a position: loads, waits,
+// stores - the in-place gather of kv_reorder_kernel with a parent table per position.
+__global__ __launch_bounds__(256) void kv_gather_kernel(f16* __restrict__ kc, f16* __restrict__ vc, size_t lstride, const int* __restrict__ vs, const int* __restrict__ done,
+                                                        int k, int w0, int ctx, int d) {
+  const int lk = blockIdx.y, tid = threadIdx.x;
+  const int nwin = vs[2];
+  if (done[0] == 1 || nwin <= 0) return;         // finished inside the window (the cache is not read again) / nothing replayed
+  f16* cache = ((lk & 1) ? vc : kc) + (size_t)(lk >> 1) * lstride;
+  const int c8 = d >> 3, npos = w0 + nwin;
+  for (int p = blockIdx.x; p < npos; p += gridDim.x) {
+    int par[MAX_R];
+#pragma unroll
+    for (int j = 0; j < MAX_R; ++j) par[j] = j < k ? (p < w0 ? vs[VS_BASE + j] : vs[VS_PATH + j * VS_PATH_W + (p - w0)]) : j;
+    for (int ch = tid; ch < c8; ch += 256) {
+      u32x4 v[MAX_R];
+#pragma unroll
+      for (int j = 0; j < MAX_R; ++j) if (j < k && par[j] != j) v[j] = *reinterpret_cast<const u32x4*>(cache + ((size_t)par[j] * ctx + p) * d + ch * 8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < MAX_R; ++j) if (j < k && par[j] != j) *reinterpret_cast<u32x4*>(cache + ((size_t)j * ctx + p) * d + ch * 8) = v[j];
+    }
+  }
+}
+int launch_kv_gather(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const int* vstate, const int* done, int beam, int w0, int ctx, int d) {
+  hipLaunchKernelGGL(kv_gather_kernel, dim3(8, 2 * L), dim3(256), 0, st, kc, vc, layer_stride, vstate, done, beam, w0, ctx, d);
   return WIS_OK;
 }
 

@@ -119,7 +119,7 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 // the cache rows of positions < w0 from slot anc[m * aw] and position w0 + t from slot anc[m * aw + t] (its ancestor at window step t)
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr, int out_mb = 0,
-                         const int* anc = nullptr, int w0 = 0, int aw = 0);
+                         const int* anc = nullptr, int w0 = 0, int aw = 0, const int* base = nullptr);      // base (optional): slot of the positions before w0, per row
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 // gran / epoch (optional): the granule hand-off of small grids (dec_kernels.hip, SPIN): gran = 8-byte slots [B*H][6][8][66], epoch =
@@ -147,7 +147,8 @@ struct SampleCfg {
 constexpr int STAT_SUB = 64;      // sub-chunks per logits row (one wave each): statistics and top-n_cand candidates per sub-chunk
 int launch_logit_stats(hipStream_t st, const float* logits, const float* bias_all, const float* bias_begin, const int* step_u,
                        float* st_max, float* st_sum, float* st_val, int* st_idx, int B, const SampleCfg& cfg,
-                       int lr_b, int lr_j, int lr_off, unsigned long long* prof = nullptr);   // logits row of (b, j) = b*lr_b + j*lr_j + lr_off
+                       int lr_b, int lr_j, int lr_off, unsigned long long* prof = nullptr,    // logits row of (b, j) = b*lr_b + j*lr_j + lr_off
+                       const int* rowmap = nullptr);      // ... or b*lr_b + rowmap[j]*lr_j + lr_off (device table: draft verification of a beam search)
 struct BeamState {
   int* step_u;      // [B] generated-token count so far
   int* done;        // [B]
@@ -184,10 +185,13 @@ __host__ __device__ inline int* hp_out_ids(unsigned long long* hp) { return rein
 int launch_kv_reorder(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const BeamState& bs, int B, int beam, int P, int ctx, int d);
 int launch_beam_step(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx,
                      const BeamState& bs, const RowMeta& rm, int B, int P, int ctx, const SampleCfg& cfg, unsigned long long* prof = nullptr);
-// draft verification at beam > 1 (one utterance): after a replayed beam step, is the search where the draft says it was?  draft = [n_draft][MAX_R][2]
-// in BeamState::traj's layout.  Equal: vstate[0] = steps verified so far; different (or the draft has no entry for the step): done[0] = 2 -
-// the step itself stands (its inputs were verified), the beam steps queued behind it return at their `done` test
-int launch_draft_check(hipStream_t st, const BeamState& bs, const int* draft, int n_draft, int beam, int* vstate);
+// draft verification at beam > 1 (one utterance; dec_kernels.hip draft_match_kernel / kv_gather_kernel): behind a replayed beam step, match the live set
+// it produced with the draft's entry for the step AS A SET (draft = [n_draft][MAX_R][2] in BeamState::traj's layout); vstate ints: 0 steps verified,
+// 2 window steps applied, 8.. the draft node each live beam is matched to (logit_stats rowmap), 16.. / 32.. the slots holding each beam's history
+// (book = 1: maintained per window step, applied to the cache by launch_kv_gather once per window).  No match: done[0] = 2 parks the search
+constexpr int DRAFT_VS_INTS = 32 + MAX_R * 32, DRAFT_VS_PERM = 8, DRAFT_VS_BASE = 16;
+int launch_draft_match(hipStream_t st, const BeamState& bs, const int* draft, int n_draft, int beam, int* vstate, int book);
+int launch_kv_gather(hipStream_t st, f16* kc, f16* vc, size_t layer_stride, int L, const int* vstate, const int* done, int beam, int w0, int ctx, int d);
 // teacher-forced rows: the token a k = 1 beam step would take from each row's statistics, and its log-probability
 int launch_greedy_pick(hipStream_t st, const float* st_max, const float* st_sum, const float* st_val, const int* st_idx, int rows, const SampleCfg& cfg, int* tok_out, float* lp_out);
 // language detection: softmax over lang_ids of the row's logits

@@ -165,7 +165,7 @@ struct wis_model {
   float *st_max, *st_sum, *st_val; int* st_idx;
   float* d_in; int64_t* d_nsamp; float* d_probs;
   int* vstep = nullptr; int* pick_tok = nullptr; float* pick_lp = nullptr;      // wis_generate_draft: per-row step index, picked token / log-probability of the teacher-forced rows
-  int* d_draft = nullptr; int* d_anc = nullptr; int* d_vstate = nullptr;        // wis_generate_draft_beam: the draft trajectory [256][MAX_R][2], the window rows' ancestor slots [MAX_ROWS][32], {steps verified}
+  int* d_draft = nullptr; int* d_anc = nullptr; int* d_vstate = nullptr; int* d_base = nullptr;        // wis_generate_draft_beam: the draft trajectory [256][MAX_R][2], the window rows' ancestor slots [MAX_ROWS][32], {steps verified}
   float* lm_logspec = nullptr; unsigned* lm_gmax = nullptr;   // log-mel scratch of THIS replica (never shared with other callers)
   int* h_pin;      // pinned host scratch
   unsigned long long* h_prog = nullptr;      // host-mapped progress block of the beam search (kernels.hpp HP_*): the decode loop polls it
@@ -519,7 +519,7 @@ int alloc_buffers(wis_model* m) {
   WIS_RET(dalloc(m, &m->bs.tick, 4));
   WIS_RET(dalloc(m, &m->vstep, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_tok, MAX_ROWS)); WIS_RET(dalloc(m, &m->pick_lp, MAX_ROWS));
   WIS_RET(dalloc(m, &m->bs.traj, (size_t)Bm * 256 * MAX_R * 2));
-  WIS_RET(dalloc(m, &m->d_draft, (size_t)256 * MAX_R * 2)); WIS_RET(dalloc(m, &m->d_anc, (size_t)MAX_ROWS * 32)); WIS_RET(dalloc(m, &m->d_vstate, 4));
+  WIS_RET(dalloc(m, &m->d_draft, (size_t)256 * MAX_R * 2)); WIS_RET(dalloc(m, &m->d_anc, (size_t)MAX_ROWS * 32)); WIS_RET(dalloc(m, &m->d_vstate, DRAFT_VS_INTS)); WIS_RET(dalloc(m, &m->d_base, MAX_ROWS));
   WIS_HIP_CHECK(hipMemsetAsync(m->bs.tick, 0, 16, m->st));
   WIS_RET(dalloc(m, &m->bs.out_ids, (size_t)Bm * max_new)); WIS_RET(dalloc(m, &m->bs.out_len, Bm)); WIS_RET(dalloc(m, &m->bs.out_score, Bm));
   WIS_RET(dalloc(m, &m->st_max, (size_t)MAX_ROWS * STAT_SUB)); WIS_RET(dalloc(m, &m->st_sum, (size_t)MAX_ROWS * STAT_SUB));
@@ -707,7 +707,7 @@ static int spin_gave_up(wis_model* m, bool* gave_up) {
 // LayerNorm launch, no per-workgroup LDS staging of the activations.
 // tw (draft verification at beam > 1): the M rows are nodes of ONE utterance's beam tree - self-attention by ancestor table (anc [M][aw], first
 // window position w0), cross-attention as B = M / 16 groups of R = 16 rows that all read utterance 0's K / V
-struct TreeWin { const int* anc; int w0, aw; };
+struct TreeWin { const int* anc; int w0, aw; const int* base = nullptr; };
 constexpr int ANC_W = 32;      // ancestor-table entries per row = the most steps a window holds (beam 2 / 3: 32 steps = 64 / 96 rows)
 static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits, int sstride, int rmul, int chunks, const TreeWin* tw = nullptr) {
   const wis_config_t& c = m->cfg; hipStream_t st = m->st;
@@ -732,7 +732,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     g.csum = w.c_qkv; g.stat_in = m->dstat; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
     WIS_RET(launch_gemv_frag(st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB, tw ? tw->anc : nullptr, tw ? tw->w0 : 0, tw ? tw->aw : 0));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB, tw ? tw->anc : nullptr, tw ? tw->w0 : 0, tw ? tw->aw : 0, tw ? tw->base : nullptr));
     if (fold) {
       // ONE launch, three d x d problems on 3 d / 16 workgroups: x1 = x0 + Wo a + bo (residual rows + their LayerNorm partials; nobody
       // reads x1's fragment image any more, so none is written and x0's image stays valid for the other two), q_A = W'q x0 + W'q bo
@@ -1217,48 +1217,60 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     const int nd = std::min(n_draft, max_new - 1);
     int* hd = m->h_pin + 8192;                         // the draft in BeamState::traj's layout ([step][MAX_R][2])
     for (int s_ = 0; s_ < nd; ++s_) for (int j = 0; j < k; ++j) { hd[(s_ * MAX_R + j) * 2] = draft[s_ * k + j]; hd[(s_ * MAX_R + j) * 2 + 1] = draft_org[s_ * k + j]; }
-    int* hv = m->h_pin + 12288;                        // [0] steps verified, [1] done flag, [2] step counter (read back per window)
-    hv[0] = 0;
+    int* hv = m->h_pin + 12288;                        // staging of the verification state (dec_kernels.hip draft_match_kernel: vs), read back per window
+    for (int i = 0; i < 32; ++i) hv[i] = 0;
+    for (int j = 0; j < MAX_R; ++j) { hv[DRAFT_VS_PERM + j] = j; hv[DRAFT_VS_BASE + j] = j; }
     if (nd > 0) WIS_HIP_CHECK(hipMemcpyAsync(m->d_draft, hd, (size_t)nd * MAX_R * 2 * 4, hipMemcpyHostToDevice, st));
-    WIS_HIP_CHECK(hipMemcpyAsync(m->d_vstate, hv, 4, hipMemcpyHostToDevice, st));
+    WIS_HIP_CHECK(hipMemcpyAsync(m->d_vstate, hv, 32 * 4, hipMemcpyHostToDevice, st));
     // merged prefill + first step as in the ordinary call, then: is the search where the draft's step 0 says?
     WIS_RET(dec_forward(m, P, P, 1, true, beam, 0));
     WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, 1, sc, P, 0, P - 1));
     WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, 1, P, ctx, sc));
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, 1, beam, P, ctx, c.d_model));
-    WIS_RET(launch_draft_check(st, m->bs, m->d_draft, nd, k, m->d_vstate));
+    WIS_RET(launch_draft_match(st, m->bs, m->d_draft, nd, k, m->d_vstate, 0));
     const int RW = std::min(ANC_W, MAX_ROWS / k);       // steps per window: k x RW rows (beam 2 / 3: 32 steps, 5: 19, 8: 12), padded to whole groups of 16
     const int s_last = std::min(nd, max_new - 1);       // last step a window can hold: rows from the draft's entry s - 1; step max_new - 1 ends every search
     int* ha = m->h_pin + 12352;                         // ancestor table of the window rows, [rows][ANC_W] (.. 15424; the rows' staging follows at 15488)
+    int* hb = m->h_pin + 15872;                         // ... and the slot holding each row's history before the window, [rows] (.. 15968)
+    int* hw2 = m->h_pin + 16000;                        // per-window reset of the path bookkeeping: vs[2] = 0, vs[16 + j] = j
     int done_flag = 0, step_dev = 0;
+    int pinv[MAX_R];                                    // real slot of draft node i at the window's start (the matching read back at the previous sync)
+    for (int j = 0; j < MAX_R; ++j) pinv[j] = j;        // (first window: every slot holds the same prompt rows - any assignment is right)
     for (int s0 = 1;; ) {
       const int Rw = std::min(RW, s_last - s0 + 1);
       if (Rw >= 1) {
         std::vector<int> tok, pos, slot, ls;
         const int Mpad = fill_tree_window(hd, s0, Rw, k, P, tok, pos, slot, ls, ha);
+        for (int r = 0; r < Mpad; ++r) hb[r] = pinv[ha[r * ANC_W]];      // the row's window-step-0 ancestor is draft node ha[r][0]: its earlier history sits in that node's REAL slot
         // the window's rows go through a row table of their own: the search's table (next input rows, written by the last beam step that
         // counted) must survive a window that turns out to sit behind a parked search (queued before the host has looked)
         const RowMeta rm_search = m->rm;
         m->rm = m->rm_win;
         int rc = upload_rows(m, tok, pos, slot, ls, false, 15488);      // (the prompt rows' staging copy may still be pending: own area; windows are a sync apart)
-        if (!rc && hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * ANC_W * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("draft window: ancestor table upload failed"); rc = WIS_E_HIP; }
-        const TreeWin tw{m->d_anc, P - 1 + s0, ANC_W};
+        if (!rc && (hipMemcpyAsync(m->d_anc, ha, (size_t)Mpad * ANC_W * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(m->d_base, hb, (size_t)Mpad * 4, hipMemcpyHostToDevice, st) != hipSuccess)) { set_error("draft window: ancestor table upload failed"); rc = WIS_E_HIP; }
+        TreeWin tw{m->d_anc, P - 1 + s0, ANC_W}; tw.base = m->d_base;
         if (!rc) rc = dec_forward(m, Mpad, 16, Mpad / 16, true, 1, 0, &tw);
         m->rm = rm_search;
         WIS_RET(rc);
-        for (int t = 0; t < Rw; ++t) {
-          WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, 1, sc, beam, 1, t * k));
+        hw2[0] = 0; for (int j = 0; j < MAX_R; ++j) hw2[1 + j] = j;
+        WIS_HIP_CHECK(hipMemcpyAsync(m->d_vstate + 2, hw2, 4, hipMemcpyHostToDevice, st));
+        WIS_HIP_CHECK(hipMemcpyAsync(m->d_vstate + DRAFT_VS_BASE, hw2 + 1, MAX_R * 4, hipMemcpyHostToDevice, st));
+        for (int t = 0; t < Rw; ++t) {      // replay: beam j's logits come from the row of the draft node it is matched to (rowmap); no cache traffic per step
+          WIS_RET(launch_logit_stats(st, m->logits, bias_all, m->bias_begin, m->bs.step_u, m->st_max, m->st_sum, m->st_val, m->st_idx, 1, sc, beam, 1, t * k, nullptr, m->d_vstate + DRAFT_VS_PERM));
           WIS_RET(launch_beam_step(st, m->st_max, m->st_sum, m->st_val, m->st_idx, m->bs, m->rm, 1, P, ctx, sc));
-          WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, 1, beam, P, ctx, c.d_model));
-          WIS_RET(launch_draft_check(st, m->bs, m->d_draft, nd, k, m->d_vstate));
+          WIS_RET(launch_draft_match(st, m->bs, m->d_draft, nd, k, m->d_vstate, 1));
         }
+        // the window's paths applied to the cache at once: slot j = live beam j's history, as ordinary steps (and the next window) expect it
+        WIS_RET(launch_kv_gather(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->d_vstate, m->bs.done, beam, P - 1 + s0, ctx, c.d_model));
       }
-      WIS_HIP_CHECK(hipMemcpyAsync(hv, m->d_vstate, 4, hipMemcpyDeviceToHost, st));
-      WIS_HIP_CHECK(hipMemcpyAsync(hv + 1, m->bs.done, 4, hipMemcpyDeviceToHost, st));
-      WIS_HIP_CHECK(hipMemcpyAsync(hv + 2, m->bs.step_u, 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(hv, m->d_vstate, 16 * 4, hipMemcpyDeviceToHost, st));      // steps verified, ..., the matching
+      WIS_HIP_CHECK(hipMemcpyAsync(hv + 24, m->bs.done, 4, hipMemcpyDeviceToHost, st));
+      WIS_HIP_CHECK(hipMemcpyAsync(hv + 25, m->bs.step_u, 4, hipMemcpyDeviceToHost, st));
       WIS_HIP_CHECK(hipStreamSynchronize(st));
-      done_flag = hv[1]; step_dev = hv[2];
+      done_flag = hv[24]; step_dev = hv[25];
       if (Rw < 1 || done_flag != 0) break;
+      for (int j = 0; j < k; ++j) { const int n_ = hv[DRAFT_VS_PERM + j]; if (n_ >= 0 && n_ < k) pinv[n_] = j; }
       s0 += Rw;
     }
     if (accepted) *accepted = hv[0];
