@@ -174,8 +174,9 @@ int wis_generate_draft(wis_model_t* m, const float* input, const int32_t* prompt
  * settings.py:14-18 - BASELINE configs[4]'s 29 s fixture included).  The draft is the TRAJECTORY of an earlier search over (most of) the same
  * audio, as wis_last_trajectory returns it: per step the k live beams it left - draft_tok [n_steps][beam_size] their newest tokens, draft_org
  * [n_steps][beam_size] the live beam (0 .. beam_size-1 of the step before) each continued from.  While the search over the final window
- * follows the draft, 16 steps cost ONE decoder pass: the rows of all 16 x beam_size tree nodes go through the decoder together, the steps
- * are replayed on their logits by the ordinary sampling kernels, and ordinary steps resume behind the first step whose live set differs.
+ * follows the draft, up to 32 steps cost ONE decoder pass: the rows of all steps x beam_size tree nodes (<= 96) go through the decoder together,
+ * the steps are replayed on their logits by the ordinary sampling kernels, and ordinary steps resume behind the first step whose live set
+ * differs from the draft's AS A SET (the slot order of the live beams does not matter: near-tied candidates swap slots between two searches).
  * Every step that counts ran the engine's beam step on the logits of its true inputs: the result is the beam search of the final window,
  * what wis_generate returns for it (up to the summation order of the multi-row passes, as between any two batch shapes).
  * accepted_steps: steps whose live set equalled the draft's (may be NULL).  n_steps == 0 is wis_generate. */

@@ -1207,12 +1207,15 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     // TREE (a beam's history is a path through earlier live sets), so the pass runs the self-attention by ancestor table (dec_self_attn_kernel
     // TREE: node (s, j) keeps its K / V in slot j, row (s, j) reads position P - 1 + s' from the slot of its ancestor at step s') and the
     // cross-attention as groups of 16 rows over the utterance's one K / V.  One weight stream then yields the logits of Rw steps x k beams;
-    // the steps are REPLAYED on them by the ordinary sampling kernels (logit_stats, beam_step, kv_reorder - the search state, the hypothesis
-    // list and the cache end up exactly where Rw ordinary steps would leave them), each followed by draft_check_kernel: if the live set a
-    // replayed step produced is the draft's, the next step's rows were the right ones; the first step that differs still stands (its own
-    // inputs were verified), parks the search (done = 2), and ordinary steps resume behind it.  A whole window is queued without a host
-    // round trip; the host looks once per window.  Exact by construction: every accepted step ran beam_step_kernel on the logits of its
-    // true inputs (summed in the multi-row order, as any other batch shape of the engine).
+    // the steps are REPLAYED on them by the ordinary sampling kernels (logit_stats, beam_step: search state and hypothesis list end up exactly
+    // where Rw ordinary steps would leave them), each followed by draft_match_kernel: if the live set a replayed step produced is the draft's -
+    // as a SET: near-tied candidates swap slots between two searches all the time, so live beam j may be any draft node as long as every beam is
+    // found once; the next step reads beam j's logits from the row of its node - the next step's rows were the right ones; the first step with a
+    // beam the draft does not have still stands (its own inputs were verified), parks the search (done = 2), and ordinary steps resume behind
+    // it.  The cache: the pass left node (s, i)'s K / V in slot i of the draft's numbering; the matching kernel keeps every live beam's path
+    // through those slots and kv_gather_kernel turns the paths into "slot j = beam j's history" once per window.  A whole window is queued
+    // without a host round trip; the host looks once per window.  Exact by construction: every accepted step ran beam_step_kernel on the logits
+    // of its true inputs (summed in the multi-row order, as any other batch shape of the engine).
     const int k = beam;
     const int nd = std::min(n_draft, max_new - 1);
     int* hd = m->h_pin + 8192;                         // the draft in BeamState::traj's layout ([step][MAX_R][2])
