@@ -308,6 +308,9 @@ class StreamingSession:
     def stop(self):
         """End of the recording: the same 6-tuple `do_whisper` returns for the complete audio (infer_time counts only the work
         left at stop time - the windows transcribed while the audio was arriving are already done)."""
+        job = getattr(self, "_spec_job", None)
+        if job is not None and not job.done():
+            job.cancel()          # not started yet: never will be (one that is running finishes beside the final decode; its result is not waited for)
         try:
             return self._transcribe(final=True)
         finally:
