@@ -466,3 +466,63 @@ def test_melstream_incremental_equals_batch_logmel(golden_dir):
     st.reset()
     assert np.array_equal(st.finish(), audio.log_mel_spectrogram(np.zeros(480000, np.float32), device=0).numpy())
     st.close()
+
+
+def test_two_server_processes_behind_one_port_on_the_gpu(golden_dir):
+    """`python -m wis_hip.server --workers-per-node 2` with the REAL engine (tiny, seeded weights): two server processes - both pinned to GPU 0 here, the
+    box has one; a node gives each its own (`HIP_VISIBLE_DEVICES=i`) - share the port (SO_REUSEPORT); requests over real sockets come back with the same
+    transcript whichever process the kernel hands the connection to, and SIGTERM drains the node.  (tests/test_server_cpu.py covers supervision and
+    batching with the fake engine.)"""
+    import json
+    import signal
+    import socket
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s0:
+        s0.bind(("127.0.0.1", 0))
+        port = s0.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "willow-inference-server_amd"), os.environ.get("PYTHONPATH", "")]),
+               WHISPER_MODEL_PATH="synthetic:{size}", FIXED_NEW_TOKENS="12", MAX_BATCH="4", REPLICAS_PER_GPU="1")
+    sup = subprocess.Popen([sys.executable, "-m", "wis_hip.server", "--host", "127.0.0.1", "--port", str(port), "--workers-per-node", "2", "--devices", "0,0",
+                            "--log-level", "warning", "--graceful-timeout", "5"], env=env)
+    clip = open(os.path.join(golden_dir, "clips", "3sec.flac"), "rb").read()
+    b = "wisTestBoundary"
+    body = (f"--{b}\r\nContent-Disposition: form-data; name=\"audio_file\"; filename=\"3sec.flac\"\r\nContent-Type: audio/flac\r\n\r\n").encode() + clip + f"\r\n--{b}--\r\n".encode()
+    req = (f"POST /api/asr?task=transcribe&output=json&model=tiny&beam_size=3&detect_language=False HTTP/1.1\r\nHost: x\r\nContent-Type: multipart/form-data; boundary={b}\r\n"
+           f"Content-Length: {len(body)}\r\nConnection: close\r\n\r\n").encode() + body
+
+    def post():
+        with socket.create_connection(("127.0.0.1", port), timeout=60) as c:
+            c.sendall(req)
+            data = b""
+            while True:
+                chunk = c.recv(65536)
+                if not chunk:
+                    break
+                data += chunk
+        head, _, payload = data.partition(b"\r\n\r\n")
+        assert head.startswith(b"HTTP/1.1 200"), head[:200]
+        return json.loads(payload.decode())
+
+    def ping():
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=1) as c:
+                c.sendall(b"GET /api/ping HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n")
+                return b"200" in c.recv(64)
+        except OSError:
+            return False
+
+    try:
+        t_end = time.time() + 120
+        while time.time() < t_end and not all(ping() for _ in range(6)):
+            time.sleep(0.3)
+        assert ping()
+        texts = [post()["text"] for _ in range(12)]            # 12 connections: both listeners get some (the kernel hashes them)
+        assert len(set(texts)) == 1 and texts[0]
+        print("two server processes, one port, GPU 0: 12 requests, one transcript:", texts[0][:60])
+        sup.send_signal(signal.SIGTERM)
+        assert sup.wait(30) == 0
+    finally:
+        if sup.poll() is None:
+            sup.kill()
