@@ -707,10 +707,36 @@ __global__ __launch_bounds__(256) void gemv_kernel(WIS_GV_LEAD_DECL(l_), int KC,
 // Two skinny GEMMs in ONE launch (workgroups [0, nA) run problem A, the rest problem B; both f16-activation, single-chunk,
 // <= 16 rows): the decoder's attention output projection together with the cross-attention query projection folded THROUGH it
 // (model.hip fused_out_cq): one dependent stage instead of two.
+// (r6, WIS_CA_PREFETCH=1) L2 prefetch riders: the launch leaves 96 of 256 CUs idle, the cross-attention that follows it starts with a 7.7 MB K / V stream
+// from HBM.  Workgroup nA + nB + i of this launch touches exactly what workgroup i of the cross-attention will load (key chunk c = i % chunks of head
+// h = i / chunks: 32 KB of K fragments, 32 KB of V^T rows) and leaves; with the round-robin placement of linear workgroup ids over the 8 XCDs both land on
+// XCD i % 8, i.e. in the L2 the consumer reads through.
+struct DualPf { const f16* k; const f16* v; int T, Tpad, chunks, CL, n; };
 template <int SCA, int SCB>
 __global__ __launch_bounds__(256) void gemv_dual_kernel(int nA, int M, const void* ax, const f16* aWp, const void* bx, const void* bx2, const f16* bWp, int bxsplit,
-                                                        GemvP pa, GemvP pb) {
+                                                        GemvP pa, GemvP pb, DualPf pf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (pf.n && (int)blockIdx.x >= pf.n) {
+    const int i = (int)blockIdx.x - pf.n, c = i % pf.chunks, h = i / pf.chunks, tid = threadIdx.x;
+    const int klo = c * pf.CL;
+    const f16* kb = pf.k + (size_t)h * 8 * pf.T * 8;
+    const f16* vb = pf.v + (size_t)h * 64 * pf.Tpad;
+    u32x4 sink = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {      // K: 8 planes x CL keys x 16 B
+      int key = klo + tid; if (key > pf.T - 1) key = pf.T - 1;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(kb + ((size_t)u * pf.T + key) * 8);
+      sink[0] ^= v[0]; sink[1] ^= v[1]; sink[2] ^= v[2]; sink[3] ^= v[3];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {      // V^T: 64 rows x CL keys x 2 B = 64 x 32 pieces of 16 B
+      const int piece = tid + 256 * u, row = piece >> 5, col = piece & 31;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(vb + (size_t)row * pf.Tpad + klo + 8 * col);
+      sink[0] ^= v[0]; sink[1] ^= v[1]; sink[2] ^= v[2]; sink[3] ^= v[3];
+    }
+    asm volatile("" :: "v"(sink[0]), "v"(sink[1]), "v"(sink[2]), "v"(sink[3]));
+    return;
+  }
   // (K of either problem is the instantiation's: SC k-steps of 32 per wave, four waves)
   if ((int)blockIdx.x < nA) { pa.x = ax; pa.x2 = nullptr; pa.Wp = aWp; pa.M = M; pa.K = SCA * 128; gemv_body<1, 2, SCA, 1, false>(pa, SCA * 128, blockIdx.x, smem); }
   else { pb.x = bx; pb.x2 = bx2; pb.Wp = bWp; pb.M = M; pb.K = SCB * 128; pb.xsplit = bxsplit; gemv_body<1, 2, SCB, 1, false>(pb, SCB * 128, (int)blockIdx.x - nA, smem); }
@@ -729,7 +755,7 @@ static size_t gemv_lds_limit(int dev) {
   }
   return v;
 }
-int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
+int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb, const f16* pf_k, const f16* pf_v, int pf_T, int pf_Tpad, int pf_chunks, int pf_H) {
   if (pa.M != pb.M || pa.M < 1 || pa.M > 16 || pa.x2 || pa.wscale || pb.wscale || (pa.flags & (GV_LN | GV_QKV)) || (pb.flags & (GV_LN | GV_QKV))) { set_error("gemv_dual: unsupported pair"); return WIS_E_UNSUPPORTED; }
   if (pa.M * (pa.K / 8) > 13 * 256 || pb.M * (pb.K / 8) > 13 * 256 || pa.K % 128 || pb.K % 128) { set_error("gemv_dual: rows do not fit the register staging (M=%d K=%d/%d)", pa.M, pa.K, pb.K); return WIS_E_UNSUPPORTED; }
   const int sa = pa.K / 128, sb = pb.K / 128;
@@ -738,13 +764,18 @@ int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb) {
   const size_t lds = (((size_t)pa.M * (Kmax + 8) * 2 + 15) & ~(size_t)15) + aux;
   if (lds > 65536) { set_error("gemv_dual: LDS"); return WIS_E_UNSUPPORTED; }
   const int nA = cdiv(pa.N, 16), nB = cdiv(pb.N, 16);
-  dim3 grid(nA + nB), block(256);
+  DualPf pf; memset(&pf, 0, sizeof(pf));
+  if (pf_k && pf_v && pf_chunks > 0) {
+    const int CL = cdiv(cdiv(pf_T, pf_chunks), 32) * 32, used = cdiv(pf_T, CL);
+    if (CL == 256 && (nA + nB) % 8 == 0) { pf.k = pf_k; pf.v = pf_v; pf.T = pf_T; pf.Tpad = pf_Tpad; pf.chunks = used; pf.CL = CL; pf.n = nA + nB; }
+  }
+  dim3 grid(nA + nB + (pf.n ? pf.chunks * pf_H : 0)), block(256);
   GemvP a = pa, b = pb; a.rows = 16; b.rows = 16;
-  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
-  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
-  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
-  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
-  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b);
+  if (sa == 10 && sb == 20) hipLaunchKernelGGL((gemv_dual_kernel<10, 20>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b, pf);
+  else if (sa == 8 && sb == 16) hipLaunchKernelGGL((gemv_dual_kernel<8, 16>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b, pf);
+  else if (sa == 6 && sb == 12) hipLaunchKernelGGL((gemv_dual_kernel<6, 12>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b, pf);
+  else if (sa == 4 && sb == 8) hipLaunchKernelGGL((gemv_dual_kernel<4, 8>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b, pf);
+  else if (sa == 3 && sb == 6) hipLaunchKernelGGL((gemv_dual_kernel<3, 6>), grid, block, lds, st, nA, a.M, a.x, a.Wp, b.x, b.x2, b.Wp, b.xsplit, a, b, pf);
   else { set_error("gemv_dual: K=%d/%d not instantiated", pa.K, pb.K); return WIS_E_UNSUPPORTED; }
   return WIS_OK;
 }

@@ -88,7 +88,8 @@ struct GemvP {
   unsigned long long* sa_gran; unsigned* sa_epoch; unsigned* sa_flag; f16* sa_out; int sa_rpu, sa_sstride, sa_first;
 };
 int launch_gemv(hipStream_t st, const GemvP& p);
-int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb);     // two f16-activation skinny GEMMs in one launch
+// two f16-activation skinny GEMMs in one launch (+ optionally L2 prefetch riders for the cross-attention that follows: pf_k / pf_v = its K / V^T of utterance 0)
+int launch_gemv_dual(hipStream_t st, const GemvP& pa, const GemvP& pb, const f16* pf_k = nullptr, const f16* pf_v = nullptr, int pf_T = 0, int pf_Tpad = 0, int pf_chunks = 0, int pf_H = 0);
 // Batched decode rows (8 < M <= 96).  The skinny GEMM reads its activations as ready-made MFMA B fragments straight from L2
 // (written in that order by the producing kernel: no per-workgroup LDS staging, no staging barrier, many workgroups per CU), and
 // the pre-LN LayerNorm needs no launch of its own: every residual epilogue leaves per-16-column partial sums of the rows it

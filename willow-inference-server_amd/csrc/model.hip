@@ -838,6 +838,9 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
       if (!stat_rows) ga.stat_out = m->dstat;
       GemvP gb; memset(&gb, 0, sizeof(gb));
       gb.x = m->dxh; gb.x2 = m->dao; gb.xsplit = d; gb.Wp = w.p_cqo; gb.bias = w.b_cqo; gb.y = m->dq; gb.M = M; gb.N = d; gb.K = 2 * d; gb.flags = GV_OUT_F32;
+      static const bool ca_pf = getenv("WIS_CA_PREFETCH") && atoi(getenv("WIS_CA_PREFETCH")) != 0;      // (r6 A/B: L2 prefetch riders for the cross-attention's K / V)
+      if (ca_pf && B == 1) WIS_RET(launch_gemv_dual(st, ga, gb, m->kx[l], m->vx[l], T, m->Tpad, chunks, H));
+      else
       WIS_RET(launch_gemv_dual(st, ga, gb));
       if (!stat_rows) WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->dao, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, 0,
                                                     m->dstat, w.c_cq, w.b_cq, m->spin_now ? m->ca_gran : nullptr, m->ca_epoch, nullptr, 1));
