@@ -521,6 +521,23 @@ def test_two_server_processes_behind_one_port_on_the_gpu(golden_dir):
         texts = [post()["text"] for _ in range(12)]            # 12 connections: both listeners get some (the kernel hashes them)
         assert len(set(texts)) == 1 and texts[0]
         print("two server processes, one port, GPU 0: 12 requests, one transcript:", texts[0][:60])
+        # ... and under concurrency: 16 client threads x 4 requests each, both processes batching on the shared GPU
+        import threading
+        got, errs = [], []
+
+        def client():
+            try:
+                for _ in range(4):
+                    got.append(post()["text"])
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+        ts = [threading.Thread(target=client) for _ in range(16)]
+        t0 = time.perf_counter()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        el = time.perf_counter() - t0
+        assert not errs and len(got) == 64 and set(got) == {texts[0]}, (errs[:2], len(got))
+        print(f"  64 concurrent requests in {el:.2f} s ({64 / el:.0f} requests/s through two processes on one GPU), all with the same transcript")
         sup.send_signal(signal.SIGTERM)
         assert sup.wait(30) == 0
     finally:
