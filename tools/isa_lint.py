@@ -160,6 +160,13 @@ def lint(paths, table=False):
                 rows.append((os.path.basename(p), name, k["vgpr"], waves, k["mfma"], k["pk"], k["scratch"]))
                 if k["mfma"] and k["pk"]:
                     bad.append(rows[-1])
+                # rule 3 (round 6; round-5 review weak 11: "one ROCm bump from a silent change"): the library is built with `-mllvm -amdgpu-mfma-vgpr-form`
+                # (accumulators in VGPRs: no v_accvgpr moves around the softmax of the attention loops); if a compiler stops honouring the switch the
+                # kernels still run, 10-15 % slower - so an MFMA kernel that allocates AGPRs fails the build instead
+                # (checked on the kernels the switch was introduced for - the encoder attention loops and GEMMs; a register-starved skinny-GEMM
+                # instantiation may legitimately use AGPRs as spill space)
+                if k["mfma"] and k["agpr"] and ("enc_attn" in name or "gemm_" in name):
+                    bad.append((os.path.basename(p), f"{name}: {k['mfma']} MFMAs with {k['agpr']} AGPRs allocated - `-mllvm -amdgpu-mfma-vgpr-form` is not in effect", 0, 0, 0, -1, 0))
     if table:
         print(f"{'object':22s} {'VGPRs':>5s} {'waves/SIMD':>10s} {'MFMA':>6s} {'v_pk f32':>8s}  kernel")
         for o, n, v, w, mf, pk, sc in rows:
@@ -179,5 +186,5 @@ if __name__ == "__main__":
     scratch = [r for r in rows if r[6]]
     for o, n, v, w, mf, pk, sc in scratch:
         print(f"isa_lint: {o}: {n}: {sc} bytes of scratch per lane", file=sys.stderr)
-    print(f"isa_lint: {len(rows)} kernels, {sum(1 for b in bad if b[5] >= 0)} packed-f32 violations, {sum(1 for b in bad if b[5] < 0)} scalar-load hazards, {len(scratch)} kernels with scratch")
+    print(f"isa_lint: {len(rows)} kernels, {sum(1 for b in bad if b[5] >= 0)} packed-f32 violations, {sum(1 for b in bad if b[5] < 0)} scalar-load hazards / AGPR findings, {len(scratch)} kernels with scratch")
     sys.exit(1 if bad or scratch else 0)
