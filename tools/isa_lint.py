@@ -3,7 +3,9 @@
     python tools/isa_lint.py [--table] build/*.hip.o
 
 Rule: NO kernel that contains MFMA instructions may contain packed-f32 VALU arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32),
-(rule 2, round 6: no instruction names the destination SGPR of a scalar load before the s_waitcnt that retires it - smem_hazards below),
+(rule 2, round 6: no instruction names the destination SGPR of a scalar load before the s_waitcnt that retires it - smem_hazards below;
+rule 3: no AGPRs in the encoder attention / GEMM kernels = `-amdgpu-mfma-vgpr-form` in effect; rule 4: the decoder kernels' descriptors preload kernel
+arguments = `-amdgpu-kernarg-preload-count` in effect),
 whatever its occupancy (the failures were seen at three waves per SIMD, <= 168 unified VGPRs; the table prints the register bound
 so a reader can see which kernels could get there), and no kernel may use scratch.  Round 3/4 finding ("The two-tile
 kernel's corruption"): the two-n-tile skinny GEMM's 168-VGPR instantiation returned wrong LOW halves of v_pk_*_f32 results in
@@ -146,6 +148,31 @@ def smem_hazards_text(dis):
     return out
 
 
+PRELOAD_KERNELS = ("gemv_kernel", "gemv_dual_kernel", "gemv_frag_kernel", "gemv_frag2_kernel", "dec_self_attn_kernel", "dec_cross_attn_kernel")
+
+
+def kernarg_preload(co):
+    """-> {kernel: dwords of kernel arguments the command processor preloads into SGPRs} from the kernel descriptors (`<kernel>.kd`, 64 bytes in .rodata:
+    bits 0-6 of the 16-bit field at offset 58).  Rule 4 (round 6): the library is built with `-mllvm -amdgpu-kernarg-preload-count=16` and the decoder
+    kernels list their early operands as leading scalars so that the switch takes effect (decode step -4.2 %); a compiler that drops
+    the switch would leave them correct and slower - so a decoder kernel with a preload length of 0 fails the build."""
+    syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "-W", co], capture_output=True, text=True, check=True).stdout
+    secs = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-S", "-W", co], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"\.rodata\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", secs)
+    if not m:
+        return {}
+    addr, off, size = (int(x, 16) for x in m.groups())
+    blob = open(co, "rb").read()[off:off + size]
+    out = {}
+    for ln in syms.split("\n"):
+        f = ln.split()
+        if len(f) >= 8 and f[-1].endswith(".kd") and f[3] == "OBJECT":
+            a = int(f[1], 16) - addr
+            if 0 <= a and a + 64 <= len(blob):
+                out[f[-1][:-3]] = int.from_bytes(blob[a + 58:a + 60], "little") & 0x7F
+    return out
+
+
 def lint(paths, table=False):
     bad, rows = [], []
     with tempfile.TemporaryDirectory() as tmp:
@@ -155,6 +182,9 @@ def lint(paths, table=False):
                 continue
             for kn, ld, use in smem_hazards(co):
                 bad.append((os.path.basename(p), f"{kn}: `{use}` names an SGPR of the scalar load `{ld}` before the wait that retires it", 0, 0, 0, -1, 0))
+            for kn, n_pre in sorted(kernarg_preload(co).items()):
+                if n_pre == 0 and any(f"wis{len(t)}{t}" in kn or f"wis::{t}" in kn for t in PRELOAD_KERNELS):
+                    bad.append((os.path.basename(p), f"{kn}: no kernel argument is preloaded - `-mllvm -amdgpu-kernarg-preload-count` is not in effect (or the kernel's signature no longer leads with scalars)", 0, 0, 0, -1, 0))
             for name, k in sorted(kernels(co).items()):
                 waves = min(8, 512 // (((k["vgpr"] + 7) // 8) * 8)) if k["vgpr"] else 8
                 rows.append((os.path.basename(p), name, k["vgpr"], waves, k["mfma"], k["pk"], k["scratch"]))
