@@ -1110,12 +1110,18 @@ __global__ __launch_bounds__(256) void gemv_frag_kernel(const void* l_x, const f
 // one half reads the layer input's fragment image, the other the attention output's; the cross-attention kernel adds the halves and
 // applies the LayerNorm statistics of the rows the out-projection produces in this same launch).
 struct GemvP3 { GemvP p[3]; int n0, n1; };
+// (r6: what a workgroup's first requests need - which problem it is, that problem's activation and weight bases, the common shape and the k-step window -
+// leads the argument list as 14 dwords of scalars, so the command processor preloads it into SGPRs (build.py: -amdgpu-kernarg-preload-count); the by-value
+// struct alone had a preload length of 0: every workgroup began with a kernarg fetch)
 template <int MB, int PF>
-__global__ __launch_bounds__(256) void gemv_frag3_kernel(GemvP3 ps) {
+__global__ __launch_bounds__(256) void gemv_frag3_kernel(int n0, int n1, const void* x0, const void* x1, const void* x2, const f16* w0, const f16* w1, const f16* w2, GemvP3 ps) {
   const int b = blockIdx.x;
-  const int sel = b < ps.n0 ? 0 : (b < ps.n0 + ps.n1 ? 1 : 2);
-  const int nt = sel == 0 ? b : (sel == 1 ? b - ps.n0 : b - ps.n0 - ps.n1);
-  gemv_frag_body<MB, PF, false>(ps.p[sel], nt, 1, 0);
+  const int sel = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);
+  const int nt = sel == 0 ? b : (sel == 1 ? b - n0 : b - n0 - n1);
+  GemvP p = ps.p[sel];
+  p.x = sel == 0 ? x0 : (sel == 1 ? x1 : x2);
+  p.Wp = sel == 0 ? w0 : (sel == 1 ? w1 : w2);
+  gemv_frag_body<MB, PF, false>(p, nt, 1, 0);
 }
 
 // The same skinny GEMM with TWO n-tiles (32 output columns) per workgroup, for the LayerNorm-folded projections that have more
@@ -1275,7 +1281,8 @@ int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n) {
   ps.n0 = nts[0]; ps.n1 = nts[1];
   dim3 grid(nts[0] + nts[1] + nts[2]), block(256);
   const bool s10 = p[0].K == 1280;
-#define WIS_GF3(MBv, PFA, PFB) do { if (s10) hipLaunchKernelGGL((gemv_frag3_kernel<MBv, PFA>), grid, block, 0, st, ps); else hipLaunchKernelGGL((gemv_frag3_kernel<MBv, PFB>), grid, block, 0, st, ps); } while (0)
+#define WIS_GF3_ARGS ps.n0, ps.n1, ps.p[0].x, ps.p[1].x, ps.p[2].x, ps.p[0].Wp, ps.p[1].Wp, ps.p[2].Wp, ps
+#define WIS_GF3(MBv, PFA, PFB) do { if (s10) hipLaunchKernelGGL((gemv_frag3_kernel<MBv, PFA>), grid, block, 0, st, WIS_GF3_ARGS); else hipLaunchKernelGGL((gemv_frag3_kernel<MBv, PFB>), grid, block, 0, st, WIS_GF3_ARGS); } while (0)
   switch (p[0].xmb) {
     case 1: WIS_GF3(1, 10, 8); break;
     case 2: WIS_GF3(2, 10, 8); break;
@@ -1286,6 +1293,7 @@ int launch_gemv_frag3(hipStream_t st, const GemvP* p, int n) {
     default: set_error("gemv_frag3: %d row blocks unsupported", p[0].xmb); return WIS_E_UNSUPPORTED;
   }
 #undef WIS_GF3
+#undef WIS_GF3_ARGS
   return WIS_OK;
 }
 
