@@ -259,7 +259,7 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
         r8 = model_r.generate(batch, [prompts2[i] for i in order8], beam_size=5)
         from wis_hip import weights as W2
         from test_gpu_eot import oracle_rescore, MARGIN as EOT_MARGIN
-        want, exact = {}, 0
+        want, exact, flipped = {}, 0, set()
         for pi, prompt in enumerate(prompts2):
             ids, score, trace = ref_r.generate(None, prompt, beam_size=5, suppress_ids=W2.SUPPRESS_IDS, suppress_begin=W2.SUPPRESS_IDS_BEGIN, memory=memory, return_trace=True)
             want[pi] = (ids, score, min(trace), ref_r.last_search)
@@ -274,6 +274,8 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
             if margin > EOT_MARGIN:
                 assert got == ids
             exact += got == ids
+            if got != ids:
+                flipped.add(pi)
         # ---- natural termination through the DRAFT-VERIFIED decodes at this size (beam 1 and the reference's long-audio beam 3): the search ends on
         # EOT inside or behind the verified steps; against the oracle under the margin rule
         for bm in (1, 3):
@@ -296,7 +298,10 @@ def test_fullsize_vs_oracle(size, beam, clip, S, golden_dir, lib):
                     assert got == ids_o
         finish = {pi: want[pi][3]["finish_step"] for pi in want}
         print(f"large, natural EOT: {exact} of 9 identical to the oracle; finish steps of the four prompts {finish}; engine ran {model_r.last_timing()['decode_steps']} steps")
-        assert len(set(finish.values())) >= 3 and max(finish.values()) < 60 and exact >= 7          # utterances of ONE device batch end at >= 3 different steps
+        # utterances of ONE device batch end at >= 3 different steps.  The nine results are four prompts (prompt 0 three times), every one of them inside
+        # the margin rule's band (decision margins 0.0002 - 0.004 on these weights): at most ONE prompt may come out as the oracle's runner-up (round 6: prompt 0,
+        # margin 0.0002, does since the cross-attention adds its row sums in another order; its rescored score is 0.0002 below the oracle's best)
+        assert len(set(finish.values())) >= 3 and max(finish.values()) < 60 and len(flipped) <= 1, (exact, flipped)
         assert any(len({len(h[1]) for h in want[pi][3]["hyps"]}) > 1 for pi in want)          # hypotheses of unequal length were ranked
         assert r8[0].sequences_ids == r8[5].sequences_ids and r8[1].sequences_ids == r8[4].sequences_ids       # same prompt, same answer, whatever the slot
         model_r.close()

@@ -1654,7 +1654,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   // against utterance 0's K / V); queries, outputs, partials and tickets stay per group
   const int Tpad = TpadF & 0x3FFFFFFF, bkv = (TpadF >> 30) ? 0 : b;
   const int klo = c * CL, n = (klo + CL <= T) ? CL : T - klo;   // 1 <= n <= 256, klo % 32 == 0
-  unsigned long long* pf = (c == 0 && h == 0 && b == 0 && tid == 0) ? prof : nullptr;
+  // (tap builds: workgroup (0, 0, 0) stamps entries 0-5 of its row, the LAST chunk's workgroup - the combiner of the granule form - entries 7-13)
+  unsigned long long* pf = (h == 0 && b == 0 && tid == 0 && prof) ? (c == 0 ? prof : (c == C - 1 ? prof + 7 : nullptr)) : nullptr;
   if (tid == 0) tl_begin(prof);
   stamp(pf, 0);
 
@@ -1948,7 +1949,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
       *reinterpret_cast<f16x2*>(out + (out_mb ? xf_index(b * R + r, h * 64 + 2 * dp, out_mb) : (size_t)(b * R + r) * d + h * 64 + 2 * dp)) = o2;
     }
     if (tid == 0) __hip_atomic_store(epoch + 1 + b * H + h, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // next launch's epoch
-    stamp(pf, 7);
+    stamp(pf, 6);
     if (tid == 0) tl_end(prof);
     return;
   }
@@ -2012,6 +2013,367 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
   if (tid == 0) tl_end(prof);
 }
 
+// =======================================================================================
+// Cross-attention of the batched step with ROLES (round 6; the folded query from row partials, 256-key chunks, <= 8 rows, d <= 1280).
+// What the phase stamps of dec_cross_attn_kernel<4, 6, 4> showed at 8 utterances (profiles/r06_phase_cycles.md): a wave spends half of its
+// life getting its 17 requests ACCEPTED (960 workgroups ask for 61 MB at once; the CU's address path takes them at the rate HBM
+// answers), and scores, softmax and P.V - 6 us - start only behind that: a wave that is waiting for the memory pipeline to take its V
+// requests cannot multiply the K fragments that have landed.  Here the waves of a workgroup have roles:
+//   waves 0-1 (K waves)  request the query's operands, the row partials and the K fragments of THEIR 128 keys, finish the folded query,
+//                        take scores, maximum, exponentials and row sums of their half chunk in registers (the MFMA output layout keeps a
+//                        query row in a lane column: two cross-row shuffles, no score buffer), exchange the two row maxima through LDS flag
+//                        words (K wave with K wave: no workgroup barrier) and leave P (f16) + (max, sum) in LDS behind a flag word;
+//   waves 2-3 (V waves)  request V^T (32 head dimensions each) once the K waves' requests are in (one raw barrier), so K leads V through
+//                        the memory pipeline, then accumulate O = V P half chunk by half chunk as the flags come up and publish the chunk
+//                        partial as before (two granules per 16-byte store).
+// The K waves never wait for a V wave (no workgroup barrier between the first one and the tail), so scores and softmax run while V is
+// still streaming in.  Arithmetic: P and O are dec_cross_attn_kernel's bit for bit (exponentials about the chunk's maximum, P.V steps in key
+// order); the row sum is added in another order (last-bit differences); partial format, combine and its order are the same.
+// NT: K / V fragments by non-temporal loads - small grids only (every fragment is read once by one workgroup; measured -0.4 % of the one-utterance
+// step, +1.6 % of the step at 8 utterances: session r6D)
+#define WIS_CA_LD(p) (NT ? __builtin_nontemporal_load(p) : *(p))
+// two granules in one 16-byte write-through store (the lane's neighbouring values): each half is a naturally aligned 8-byte unit of one 16-byte
+// aligned store of one lane, which the memory pipeline carries in one piece (the reader still takes 8-byte granules); a quarter of the write
+// transactions of the one-granule form
+__device__ __forceinline__ void st_gran2(gran_t* p, unsigned tag, float v0, float v1) {
+  const u32x4 g = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
+}
+// NKW = K waves = V waves per workgroup: 2 (256 threads, four workgroups per CU: the batched step's 960 workgroups in one round) or 4 (512 threads: the
+// one-utterance step's 120 workgroups have a CU each - twice the waves put the workgroup's 160 requests into the CU's address path in half the time, and
+// every K wave has half the scores and exponentials to take: its path - requests, query, scores, softmax - is the critical one there)
+// all-reduce over the four 16-lane rows of a lane column (lanes l, l + 16, l + 32, l + 48) with gfx950's row-swap moves: v_permlane32_swap exchanges the upper
+// half of its first operand with the lower half of its second (both = v: one register then holds the lower half's values twice, the other the upper half's),
+// v_permlane16_swap the odd rows of the first with the even rows of the second - two VALU moves instead of two ds_bpermute round trips through the LDS pipe
+__device__ __forceinline__ float xrow_max(float v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xrow_sum(float v) {      // (both lanes of a pair add the same two operands in the same order: every lane of the column holds the same bits)
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <bool SPIN, bool NT, int NKW>
+__global__ __launch_bounds__(128 * NKW) void dec_cross_attn_rs_kernel(const float* __restrict__ q, const f16* __restrict__ kx, const f16* __restrict__ vt,
+                                                                const float* __restrict__ xres, const float* __restrict__ q2, unsigned* epoch, int RHCC, int dT,
+                                                                int TpadF, f16* __restrict__ out, float* part, unsigned* counters,
+                                                                unsigned long long* prof, int out_mb,
+                                                                const float* __restrict__ qcs, const float* __restrict__ qb, gran_t* gran) {
+  constexpr int CM = 6, SQP = 68, NPT = 10, KT = 16 / NKW, KEYS = 256 / NKW, NB = 4 / NKW, VS = 8 / NKW, NTHR = 128 * NKW;      // key tiles / keys per K wave, 16-dh blocks / 32-key steps per flag per V wave
+  // (CM: <= 6 chunks; SQP: staged operand pitch; NPT: row partials per lane, 8 lanes per row, d <= 1280)
+  const int R = RHCC & 0xFF, H = (RHCC >> 8) & 0x3F, C = (RHCC >> 24) & 0xFF, d = dT & 0xFFFF, T = (dT >> 16) & 0xFFFF;
+  __shared__ __attribute__((aligned(16))) f16 sp16[16 * CA_PSTR];
+  __shared__ __attribute__((aligned(16))) float sq[NKW][10 * SQP];      // per K wave: rows 0..7 q_raw (both halves added), 8 column sums, 9 bias
+  __shared__ float srow[NKW][8][2];
+  __shared__ float sml[NKW][16][2];                                    // (chunk max, sum) of the K waves' parts
+  __shared__ float own[16][66];                                        // the combiner's own partial
+  __shared__ float smaxw[NKW][16];                                       // the K waves' row maxima (exchanged behind flagm)
+  __shared__ int flag[NKW], flagm[NKW];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int Tpad = TpadF & 0x3FFFFFFF, bkv = (TpadF >> 30) ? 0 : b;
+  const int klo = c * 256, n = (klo + 256 <= T) ? 256 : T - klo;
+  const bool kwave = wave < NKW; const int kw = wave & (NKW - 1);
+  const int rq = l15 < R ? l15 : R - 1;
+  // (tap builds: workgroup (0, 0, 0): its first K wave stamps entries 0-5 of the row, its first V wave entries 7-13)
+  unsigned long long* pf = (c == 0 && h == 0 && b == 0 && lane == 0 && prof) ? (wave == 0 ? prof : (wave == NKW ? prof + 7 : nullptr)) : nullptr;
+  if (tid == 0) tl_begin(prof);
+  stamp(pf, 0);
+  unsigned ep_now = 0;
+  if (SPIN) ep_now = __hip_atomic_load(epoch + 1 + b * H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float o_[NB][4]; float Mc = 0.f, Lc = 0.f;      // V waves: the chunk's partial (NB 16-dh blocks of lane column r = l15)
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) o_[i][r4] = 0.f;
+
+  if (kwave) {
+    // ---- requests: the query's operands (one 16-byte piece per lane and array), the row partials (lane = (row, eighth)), the K fragments
+    float4 stq[2], stq2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sr0 = (lane >> 4) + 4 * u, sr = sr0 < R ? sr0 : R - 1;
+      const size_t so = (size_t)(b * R + sr) * d + h * 64 + 4 * (lane & 15);
+      stq[u] = *reinterpret_cast<const float4*>(q + so);
+      stq2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q2) stq2[u] = *reinterpret_cast<const float4*>(q2 + so);      // (uniform)
+    }
+    const float4 stc = *reinterpret_cast<const float4*>(((lane & 16) ? qb : qcs) + h * 64 + 4 * (lane & 15));
+    const int ntile = d >> 4, l8 = lane & 7, prow = (lane >> 3) < R ? (lane >> 3) : R - 1;
+    const float2* sp = reinterpret_cast<const float2*>(xres) + (size_t)(b * R + prow) * ntile;
+    float2 pt[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) { const int t = l8 + 8 * i; pt[i] = sp[t < ntile ? t : ntile - 1]; }
+    const f16* kb = kx + (size_t)(bkv * H + h) * 8 * T * 8;
+    u32x4 kf[KT][2];
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      int key = klo + KEYS * kw + 16 * i + l15; if (key > T - 1) key = T - 1;      // clamped; masked below
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[i][ks] = WIS_CA_LD(reinterpret_cast<const u32x4*>(kb + ((size_t)(kq + 4 * ks) * T + key) * 8));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");      // the K requests are in: the V waves may ask for theirs (raw: no wait for any load)
+    __builtin_amdgcn_sched_barrier(0);           // (and nothing that waits for a load moves above it: hipcc had hoisted the first statistics' wait)
+    stamp(pf, 1);
+    // ---- LayerNorm statistics of the R rows (Chan merge of the per-16-column (sum, M2) pairs about the first tile's mean), in every K wave
+    const float c0 = __shfl(pt[0].x, lane & ~7) * 0.0625f;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const bool in = l8 + 8 * i < ntile;
+      const float dm = in ? pt[i].x * 0.0625f - c0 : 0.f;
+      a1 += dm; a2 += in ? pt[i].y + 16.0f * dm * dm : 0.f;
+    }
+    a1 += dpp_f<0xB1>(a1); a2 += dpp_f<0xB1>(a2);
+    a1 += dpp_f<0x4E>(a1); a2 += dpp_f<0x4E>(a2);
+    a1 += dpp_f<0x141>(a1); a2 += dpp_f<0x141>(a2);      // the 8 lanes of a row hold its sums
+    float* sqw = sq[kw];
+    if (l8 == 0) {
+      const float invd = 1.0f / (float)d, dmu = a1 * 16.0f * invd;
+      srow[kw][lane >> 3][0] = c0 + dmu; srow[kw][lane >> 3][1] = 1.0f / sqrtf(fmaxf(a2 * invd - dmu * dmu, 0.f) + 1e-5f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      *reinterpret_cast<float4*>(&sqw[((lane >> 4) + 4 * u) * SQP + 4 * (lane & 15)]) = make_float4(stq[u].x + stq2[u].x, stq[u].y + stq2[u].y, stq[u].z + stq2[u].z, stq[u].w + stq2[u].w);
+    if (lane < 32) *reinterpret_cast<float4*>(&sqw[(8 + (lane >> 4)) * SQP + 4 * (lane & 15)]) = stc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private staging: the wave's own LDS writes have landed
+    const float mu = srow[kw][rq][0], rs = srow[kw][rq][1];
+    const float* sqr = &sqw[rq * SQP + 8 * kq]; const float* scs = &sqw[8 * SQP + 8 * kq]; const float* sbq = &sqw[9 * SQP + 8 * kq];
+    f16x8 qf0, qf1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qf0[e] = (f16)(rs * (sqr[e] - mu * scs[e]) + sbq[e]);
+      qf1[e] = (f16)(rs * (sqr[32 + e] - mu * scs[32 + e]) + sbq[32 + e]);
+    }
+    stamp(pf, 2);
+    // ---- scores of this wave's KEYS keys: D[key][r], lane holds r = l15 and keys 16 i + 4 kq + reg; maximum and sums across the four lane rows
+    f32x4 acc[KT];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&kf[i][0]), qf0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&kf[i][1]), qf1, a, 0, 0, 0);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int kl = KEYS * kw + 16 * i + 4 * kq + r4;
+        a[r4] = (kl < n) ? a[r4] : -INFINITY;
+        lmax = fmaxf(lmax, a[r4]);
+      }
+      acc[i] = a;
+    }
+    stamp(pf, 3);
+    lmax = xrow_max(lmax);
+    // the chunk's maximum = the larger of the two K waves' (the exponentials are taken about the CHUNK's maximum, as dec_cross_attn_kernel takes them:
+    // P and O come out bit for bit as there, only the row sum is added in another order): the one exchange between the two K waves, through LDS
+    // behind a flag word each - no workgroup barrier, the V waves are not involved
+    if (kq == 0) smaxw[kw][l15] = lmax;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&flagm[kw], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int w = 0; w < NKW; ++w)
+      while (__hip_atomic_load(&flagm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float mref = smaxw[0][l15];                               // finite: the chunk holds a key
+#pragma unroll
+    for (int w = 1; w < NKW; ++w) mref = fmaxf(mref, smaxw[w][l15]);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      f16x4 ph;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) { const float e = __expf(acc[i][r4] - mref); lsum += e; ph[r4] = (f16)e; }
+      *reinterpret_cast<f16x4*>(&sp16[l15 * CA_PSTR + KEYS * kw + 16 * i + 4 * kq]) = ph;
+    }
+    lsum = xrow_sum(lsum);
+    if (kq == 0) { sml[kw][l15][0] = mref; sml[kw][l15][1] = lsum; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&flag[kw], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    stamp(pf, 4);
+  } else {
+    if (lane < 2 * NKW && wave == NKW) __hip_atomic_store(lane < NKW ? &flag[lane] : &flagm[lane - NKW], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(pf, 0);
+    // ---- V^T fragments of this wave's 16 NB head dimensions, in key order (the first K wave's keys first)
+    const f16* vb = vt + ((size_t)(bkv * H + h) * 64 + 16 * NB * kw + l15) * Tpad + klo + 8 * kq;
+    u32x4 vf[NB][8];
+#pragma unroll
+    for (int j = 0; j < NKW; ++j)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int s4 = 0; s4 < VS; ++s4) vf[blk][VS * j + s4] = WIS_CA_LD(reinterpret_cast<const u32x4*>(vb + (size_t)blk * 16 * Tpad + 32 * (VS * j + s4)));
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(pf, 1);
+    f32x4 oacc[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) oacc[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NKW; ++j) {      // the 32-key steps in key order, as dec_cross_attn_kernel accumulates them; K wave j's keys as soon as its P is there
+      while (__hip_atomic_load(&flag[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int s4 = 0; s4 < VS; ++s4) {
+        const f16x8 pb = *reinterpret_cast<const f16x8*>(&sp16[rq * CA_PSTR + 32 * (VS * j + s4) + 8 * kq]);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) oacc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&vf[blk][VS * j + s4]), pb, oacc[blk], 0, 0, 0);
+      }
+      if (j == 0 || j == NKW - 1) stamp(pf, j == 0 ? 2 : 3);
+    }
+    Mc = sml[0][rq][0];
+    if (NKW == 2) Lc = sml[0][rq][1] + sml[1][rq][1];
+    else Lc = (sml[0][rq][1] + sml[1][rq][1]) + (sml[2 % NKW][rq][1] + sml[3 % NKW][rq][1]);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) o_[blk][r4] = oacc[blk][r4];
+    stamp(pf, 4);
+  }
+
+  // ---- the chunk's partial: (O[64], M, L) per row, published / combined as in dec_cross_attn_kernel (V wave kw owns dh 16 NB kw .. 16 NB (kw + 1) - 1)
+  const int dhb = 16 * NB * kw + 4 * kq;      // + 16 blk
+  const bool pub = !kwave && l15 < R;
+  if (C == 1) {
+    if (pub) {
+      const float inv = 1.0f / Lc;
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        const f16x4 o = {(f16)(o_[blk][0] * inv), (f16)(o_[blk][1] * inv), (f16)(o_[blk][2] * inv), (f16)(o_[blk][3] * inv)};
+        *reinterpret_cast<f16x4*>(out + (out_mb ? xf_index(b * R + l15, h * 64 + dhb + 16 * blk, out_mb) : (size_t)(b * R + l15) * d + h * 64 + dhb + 16 * blk)) = o;
+      }
+    }
+    return;
+  }
+  if (SPIN) {
+    const unsigned tag = ep_now + 1u;
+    gran_t* gbase = gran + (size_t)(b * H + h) * 6 * 8 * 66;
+    if (c != C - 1) {
+      if (pub) {
+        gran_t* gp = gbase + ((size_t)c * 8 + l15) * 66;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) { st_gran2(gp + dhb + 16 * blk, tag, o_[blk][0], o_[blk][1]); st_gran2(gp + dhb + 16 * blk + 2, tag, o_[blk][2], o_[blk][3]); }
+        if (wave == NKW && kq == 0) st_gran2(gp + 64, tag, Mc, Lc);
+      }
+      stamp(pf, 5);
+      if (tid == 0) tl_end(prof);
+      return;
+    }
+    if (pub) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) own[l15][dhb + 16 * blk + r4] = o_[blk][r4];
+      if (wave == NKW && kq == 0) { own[l15][64] = Mc; own[l15][65] = Lc; }
+    }
+    __syncthreads();
+    stamp(pf, 5);
+    for (int item = tid; item < R * 32; item += NTHR) {
+      const int r = item >> 5, dp = item & 31;
+      float2 ml[CM], ov[CM];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int cc = 0; cc < CM - 1; ++cc) {
+          if (cc < C - 1) {
+            const gran_t* gp = gbase + ((size_t)cc * 8 + r) * 66;
+            const gran_t g0 = ld_gran(gp + 64), g1 = ld_gran(gp + 65), g2 = ld_gran(gp + 2 * dp), g3 = ld_gran(gp + 2 * dp + 1);
+            ok = ok & ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag) & ((unsigned)(g2 >> 32) == tag) & ((unsigned)(g3 >> 32) == tag);
+            ml[cc] = make_float2(__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1));
+            ov[cc] = make_float2(__uint_as_float((unsigned)g2), __uint_as_float((unsigned)g3));
+          }
+        }
+        if (ok) break;
+        if (++spins > CA_SPIN_LIMIT) { atomicOr(epoch, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      float M_ = own[r][64];
+#pragma unroll
+      for (int cc = 0; cc < CM - 1; ++cc) if (cc < C - 1) M_ = fmaxf(M_, ml[cc].x);
+      float L = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < CM - 1; ++cc) {
+        if (cc < C - 1) {
+          const float w = __expf(ml[cc].x - M_);
+          L = fmaf(ml[cc].y, w, L); O0 = fmaf(ov[cc].x, w, O0); O1 = fmaf(ov[cc].y, w, O1);
+        }
+      }
+      {
+        const float w = __expf(own[r][64] - M_);
+        L = fmaf(own[r][65], w, L); O0 = fmaf(own[r][2 * dp], w, O0); O1 = fmaf(own[r][2 * dp + 1], w, O1);
+      }
+      const float inv = 1.0f / L;
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      const f16x2 o2 = {(f16)(O0 * inv), (f16)(O1 * inv)};
+      *reinterpret_cast<f16x2*>(out + (out_mb ? xf_index(b * R + r, h * 64 + 2 * dp, out_mb) : (size_t)(b * R + r) * d + h * 64 + 2 * dp)) = o2;
+    }
+    if (tid == 0) __hip_atomic_store(epoch + 1 + b * H + h, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp(pf, 6);
+    if (tid == 0) tl_end(prof);
+    return;
+  }
+  // ---- ticket form (large grids)
+  float* pbase = part + ((size_t)(b * H + h) * C) * R * 66;
+  if (pub) {
+    float* pp = pbase + ((size_t)c * R + l15) * 66;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) st_sc1(pp + dhb + 16 * blk + r4, o_[blk][r4]);
+    if (wave == NKW && kq == 0) { st_sc1(pp + 64, Mc); st_sc1(pp + 65, Lc); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  stamp(pf, 5);
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counters + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (prev == (unsigned)(C - 1));
+    if (last) {
+      __hip_atomic_store(counters + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (tid == 0) tl_end(prof);
+  if (!s_last) return;
+  for (int item = tid; item < R * 32; item += NTHR) {
+    const int r = item >> 5, dp = item & 31;
+    float2 ml[CM], ov[CM];
+#pragma unroll
+    for (int cc = 0; cc < CM; ++cc) {
+      if (cc < C) {
+        const float* pp = pbase + ((size_t)cc * R + r) * 66;
+        ml[cc] = *reinterpret_cast<const float2*>(pp + 64);
+        ov[cc] = *reinterpret_cast<const float2*>(pp + 2 * dp);
+      }
+    }
+    float M_ = -INFINITY;
+#pragma unroll
+    for (int cc = 0; cc < CM; ++cc) if (cc < C) M_ = fmaxf(M_, ml[cc].x);
+    float L = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CM; ++cc) {
+      if (cc < C) {
+        const float w = __expf(ml[cc].x - M_);
+        L = fmaf(ml[cc].y, w, L); O0 = fmaf(ov[cc].x, w, O0); O1 = fmaf(ov[cc].y, w, O1);
+      }
+    }
+    const float inv = 1.0f / L;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 o2 = {(f16)(O0 * inv), (f16)(O1 * inv)};
+    *reinterpret_cast<f16x2*>(out + (out_mb ? xf_index(b * R + r, h * 64 + 2 * dp, out_mb) : (size_t)(b * R + r) * d + h * 64 + 2 * dp)) = o2;
+  }
+  stamp(pf, 6);
+}
+
 int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f16* vt, f16* out, float* part, unsigned* counters,
                           int B, int R, int H, int d, int T, int Tpad, int chunks, unsigned long long* prof, int out_mb,
                           const float* xres, const float* qcs, const float* qb, unsigned long long* gran, unsigned* epoch, const float* q2, int xres_is_stat, int kv_shared) {
@@ -2025,10 +2387,23 @@ int launch_dec_cross_attn(hipStream_t st, const float* q, const f16* kx, const f
   static const int env_spin = getenv("WIS_CA_SPIN") ? atoi(getenv("WIS_CA_SPIN")) : 1;      // 0: always the ticket form (A/B switch)
   // granule hand-off: small grids only (fewer spinning combiners than CUs), the default 256-key chunking, <= 8 rows per utterance
   const bool spin = env_spin && gran && epoch && B * H <= CA_SPIN_MAX_BH && CL == 256 && used >= 2 && used <= 6 && R <= 8;
-#define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), 0, st, q, kx, vt, xres, q2, epoch, \
+  static const int lds_pad = getenv("WIS_CA_LDS_PAD") ? atoi(getenv("WIS_CA_LDS_PAD")) : 0;      // experiment: dynamic LDS nobody uses = fewer workgroups per CU
+  const int shm = (long)B * H * used > 512 ? lds_pad : 0;
+#define WIS_CA(TPWv, CMv, FOLDv, SPINv) hipLaunchKernelGGL((dec_cross_attn_kernel<TPWv, CMv, FOLDv, SPINv>), dim3(used, H, B), dim3(256), shm, st, q, kx, vt, xres, q2, epoch, \
                                                   (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), (Tpad | (kv_shared ? (1 << 30) : 0)), out, part, counters, prof, out_mb, qcs, qb, gran)
   if (xres_is_stat) {
     const bool small = (long)B * H * used <= 256;      // at most one workgroup per CU: V is requested up front (FOLD 3)
+    // the role-split kernel (K waves / V waves): WIS_CA_RS=0 off (A/B switch), 1 the batched step's grids only, 2 (default) the one-utterance step's too
+    static const int ca_rs = getenv("WIS_CA_RS") ? atoi(getenv("WIS_CA_RS")) : 2;
+    if (ca_rs && (!small || ca_rs >= 2) && CL == 256 && used <= 6 && R <= 8 && d <= 1280) {
+#define WIS_CA_RS(SPINv, NTv, NKWv) hipLaunchKernelGGL((dec_cross_attn_rs_kernel<SPINv, NTv, NKWv>), dim3(used, H, B), dim3(128 * NKWv), 0, st, q, kx, vt, xres, q2, epoch, \
+                                                        (R | (H << 8) | (CL << 14) | (used << 24)), (d | (T << 16)), (Tpad | (kv_shared ? (1 << 30) : 0)), out, part, counters, prof, out_mb, qcs, qb, gran)
+      static const bool rs8 = getenv("WIS_CA_RS8") && atoi(getenv("WIS_CA_RS8")) != 0;      // small grids with 4 + 4 waves per workgroup: measured 0.8 % SLOWER per step than 2 + 2 (session r6G); A/B switch, off
+      if (spin) { if (small && rs8) WIS_CA_RS(true, true, 4); else if (small) WIS_CA_RS(true, true, 2); else WIS_CA_RS(true, false, 2); }
+      else { if (small && rs8) WIS_CA_RS(false, true, 4); else if (small) WIS_CA_RS(false, true, 2); else WIS_CA_RS(false, false, 2); }
+#undef WIS_CA_RS
+      return WIS_OK;
+    }
     // FOLD 4 (large grids, <= 8 rows): the folded query's operands through LDS, V requested up front (WIS_CA_FOLD4=0: FOLD 2, V behind the prologue)
     static const bool fold4 = !(getenv("WIS_CA_FOLD4") && atoi(getenv("WIS_CA_FOLD4")) == 0);
     const bool f4 = fold4 && !small && R <= 8;

@@ -748,7 +748,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
       g3[2] = base(m->daoxf, w.p_cqo, nullptr, nullptr, d, d, GV_OUT_F32);
       g3[2].y = m->dq2; g3[2].wks = 2 * d / 32; g3[2].wk0 = d / 32;
       WIS_RET(launch_gemv_frag3(st, g3, 3));
-      WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, nullptr, MB, m->dstat, w.c_cq, w.b_cq,
+      WIS_RET(launch_dec_cross_attn(st, m->dq, m->kx[l], m->vx[l], m->daoxf, m->part, m->counters, B, R, H, d, T, m->Tpad, chunks, pr ? pr + 64 : nullptr, MB, m->dstat, w.c_cq, w.b_cq,
                                     m->spin_now ? m->ca_gran : nullptr, m->ca_epoch, m->dq2, 1));
     } else {
     g = base(m->daoxf, w.p_out, w.s_out, w.b_out, d, d, GV_RESID);
