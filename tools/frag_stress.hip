@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
 
   struct Shape { const char* name; int N, K, flags, ksplit, kind; };      // kind 0 = one problem, 1 = the three-problem fold launch
   const Shape shapes[] = {{"QKV 3840x1280 LN+scatter", 3 * d, d, GV_LN | GV_QKV, 1, 0}, {"out 1280x1280 resid", d, d, GV_RESID, 1, 0}, {"cross-Q 1280x1280 LN f32", d, d, GV_LN | GV_OUT_F32, 1, 0},
-                          {"FFN1 5120x1280 LN+GELU image", 4 * d, d, GV_LN | GV_GELU, 1, 0}, {"FFN2 1280x5120 resid ksplit2", d, 4 * d, GV_RESID, 2, 0},
+                          {"FFN1 5120x1280 LN+GELU image", 4 * d, d, GV_LN | GV_GELU, 1, 0}, {"FFN2 1280x5120 resid ksplit2|msplit", d, 4 * d, GV_RESID, 2, 0},
                           {"vocab 51872x1280 LN f32", 51872, d, GV_LN | GV_OUT_F32, 1, 0}, {"fold3 out+qA+qB 1280x1280", d, d, 0, 1, 1}};
   auto fill_g = [&](const Shape& s, const Arena& a, int M, bool w8, GemvP* g3) {
     const int MB = (M + 15) / 16;

@@ -148,7 +148,7 @@ def smem_hazards_text(dis):
     return out
 
 
-PRELOAD_KERNELS = ("gemv_kernel", "gemv_dual_kernel", "gemv_frag_kernel", "gemv_frag2_kernel", "gemv_frag3_kernel", "dec_self_attn_kernel", "dec_cross_attn_kernel", "dec_cross_attn_rs_kernel")
+PRELOAD_KERNELS = ("gemv_kernel", "gemv_dual_kernel", "gemv_frag_kernel", "gemv_frag2_kernel", "gemv_frag3_kernel", "gemv_frag_ms_kernel", "dec_self_attn_kernel", "dec_cross_attn_kernel", "dec_cross_attn_rs_kernel")
 
 
 def kernarg_preload(co):

@@ -891,7 +891,12 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 // per-16-column partial sums the producing residual epilogue left in stat_in (summed in a fixed order: deterministic):
 //   y = rs * (W'x - mu * c) + b'.
 // Residual epilogues (GV_RESID) write the fp32 rows in place, their f16 fragment image for the next projection and the partials.
-template <int MB, int PF, bool W8>
+// MS (r6): M split - the workgroup computes MB row blocks (from p.mb0) of an image of p.mbi: a projection with few n-tiles (d x d: 80) is run by
+// (n-tile, row-block group) workgroups, each pulling ITS rows' activation fragments through its CU instead of the whole image (the phase stamps put 40-50 %
+// of such a wave's life into getting the image's requests accepted: profiles/r06_phase_cycles.md); no cross-workgroup reduction - rows are independent.
+// The row-block groups of an n-tile read the same weight fragments (ids a multiple of 8 apart: dispatched to the same XCD, whose L2 serves the repeats), so
+// the weights are requested with ordinary loads there, not non-temporal ones.
+template <int MB, int PF, bool W8, bool MS = false>
 __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, const int KS, const int ksi) {
   typedef typename WFrag<W8>::T WT;
   constexpr int EPN = (MB + 3) / 4;      // row blocks a wave finishes in the epilogue: wave w owns blocks w, w + 4 (up to 96 rows = 6 blocks)
@@ -905,17 +910,18 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
   // phase stamps of ONE wave (tap builds only; stamp() is empty otherwise): workgroup 0 / slice 0 / thread 0 -
   // 0 start, 1 first PF k-steps requested, 2 stream consumed (MFMA loop), 3 epilogue operands requested + partial sums in LDS + barrier,
   // 4 K-split merge passed (ticket), 5 epilogue done
-  unsigned long long* pf = (nt == 0 && ksi == 0 && tid == 0) ? p.prof : nullptr;
+  unsigned long long* pf = (nt == 0 && ksi == 0 && tid == 0 && (!MS || p.mb0 == 0)) ? p.prof : nullptr;
   stamp(pf, 0);
   const WT* wq = reinterpret_cast<const WT*>(p.Wp) + ((size_t)nt * wks + p.wk0 + (size_t)(ksi * 4 + wave) * S) * 64 + lane;
-  const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + (size_t)(ksi * 4 + wave) * S * MB * 64 + lane;
+  const int MBI = MS ? p.mbi : MB, mb0 = MS ? p.mb0 : 0;      // row blocks of the image, this workgroup's first
+  const u32x4* xq = reinterpret_cast<const u32x4*>(p.x) + ((size_t)(ksi * 4 + wave) * S * MBI + mb0) * 64 + lane;
   WT a[PF]; u32x4 b[PF][MB];
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     if (u < S) {
-      a[u] = __builtin_nontemporal_load(wq + (size_t)u * 64);
+      a[u] = MS ? wq[(size_t)u * 64] : __builtin_nontemporal_load(wq + (size_t)u * 64);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(u * MB + mb) * 64];
+      for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(u * MBI + (MS && mb0 + mb >= MBI ? 0 : mb)) * 64];      // (a ragged last group: a valid block, its sums discarded)
     }
   }
   stamp(pf, 1);
@@ -931,9 +937,9 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
         for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, *reinterpret_cast<const f16x8*>(&b[u][mb]), acc[mb], 0, 0, 0);
         const int nx = base + u + PF;
         if (nx < S) {
-          a[u] = __builtin_nontemporal_load(wq + (size_t)nx * 64);
+          a[u] = MS ? wq[(size_t)nx * 64] : __builtin_nontemporal_load(wq + (size_t)nx * 64);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(nx * MB + mb) * 64];
+          for (int mb = 0; mb < MB; ++mb) b[u][mb] = xq[(size_t)(nx * MBI + (MS && mb0 + mb >= MBI ? 0 : mb)) * 64];
         }
       }
     }
@@ -961,7 +967,7 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
 #pragma unroll
   for (int e = 0; e < EPN; ++e) {
     const int mb = wave + 4 * e;
-    ep_act[e] = mb < MB; ep_m[e] = mb * 16 + l15; ep_ok[e] = ep_act[e] && ep_m[e] < M && ep_n < p.N;
+    ep_act[e] = mb < MB && (!MS || mb0 + mb < MBI); ep_m[e] = (mb0 + mb) * 16 + l15; ep_ok[e] = ep_act[e] && ep_m[e] < M && ep_n < p.N;
     ep_res[e] = make_float4(0.f, 0.f, 0.f, 0.f); ep_slot[e] = 0; ep_pos[e] = 0; s1[e] = 0.f; s2[e] = 0.f; sc0[e] = 0.f;
     if (ep_act[e]) {
       const int mm = ep_m[e] < M ? ep_m[e] : M - 1;
@@ -1103,6 +1109,11 @@ template <int MB, int PF, bool W8>
 __global__ __launch_bounds__(256) void gemv_frag_kernel(const void* l_x, const f16* l_Wp, int l_M, int l_N, int l_K, int l_wks, int l_wk0, int KS, GemvP p) {
   p.x = l_x; p.Wp = l_Wp; p.M = l_M; p.N = l_N; p.K = l_K; p.wks = l_wks; p.wk0 = l_wk0;      // (KS = gridDim.y, passed: the hidden grid-size arguments are a kernarg load too)
   gemv_frag_body<MB, PF, W8>(p, blockIdx.x, KS, blockIdx.y);
+}
+template <int MB, int PF, bool W8>      // the M-split form: grid (n-tiles, 1, row-block groups), MB row blocks per workgroup of an image of mbi
+__global__ __launch_bounds__(256) void gemv_frag_ms_kernel(const void* l_x, const f16* l_Wp, int l_M, int l_N, int l_K, int l_wks, int l_wk0, int mbi, GemvP p) {
+  p.x = l_x; p.Wp = l_Wp; p.M = l_M; p.N = l_N; p.K = l_K; p.wks = l_wks; p.wk0 = l_wk0; p.mbi = mbi; p.mb0 = blockIdx.z * MB;
+  gemv_frag_body<MB, PF, W8, true>(p, blockIdx.x, 1, 0);
 }
 // Up to three skinny GEMMs of one row count in ONE launch (f16 weights, no K split): workgroups [0, n0) run problem 0, the next n1
 // problem 1, the rest problem 2 - a dependent stage less per decoder layer at 9-96 rows (model.hip dec_forward_frag): the self-attention
@@ -1332,6 +1343,24 @@ int launch_gemv_frag(hipStream_t st, const GemvP& p) {
       default: set_error("gemv_frag: %d row blocks unsupported", p.xmb); return WIS_E_UNSUPPORTED;
     }
 #undef WIS_GF2
+    return WIS_OK;
+  }
+  // M split (r6): few n-tiles (<= 85: the d x d projections), no K split, 2-6 row blocks in equal groups: (n-tile, group) workgroups of 1 or 2 row blocks
+  // (WIS_FRAG_MSPLIT=0: one workgroup per n-tile, A/B switch)
+  static const bool env_ms = !(getenv("WIS_FRAG_MSPLIT") && atoi(getenv("WIS_FRAG_MSPLIT")) == 0);
+  // ... INSTEAD of a K split where one was asked for (the K = 4d projection, 80 n-tiles: two K slices were 160 workgroups of 80 KB of weights + HALF the
+  // image each and a ticket merge; three row-block groups are 240 workgroups of 160 KB + a THIRD of the image, no merge: 1.996 -> 1.936 ms per step at 8 utterances)
+  const int ms_groups = p.xmb <= 1 ? 0 : (p.xmb <= 3 ? p.xmb : (p.xmb + 1) / 2);      // groups of one row block up to 48 rows, of two beyond (the last may be ragged)
+  if (env_ms && ms_groups && npad / 16 <= 85) {
+    dim3 gm(npad / 16, 1, ms_groups), blk(256);
+    // (a 20- / 12-deep ring for the K = 5120 streams - 160 KB requested per CU instead of 64 - measured 1.930 / 1.937 vs 1.937 / 1.938 ms per step at 8 utterances
+    // and no better at 12 / 16, session r6K: what a CU takes in is capped near 64 GB/s whatever is asked for; the eight-deep ring stays)
+    const bool s10m = p.K == 1280;
+#define WIS_GFM(MBv) do { \
+    if (p.wscale) { if (s10m) hipLaunchKernelGGL((gemv_frag_ms_kernel<MBv, 10, true>), gm, blk, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, p.xmb, p); else hipLaunchKernelGGL((gemv_frag_ms_kernel<MBv, 8, true>), gm, blk, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, p.xmb, p); } \
+    else { if (s10m) hipLaunchKernelGGL((gemv_frag_ms_kernel<MBv, 10, false>), gm, blk, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, p.xmb, p); else hipLaunchKernelGGL((gemv_frag_ms_kernel<MBv, 8, false>), gm, blk, 0, st, p.x, p.Wp, p.M, p.N, p.K, p.wks, p.wk0, p.xmb, p); } } while (0)
+    if (p.xmb <= 3) WIS_GFM(1); else WIS_GFM(2);
+#undef WIS_GFM
     return WIS_OK;
   }
   dim3 grid(npad / 16, ks), block(256);

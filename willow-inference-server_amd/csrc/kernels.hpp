@@ -79,6 +79,8 @@ struct GemvP {
   // to kpart [N/16][ksplit][xmb][64] float4 and the last-arriving slice of an n-tile (ticket kcnt[N/16], zero-initialised once,
   // re-armed by the winner) adds the slices in index order and runs the epilogue
   int ksplit; float* kpart; unsigned* kcnt;
+  // M split over workgroups (launch_gemv_frag decides; set by the kernel): this workgroup's first row block and the image's row blocks
+  int mb0, mbi;
   // the weight matrix as a k-step window of a wider packed image (launch_gemv_frag / launch_gemv_frag3): wks = k-steps per n-tile of
   // the image (0: K / 32, the matrix is the whole image), wk0 = first k-step of the window
   int wks, wk0;
