@@ -27,15 +27,18 @@ ALG_B1 = {r"gemv_kernel<1, 2, 40, .* 20480": 8 * D * D,            # FFN2: all 4
           r"gemv_kernel<1, 2, 10, .* 20480": 2 * D * D,            # cross-attention output projection
           r"gemv_dual_kernel<10, 20> 40960": 6 * D * D,            # out-projection + the folded cross-Q
           r"gemv_kernel<1, 1, 20, .* 414976": 2 * 51872 * D,       # vocabulary projection (two-tile workgroups)
-          r"dec_cross_attn_kernel 30720": 2 * 2 * 1500 * D}
+          r"dec_cross_attn_kernel 30720": 2 * 2 * 1500 * D,
+          r"dec_cross_attn_rs_kernel 30720": 2 * 2 * 1500 * D}       # round 6: the role-split form (K waves / V waves)
 ALG_B8 = {"gemv_frag_kernel<3, 8, false> 40960": 8 * D * D,      # FFN2: two K slices per n-tile (grid.y = 2)
           "gemv_frag_kernel<3, 10, false> 81920": 8 * D * D, "gemv_frag_kernel<3, 10, false> 61440": 6 * D * D,
           "gemv_frag_kernel<3, 10, false> 20480": 2 * D * D, "gemv_frag_kernel<3, 10, false> 829952": 2 * 51872 * D, "dec_cross_attn_kernel 245760": 8 * 2 * 2 * 1500 * D,
           # round 4: FFN1 and the vocabulary on two-tile workgroups (160 / 1621 workgroups), out-projection + the two halves of the folded cross-Q in one launch (240 workgroups)
-          "gemv_frag2_kernel<3, 6, false> 40960": 8 * D * D, "gemv_frag2_kernel<3, 6, false> 414976": 2 * 51872 * D, "gemv_frag3_kernel<3, 10> 61440": 6 * D * D}
+          "gemv_frag2_kernel<3, 6, false> 40960": 8 * D * D, "gemv_frag2_kernel<3, 6, false> 414976": 2 * 51872 * D, "gemv_frag3_kernel<3, 10> 61440": 6 * D * D,
+          # round 6: the role-split cross-attention; the d x d projection and FFN2 split by row blocks (80 n-tiles x 3 row-block groups = 240 workgroups)
+          "dec_cross_attn_rs_kernel 245760": 8 * 2 * 2 * 1500 * D, "gemv_frag_ms_kernel<1, 10, false> 61440": 2 * D * D, "gemv_frag_ms_kernel<1, 8, false> 61440": 8 * D * D}
 TEMPLATE_NOTE = ("Template arguments: `gemv_kernel<MB, MODE, SC, RM, W8>` (MODE 1 = LayerNorm-folded projection on raw fp32 rows, MODE 2 = f16 activations; SC = compile-time k-steps per wave, 0 = "
                  "generic ring: FFN2), `gemv_dual_kernel<SCA, SCB>` (out-projection + folded cross-Q in one launch), `gemv_frag_kernel<MB, PF, W8>` (batched rows on fragment images: MB 16-row blocks, "
-                 "PF k-steps in flight), `dec_cross_attn_kernel<TPW, CM, FOLD, SPIN>` (SPIN = granule hand-off of the chunk partials), `gemm_8p_kernel<Epi, TR>` (8-phase 256 x 256 LDS-DMA GEMM, "
+                 "PF k-steps in flight), `gemv_frag_ms_kernel<MB, PF, W8>` (round 6: the same split by row blocks over workgroups - grid (n-tiles, 1, row-block groups): the d x d projection and FFN2), `dec_cross_attn_kernel<TPW, CM, FOLD, SPIN>` (SPIN = granule hand-off of the chunk partials), `dec_cross_attn_rs_kernel<SPIN, NT, NKW>` (round 6: K waves / V waves; the decode steps' cross-attention), `gemm_8p_kernel<Epi, TR>` (8-phase 256 x 256 LDS-DMA GEMM, "
                  "persistent over tiles; TR = swapped operands for the V images; EpiResid = bias + fp32 residual), `gemm_8pn_kernel<Epi>` (the same on a 128 x 256 tile: FFN1 of one utterance), `gemm_f16_kernel<Epi, BM, BN, WM, WN>` / `gemm_pp_kernel<Epi>` (register-staged tiles / ping-pong 256 x 128), `enc_attn_lazy_kernel<SPLIT>` (r4: lazy softmax reference; `enc_attn_kernel<SPLIT>` is the A/B form behind WIS_ENC_ATTN_LAZY=0), "
                  "`splitk_reduce_ln_kernel<SPLITS>`, `layernorm_kernel<AFFINE>`.  By-grid table: 20480 threads = 80 tiles (d x d; FFN2 at one utterance), 40960 = FFN2 of the batched path (two K slices), 61440 = QKV, 81920 = FFN1, 829952 = vocabulary projection.")
 

@@ -330,7 +330,10 @@ __device__ __forceinline__ void gemv_body(const GemvP& p, const int KC, const in
   static_assert(NT == 1 || (NT == 2 && MB == 1 && SC > 0), "two-tile workgroups: <= 16 rows, every fragment prefetched");
   typedef typename WFrag<W8>::T WT;
   constexpr int GV_PF = SC > 0 ? SC : 16;
-  constexpr int rows = 16;   // full MFMA A fragments (4/8-row tiles were measured: more workgroups only add prologue work)
+  // full MFMA A fragments.  4- / 8-row tiles were measured twice: packed that way (round 1) and as HALF tiles of the ordinary image (round 6: 160 workgroups
+  // addressing rows 8 h .. 8 h + 7 of every fragment for the one-utterance FFN2, 1.2152 / 1.2137 vs 1.2152 / 1.2159 ms per step, session r6L) - no gain: a
+  // wave's request costs the CU's address path the same ~50 cycles whether 64 or 32 of its lanes are active, and the stream is those requests
+  constexpr int rows = 16;
   const int M = p.M, K = p.K;
   const int xstr = KC + 8;
   f16* xs = reinterpret_cast<f16*>(smem);
