@@ -34,11 +34,12 @@ for pos in (10,):
     _lib.check(lib.wis_debug_phase_cycles(h, B, 5, pos, out.ctypes.data_as(C.POINTER(C.c_uint64))))
     for i, n in enumerate(names):
         st = [int(v) for v in out[i][:14] if v]
-        if n == "cross-attn":      # entries 0-5: workgroup (chunk 0, head 0, utterance 0), a producer; 7-13: the last chunk's workgroup, the combiner of the granule form
+        if n == "cross-attn":      # entries 0-5: workgroup (chunk 0, head 0, utterance 0) - dec_cross_attn_rs_kernel: its first K wave; 7-13: the first V wave of that workgroup
+            # (dec_cross_attn_kernel, WIS_CA_RS=0: the last chunk's workgroup, the combiner of the granule form)
             comb = [int(v) for v in out[i][7:14] if v]
             st = [int(v) for v in out[i][:6] if v]
             if comb:
-                print(f"{'cross-attn combiner':16s} pos {pos}: total {comb[-1] - comb[0]:6d} cyc; phases {[comb[j + 1] - comb[j] for j in range(len(comb) - 1)]}; starts {comb[0] - st[0]:+d} after the producer")
+                print(f"{'cross-attn V wave (WIS_CA_RS=0: combiner)':16s} pos {pos}: total {comb[-1] - comb[0]:6d} cyc; phases {[comb[j + 1] - comb[j] for j in range(len(comb) - 1)]}; starts {comb[0] - st[0]:+d} after the producer")
         if st:
             ph = [st[j + 1] - st[j] for j in range(len(st) - 1)]
             print(f"{n:16s} pos {pos}: total {st[-1] - st[0]:6d} cyc; phases {ph}")
