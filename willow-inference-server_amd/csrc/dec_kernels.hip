@@ -1493,7 +1493,11 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 // TREE (draft verification of a beam search, model.hip verify_beam_draft): the rows of the pass are nodes of a beam tree - row m's history is not
 // one slot but a path: positions < w0 in slot anc[m * aw], position w0 + t in slot anc[m * aw + t] (each node's K / V sits in the slot of the beam
 // that produced it).  One dependent load more than the plain form, on a path that runs once per 16 steps.
-template <bool TREE>
+// NB (r6): 8-position blocks requested up front and per pass of the loop: 8 (64 positions), or 2 / 4 when the caller KNOWS the histories are short (model.hip picks the
+// step graph by the step index: every row of a decode pass has the same length) - the kernel always asks for 8 NB positions of K and V per (row, head), whatever the
+// length (the addresses must not wait for it), so at 8 utterances its 800 waves put 13 600 wave requests through the CUs' address paths for histories of ~20 positions;
+// any NB is correct for any length (the loop goes on in steps of 8 NB positions)
+template <bool TREE, int NB>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc,
                                                            const int* __restrict__ pos, int d, int ctx, int rpu, int sstride, int rmul,
                                                            f16* __restrict__ out, unsigned long long* prof, int out_mb,
@@ -1521,20 +1525,20 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   const int hoff = h * 64 + 8 * c;
   const f16* krow = kc + (size_t)ls * ctx * d + hoff;
   const f16* vrow = vc + (size_t)ls * ctx * d + hoff;
-  u32x4 kr[8], vr[8];
+  u32x4 kr[NB], vr[NB];
   if (!TREE) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)(8 * i + pl) * d);      // ctx >= 64: in bounds
+    for (int i = 0; i < NB; ++i) kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)(8 * i + pl) * d);      // ctx >= 64: in bounds
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(8 * i + pl) * d);
+    for (int i = 0; i < NB; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vrow + (size_t)(8 * i + pl) * d);
   } else {
-    int sl[8];
+    int sl[NB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sl[i] = slot_of(8 * i + pl);
+    for (int i = 0; i < NB; ++i) sl[i] = slot_of(8 * i + pl);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)sl[i] * ctx + 8 * i + pl) * d + hoff);
+    for (int i = 0; i < NB; ++i) kr[i] = *reinterpret_cast<const u32x4*>(kc + ((size_t)sl[i] * ctx + 8 * i + pl) * d + hoff);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)sl[i] * ctx + 8 * i + pl) * d + hoff);
+    for (int i = 0; i < NB; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)sl[i] * ctx + 8 * i + pl) * d + hoff);
   }
   stamp(pf, 1);
   float m_run = -INFINITY, l_run = 0.f;
@@ -1545,10 +1549,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
   // BEFORE it issues the q / K / V loads above; the first block is unconditional, len >= 1)
   int p0 = 0;
   do {
-    if (p0 > 0) {   // histories beyond 64 positions: next block (not prefetched).  Unconditional loads from a clamped position (masked
+    if (p0 > 0) {   // histories beyond 8 NB positions: next block (not prefetched).  Unconditional loads from a clamped position (masked
                     // below): guarded per position, hipcc serialised the sixteen loads into eight wait-for-the-last-pair round trips
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NB; ++i) {
         const int p = p0 + 8 * i + pl, pc = p < len ? p : len - 1;
         if (!TREE) {
           kr[i] = *reinterpret_cast<const u32x4*>(krow + (size_t)pc * d);
@@ -1560,9 +1564,9 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
         }
       }
     }
-    float sc[8]; float mx = -INFINITY;
+    float sc[NB]; float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int p = p0 + 8 * i + pl;
       float dot = 0.f;
       if (p < len) {
@@ -1581,7 +1585,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] *= alpha;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const float pw = __expf(sc[i] - m_new);     // 0 for masked positions
       lsum += pw;
       if (p0 + 8 * i + pl < len) {
@@ -1592,7 +1596,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
     }
     l_run = l_run * alpha + wave_sum(lsum) * 0.125f;   // every position is replicated on its 8 chunk lanes
     m_run = m_new;
-    p0 += 64;
+    p0 += 8 * NB;
   } while (p0 < len);
   stamp(pf, 2);
   // reduce acc over the 8 position slots: xor 8 inside the 16-lane row by DPP, the four rows through LDS
@@ -1611,13 +1615,17 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const float* __restri
 }
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof, int out_mb,
-                         const int* anc, int w0, int aw, const int* base) {
+                         const int* anc, int w0, int aw, const int* base, int nb) {
   if (ctx > 512 || ctx < 64) { set_error("dec_self_attn: ctx=%d outside [64, 512]", ctx); return WIS_E_UNSUPPORTED; }
   if (anc) {
     if (aw < 1) { set_error("dec_self_attn: ancestor table of width %d", aw); return WIS_E_ARG; }
-    hipLaunchKernelGGL(dec_self_attn_kernel<true>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
-  } else
-    hipLaunchKernelGGL(dec_self_attn_kernel<false>, dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
+    hipLaunchKernelGGL((dec_self_attn_kernel<true, 8>), dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
+  } else if (nb == 2)
+    hipLaunchKernelGGL((dec_self_attn_kernel<false, 2>), dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
+  else if (nb == 4)
+    hipLaunchKernelGGL((dec_self_attn_kernel<false, 4>), dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
+  else
+    hipLaunchKernelGGL((dec_self_attn_kernel<false, 8>), dim3(M, H), dim3(64), 0, st, q, kc, vc, pos, d, ctx, rpu, sstride, rmul, out, prof, out_mb, anc, w0, aw, base);
   return WIS_OK;
 }
 

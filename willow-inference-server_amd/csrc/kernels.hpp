@@ -122,7 +122,7 @@ int launch_dec_embed(hipStream_t st, const f16* emb, const f16* pos_emb, const i
 // the cache rows of positions < w0 from slot anc[m * aw] and position w0 + t from slot anc[m * aw + t] (its ancestor at window step t)
 int launch_dec_self_attn(hipStream_t st, const float* q, const f16* kc, const f16* vc, const int* pos, f16* out,
                          int M, int H, int d, int ctx, int rpu, int sstride, int rmul, unsigned long long* prof = nullptr, int out_mb = 0,
-                         const int* anc = nullptr, int w0 = 0, int aw = 0, const int* base = nullptr);      // base (optional): slot of the positions before w0, per row
+                         const int* anc = nullptr, int w0 = 0, int aw = 0, const int* base = nullptr, int nb = 8);      // nb: 8-position blocks per pass (2 / 4 / 8; plain form only)      // base (optional): slot of the positions before w0, per row
 // cross attention of R rows per utterance over the utterance's T encoder keys.
 //   q f32 [B*R][d] (pre-scaled), kx f16 [B][H][8][T][8], vt f16 [B][H][64][Tpad] (zero padded) -> out f16 [B*R][d]
 // gran / epoch (optional): the granule hand-off of small grids (dec_kernels.hip, SPIN): gran = 8-byte slots [B*H][6][8][66], epoch =

@@ -114,7 +114,7 @@ struct DecLayerW {
 };
 
 struct GraphKey {
-  int B, beam, P, max_new, fixed_new, suppress_blank, suppress_default, early_exit, spin; float lp, patience;
+  int B, beam, P, max_new, fixed_new, suppress_blank, suppress_default, early_exit, spin, sa_nb; float lp, patience;
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -153,6 +153,7 @@ struct wis_model {
   // decode state
   float *dx, *dq, *logits, *part; f16 *dao, *dh, *dln; unsigned* counters;
   float* dq2 = nullptr;         // batched fold: second half of the cross-attention q_raw (dec_forward_frag)
+  int sa_nb = 8;      // 8-position blocks the step's self-attention asks for per pass (generate_impl: by the step index; 8 outside the decode loop)
   float* gf_part = nullptr; unsigned* gf_cnt = nullptr; int gf_ksplit = 1;      // K split of the batched FFN2 skinny GEMM: slice sums, tickets (GemvP::ksplit)
   unsigned long long* ca_gran = nullptr; unsigned* ca_epoch = nullptr;      // granule hand-off of the decoder cross-attention (small grids): slots, flag + epochs
   unsigned long long* sa_gran = nullptr; unsigned* sa_epoch = nullptr;      // ... of q / k / v from the QKV projection to the self-attention fused into its launch: slots [H][8][3][64], epochs [H]
@@ -732,7 +733,7 @@ static int dec_forward_frag(wis_model* m, int M, int R, int B, bool want_logits,
     g.csum = w.c_qkv; g.stat_in = m->dstat; g.q = m->dq; g.kc = m->kc[l]; g.vc = m->vc[l]; g.slot = m->rm.slot; g.pos = m->rm.pos; g.d = d; g.ctx = ctx;
     g.prof = pr;
     WIS_RET(launch_gemv_frag(st, g));
-    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB, tw ? tw->anc : nullptr, tw ? tw->w0 : 0, tw ? tw->aw : 0, tw ? tw->base : nullptr));
+    WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->daoxf, M, H, d, ctx, R, sstride, rmul, nullptr, MB, tw ? tw->anc : nullptr, tw ? tw->w0 : 0, tw ? tw->aw : 0, tw ? tw->base : nullptr, m->sa_nb));
     if (fold) {
       // ONE launch, three d x d problems on 3 d / 16 workgroups: x1 = x0 + Wo a + bo (residual rows + their LayerNorm partials; nobody
       // reads x1's fragment image any more, so none is written and x0's image stays valid for the other two), q_A = W'q x0 + W'q bo
@@ -826,7 +827,7 @@ int dec_forward(wis_model* m, int M, int R, int B, bool want_logits, int sstride
     g.rows = gemv_rows_for(g.N == m->n_vocab_pad ? m->cfg.n_vocab : g.N, g.K);
     if (sa_fuse && !lnp && !ln16) { g.sa_gran = m->sa_gran; g.sa_epoch = m->sa_epoch; g.sa_flag = m->ca_epoch; g.sa_out = m->dao; g.sa_rpu = R; g.sa_sstride = sstride; }
     WIS_RET(launch_ln_gemv(m, st, g));
-    if (!g.sa_gran) WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr));
+    if (!g.sa_gran) WIS_RET(launch_dec_self_attn(st, m->dq, m->kc[l], m->vc[l], m->rm.pos, m->dao, M, H, d, ctx, R, sstride, rmul, pr ? pr + 16 : nullptr, 0, nullptr, 0, 0, nullptr, m->sa_nb));
     if (fold) {
       // ONE launch: x1 = x0 + Wo a + bo (tiles [0, d/16)) and q_raw = W'q x0 + (W'q Wo) a + W'q bo (the other d/16 tiles); the
       // cross-attention kernel applies the LayerNorm statistics of x1 (rs, mu) and b' to q_raw
@@ -1376,26 +1377,40 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     WIS_RET(launch_kv_reorder(st, m->kc_all, m->vc_all, m->kv_layer_stride, c.n_dec_layers, m->bs, B, beam, P, ctx, c.d_model));
     return WIS_OK;
   };
-  hipGraphExec_t gexec = nullptr;
-  if (m->use_graph) {
+  // The step graph comes in up to three forms that differ in ONE kernel argument set: how many 8-position blocks of its rows' K / V history the self-attention
+  // asks for (dec_self_attn_kernel NB).  Every row of the pass that follows s beam steps has P + s positions - known HERE, by the step index, although the graph's
+  // kernel arguments are frozen - so the pass is launched from the graph whose self-attention asks for 16 / 32 / 64 positions (WIS_SA_NB=0: always 64, A/B switch).
+  static const bool sa_short = !(getenv("WIS_SA_NB") && atoi(getenv("WIS_SA_NB")) == 0);
+  auto nb_for = [&](int passes_done) { const int len = P + passes_done; return !sa_short ? 8 : (len <= 16 ? 2 : (len <= 32 ? 4 : 8)); };
+  struct NbReset { wis_model* m; ~NbReset() { m->sa_nb = 8; } } nb_reset{m};      // (everything outside this loop - prefill, verification windows, taps - asks for 64)
+  auto graph_for = [&](int nb, hipGraphExec_t* out) -> int {
     GraphKey key; memset(&key, 0, sizeof(key));
     key.B = B; key.beam = beam; key.P = P; key.max_new = max_new; key.fixed_new = sc.fixed_new; key.suppress_blank = sc.suppress_blank;
     key.suppress_default = o->suppress_default; key.early_exit = sc.allow_early_exit; key.lp = sc.length_penalty; key.patience = patience; key.spin = (m->spin_now ? 1 : 0) | (sa_fuse_enabled() ? 2 : 0);
+    key.sa_nb = nb;
     auto it = m->graphs.find(key);
-    if (it != m->graphs.end()) gexec = it->second;
-    else {
-      hipGraph_t graph = nullptr;
-      WIS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      int rc = one_step();
-      hipError_t e = hipStreamEndCapture(st, &graph);
-      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-      if (e != hipSuccess) { set_error("graph capture failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
-      e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-      hipGraphDestroy(graph);
-      if (e != hipSuccess) { set_error("graph instantiate failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
-      m->graphs[key] = gexec;
-    }
-  }
+    if (it != m->graphs.end()) { *out = it->second; return WIS_OK; }
+    hipGraph_t graph = nullptr; hipGraphExec_t ge = nullptr;
+    WIS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = one_step();
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { set_error("graph capture failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+    e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { set_error("graph instantiate failed: %s", hipGetErrorString(e)); return WIS_E_HIP; }
+    m->graphs[key] = ge;
+    *out = ge;
+    return WIS_OK;
+  };
+  auto launch_pass = [&](int passes_done) -> int {      // the decoder pass + sampling that follows `passes_done` passes
+    m->sa_nb = nb_for(passes_done);
+    if (!m->use_graph) return one_step();
+    hipGraphExec_t ge = nullptr;
+    WIS_RET(graph_for(m->sa_nb, &ge));
+    WIS_HIP_CHECK(hipGraphLaunch(ge, st));
+    return WIS_OK;
+  };
   int needed = 0;           // steps after which the last utterance had finished (natural termination)
   bool gave_up = false, from_host = false;
   float decode_ms_dev = -1.f;
@@ -1412,7 +1427,7 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
     needed = steps;
   } else if (known) {
     // every step goes out in one burst: nothing to find out from the device before the last one
-    for (; steps < limit; ++steps) { if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step()); }
+    for (; steps < limit; ++steps) WIS_RET(launch_pass(steps));
     WIS_HIP_CHECK(hipEventRecord(m->ev[5], st));
     WIS_HIP_CHECK(hipStreamSynchronize(st));
     int st_, dn_, gu_; unpack(__atomic_load_n(&m->h_prog[HP_REC], __ATOMIC_ACQUIRE), &st_, &dn_, &gu_);
@@ -1440,7 +1455,7 @@ static int generate_impl(wis_model_t* m, const float* input, int B, const int32_
       if (st_ >= limit) break;                 // (cannot happen: the max_new-th step finishes every utterance)
       if (steps < limit && steps - st_ < depth) {
         const auto tl0 = std::chrono::steady_clock::now();
-        if (gexec) WIS_HIP_CHECK(hipGraphLaunch(gexec, st)); else WIS_RET(one_step());
+        WIS_RET(launch_pass(steps));
         ++steps;
         if (trace) tr.push_back({-steps, 0ull, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count(), steps});      // (negative step: a launch, host_us = its duration)
         continue;
