@@ -2079,6 +2079,9 @@ __device__ __forceinline__ void st_gran2(gran_t* p, unsigned tag, float v0, floa
   const u32x4 g = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
   asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
 }
+// (Measured and not kept, round 6: the folded query finished ONCE per workgroup by the first V wave - which has nothing to ask for before the barrier - instead of by
+// every K wave for itself, 81 instead of 96 wave requests per workgroup: 1.222 / 1.219 vs 1.204 / 1.205 ms per step at one utterance - the K waves then wait for a
+// wave that started later - and 1.863 / 1.874 / 1.881 / 1.888 vs 1.880 / 1.885 / 1.883 / 1.886 at eight: nothing; sessions r6R / r6S.)
 // NKW = K waves = V waves per workgroup: 2 (256 threads, four workgroups per CU: the batched step's 960 workgroups in one round) or 4 (512 threads: the
 // one-utterance step's 120 workgroups have a CU each - twice the waves put the workgroup's 160 requests into the CU's address path in half the time, and
 // every K wave has half the scores and exponentials to take: its path - requests, query, scores, softmax - is the critical one there)
