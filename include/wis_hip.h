@@ -236,7 +236,9 @@ typedef struct {
 int wis_last_timing(const wis_model_t* m, wis_timing_t* t);
 
 /* ---- tuning tap: shader-clock stamps of the phases of decoder layer 0's kernels for one decode forward at
- * text position `pos` (out: [6][16] uint64: QKV gemv, out-proj gemv, cross-attn, self-attn, FFN1 gemv, FFN2 gemv) */
+ * text position `pos` (out: [6][16] uint64: QKV gemv, out-proj gemv, cross-attn, self-attn, FFN1 gemv, FFN2 gemv; more than 8 rows: the
+ * batched-row kernels, the fourth row is the cross-attention output projection; the cross-attention row carries two stamp sets, entries 0-5 and 7-13:
+ * the first K wave and the first V wave of workgroup (0, 0, 0)) */
 int wis_debug_phase_cycles(wis_model_t* m, int B, int beam, int pos, uint64_t* out);
 
 /* ---- tuning tap: device timeline of one decode forward (B x beam rows at text position `pos`): for each of the
