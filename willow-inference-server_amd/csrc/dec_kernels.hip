@@ -894,6 +894,20 @@ int launch_gemv(hipStream_t st, const GemvP& p) {
 // per-16-column partial sums the producing residual epilogue left in stat_in (summed in a fixed order: deterministic):
 //   y = rs * (W'x - mu * c) + b'.
 // Residual epilogues (GV_RESID) write the fp32 rows in place, their f16 fragment image for the next projection and the partials.
+// A lane's quarter of a row's LayerNorm partials at K = 1280: 20 (sum, M2) pairs = 160 contiguous bytes, taken as TEN 16-byte loads requested together (they were 20
+// eight-byte loads - in the two-tile kernel issued four at a time, five dependent rounds in the kernel's tail; a wave request costs the CU's address path the same
+// whatever it carries); merged in pair order: the sums come out bit for bit as before.
+__device__ __forceinline__ void ln_partials20(const float2* sp, float c, float& s1, float& s2) {
+  const float4* sp4 = reinterpret_cast<const float4*>(sp);
+  float4 v[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) v[i] = sp4[i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const float dm0 = v[i].x * 0.0625f - c; s1 += dm0; s2 += v[i].y + 16.0f * dm0 * dm0;
+    const float dm1 = v[i].z * 0.0625f - c; s1 += dm1; s2 += v[i].w + 16.0f * dm1 * dm1;
+  }
+}
 // MS (r6): M split - the workgroup computes MB row blocks (from p.mb0) of an image of p.mbi: a projection with few n-tiles (d x d: 80) is run by
 // (n-tile, row-block group) workgroups, each pulling ITS rows' activation fragments through its CU instead of the whole image (the phase stamps put 40-50 %
 // of such a wave's life into getting the image's requests accepted: profiles/r06_phase_cycles.md); no cross-workgroup reduction - rows are independent.
@@ -980,11 +994,7 @@ __device__ __forceinline__ void gemv_frag_body(const GemvP& p, const int nt, con
         const float c = row[0].x * 0.0625f;
         sc0[e] = c;
         if (PF == 10) {      // K = 1280: the lane's 20 pairs, all requested at once
-          float2 spr[20];
-#pragma unroll
-          for (int i = 0; i < 20; ++i) spr[i] = sp[i];
-#pragma unroll
-          for (int i = 0; i < 20; ++i) { const float dm = spr[i].x * 0.0625f - c; s1[e] += dm; s2[e] += spr[i].y + 16.0f * dm * dm; }
+          ln_partials20(sp, c, s1[e], s2[e]);
         } else {
 #pragma unroll 4
           for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; const float dm = v.x * 0.0625f - c; s1[e] += dm; s2[e] += v.y + 16.0f * dm * dm; }
@@ -1219,8 +1229,11 @@ __global__ __launch_bounds__(256) void gemv_frag2_kernel(WIS_GV_LEAD_DECL(l_), G
       const float2* sp = row + (size_t)kq * nq;
       const float c = row[0].x * 0.0625f;
       sc0[e] = c;
+      if (nq == 20) ln_partials20(sp, c, s1[e], s2[e]);      // (uniform: K = 1280)
+      else {
 #pragma unroll 4
-      for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; const float dm = v.x * 0.0625f - c; s1[e] += dm; s2[e] += v.y + 16.0f * dm * dm; }
+        for (int i = 0; i < nq; ++i) { const float2 v = sp[i]; const float dm = v.x * 0.0625f - c; s1[e] += dm; s2[e] += v.y + 16.0f * dm * dm; }
+      }
       if ((p.flags & GV_QKV) && ep_m[e] < M) { ep_slot[e] = p.slot[ep_m[e]]; ep_pos[e] = p.pos[ep_m[e]]; }
     }
   }
